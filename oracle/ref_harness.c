@@ -1,0 +1,104 @@
+/* TEST INFRASTRUCTURE ONLY -- see oracle/README.md.
+ *
+ * Driver TU for building the *reference's own* hot-path objects
+ * (/root/reference, compiled in place, nothing copied) into oracle/_ref/.
+ *
+ * It instantiates tmLQCD's globals through the reference's own mechanism
+ * (global.h:54-58: "#if defined INIT_GLOBALS -> EXTERN is empty"), which in a
+ * normal tmLQCD build happens inside the flex-generated parser (read_input.l:55).
+ * The init order below follows benchmark.c:127-259 and the scalar branch of
+ * tmlqcd_mpi_init (mpi_init.c:748-778).
+ *
+ * No reference algorithm is restated here: everything numerical that this
+ * library does is executed by object code compiled from /root/reference.
+ */
+#define INIT_GLOBALS
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#ifdef TM_USE_OMP
+#include <omp.h>
+#endif
+#include "global.h"
+#include "su3.h"
+#include "geometry_eo.h"
+#include "boundary.h"
+#include "start.h"
+extern double X0, X1, X2, X3; /* boundary.c:37 */
+#include "init/init_gauge_field.h"
+#include "init/init_geometry_indices.h"
+#ifdef TM_USE_OMP
+#include "init/init_omp_accumulators.h"
+#endif
+
+static spinor *tmref_spinor_base = NULL;
+static int tmref_nfields = 0;
+
+/* Set lattice, allocate fields, build index tables and boundary phases. */
+int tmref_init(int T_, int LX_, int LY_, int LZ_, double kappa, double mu,
+               int nfields, int nthreads) {
+  g_nproc = 1; g_proc_id = 0; g_nproc_x = g_nproc_y = g_nproc_z = g_nproc_t = 1;
+  g_cart_id = 0; g_stdio_proc = 0;
+  g_proc_coords[0] = g_proc_coords[1] = g_proc_coords[2] = g_proc_coords[3] = 0;
+  T_global = T_; T = T_; L = LX_; LX = LX_; LY = LY_; LZ = LZ_;
+  VOLUME = T * LX * LY * LZ; SPACEVOLUME = VOLUME / T;
+  RAND = 0; EDGES = 0; VOLUMEPLUSRAND = VOLUME; SPACERAND = 0;
+  N_PROC_T = N_PROC_X = N_PROC_Y = N_PROC_Z = 1;
+  g_dbw2rand = 0; lowmem_flag = 0; g_debug_level = 0;
+  g_kappa = kappa; g_mu = mu; g_c_sw = 0.0; g_rgi_C1 = 1.;
+  g_sloppy_precision = 0; g_sloppy_precision_flag = 0;
+  X0 = X1 = X2 = X3 = 0.0;
+  DUM_DERI = nfields - 4; DUM_MATRIX = nfields - 3; NO_OF_SPINORFIELDS = nfields;
+#ifdef TM_USE_OMP
+  omp_num_threads = nthreads > 0 ? nthreads : 1;
+  omp_set_num_threads(omp_num_threads);
+  init_omp_accumulators(omp_num_threads);
+#else
+  (void)nthreads;
+#endif
+  if (init_gauge_field(VOLUMEPLUSRAND + g_dbw2rand, 1) != 0) return 1;
+  if (init_geometry_indices(VOLUMEPLUSRAND + g_dbw2rand) != 0) return 2;
+  /* spinor fields: one block, field i = base + i*VOLUMEPLUSRAND (full-lattice
+     sized so the same fields serve D_psi and the e/o operators) */
+  tmref_nfields = nfields;
+  tmref_spinor_base = (spinor *)calloc((size_t)nfields * VOLUMEPLUSRAND + 1, sizeof(spinor));
+  g_spinor_field = (spinor **)calloc(nfields, sizeof(spinor *));
+  if (!tmref_spinor_base || !g_spinor_field) return 3;
+  for (int i = 0; i < nfields; i++) g_spinor_field[i] = tmref_spinor_base + (size_t)i * VOLUMEPLUSRAND;
+  geometry();
+  boundary(g_kappa);
+  return 0;
+}
+
+void tmref_set_theta(double x0, double x1, double x2, double x3) {
+  X0 = x0; X1 = x1; X2 = x2; X3 = x3;
+  boundary(g_kappa);
+}
+
+void tmref_set_kappa_mu(double kappa, double mu) {
+  g_kappa = kappa; g_mu = mu;
+  boundary(g_kappa);
+}
+
+/* benchmark.c:247-259 */
+void tmref_random_fields(int seed) {
+  start_ranlux(1, seed);
+  random_gauge_field(1, g_gauge_field);
+  random_spinor_field_eo(g_spinor_field[0], 1, RN_GAUSS);
+}
+
+void tmref_random_spinor_eo(int i) { random_spinor_field_eo(g_spinor_field[i], 1, RN_GAUSS); }
+
+su3 *tmref_gauge(void) { return &g_gauge_field[0][0]; }
+spinor *tmref_spinor(int i) { return g_spinor_field[i]; }
+int *tmref_hi(void) { return g_hi; }
+int *tmref_eo2lexic(void) { return g_eo2lexic; }
+int *tmref_lexic2eosub(void) { return g_lexic2eosub; }
+void tmref_mark_gauge_dirty(void) { g_update_gauge_copy = 1; }
+int tmref_threads(void) {
+#ifdef TM_USE_OMP
+  return omp_num_threads;
+#else
+  return 1;
+#endif
+}

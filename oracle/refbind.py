@@ -1,0 +1,115 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+
+ctypes binding of oracle/_ref/libtmref*.so = the reference's own hot-path object
+code (built in place from /root/reference by oracle/Makefile, never copied).
+Used (a) to pin oracle/tm_oracle.c, (b) to generate tests/golden/*.npz,
+(c) as bench.py's `cpu_baseline` with kind "reference".
+
+One lattice per process: the reference keeps its state in C globals
+(global.h:66-260), so `RefLattice` may be constructed once per library.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MATRIX_MULT = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
+def ref_path(omp=False):
+    return os.path.join(_HERE, "_ref", "libtmref_omp.so" if omp else "libtmref.so")
+
+
+def ref_available(omp=False):
+    return os.path.exists(ref_path(omp))
+
+
+class RefLattice:
+    def __init__(self, T, LX, LY, LZ, kappa=0.125, mu=0.0, nfields=12, omp=False, threads=1):
+        self.lib = lib = C.CDLL(ref_path(omp))
+        self.T, self.LX, self.LY, self.LZ = T, LX, LY, LZ
+        self.V = T * LX * LY * LZ
+        self.nfields = nfields
+        lib.tmref_init.argtypes = [C.c_int] * 4 + [C.c_double] * 2 + [C.c_int] * 2
+        lib.tmref_gauge.restype = C.c_void_p
+        lib.tmref_spinor.restype = C.c_void_p
+        lib.tmref_spinor.argtypes = [C.c_int]
+        lib.tmref_hi.restype = C.c_void_p
+        lib.tmref_eo2lexic.restype = C.c_void_p
+        lib.tmref_lexic2eosub.restype = C.c_void_p
+        lib.tmref_set_theta.argtypes = [C.c_double] * 4
+        lib.tmref_set_kappa_mu.argtypes = [C.c_double] * 2
+        for name in ("Hopping_Matrix", "Hopping_Matrix_nocom"):
+            getattr(lib, name).argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+            getattr(lib, name).restype = None
+        lib.square_norm.restype = C.c_double
+        lib.square_norm.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.scalar_prod_r.restype = C.c_double
+        lib.scalar_prod_r.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        lib.assign_add_mul_r.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int]
+        lib.assign_mul_add_r.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+        lib.assign_mul_add_r_and_square.restype = C.c_double
+        lib.assign_mul_add_r_and_square.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
+        lib.diff.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.assign.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.gamma5.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        for name in ("Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi",
+                     "D_psi", "Q_pm_psi", "Q_plus_psi", "Q_minus_psi"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
+            getattr(lib, name).restype = None
+        lib.M_full.argtypes = [C.c_void_p] * 4
+        lib.H_eo_tm_inv_psi.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+        for name in ("mul_one_pm_imu_inv",):
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_double, C.c_int]
+        for name in ("assign_mul_one_pm_imu_inv", "assign_mul_one_pm_imu"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int]
+        lib.mul_one_pm_imu_sub_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int]
+        lib.mul_one_pm_imu_sub_mul_gamma5.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        # complex double by value: SysV passes (re, im) as two consecutive doubles in SSE regs
+        lib.tm_times_Hopping_Matrix.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+        lib.tm_sub_Hopping_Matrix.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+        lib.cg_her.restype = C.c_int
+        lib.cg_her.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p]
+        rc = lib.tmref_init(T, LX, LY, LZ, kappa, mu, nfields, threads)
+        if rc != 0:
+            raise RuntimeError("tmref_init failed: %d" % rc)
+        self.threads = lib.tmref_threads()
+
+    # ---- raw views onto the reference's own arrays (no copies) ----
+    def gauge(self):
+        """g_gauge_field as float64 [V][4][3][3][2] (lexicographic site, mu=t,x,y,z; su3.h:40-43)."""
+        n = self.V * 4 * 18
+        buf = (C.c_double * n).from_address(self.lib.tmref_gauge())
+        return np.frombuffer(buf, dtype=np.float64).reshape(self.V, 4, 3, 3, 2)
+
+    def spinor(self, i, nsites=None):
+        """g_spinor_field[i] as float64 [nsites][4][3][2] (su3.h:60-63)."""
+        nsites = nsites or self.V
+        buf = (C.c_double * (nsites * 24)).from_address(self.lib.tmref_spinor(i))
+        return np.frombuffer(buf, dtype=np.float64).reshape(nsites, 4, 3, 2)
+
+    def sp(self, i):
+        return self.lib.tmref_spinor(i)
+
+    def hi(self):
+        buf = (C.c_int * (16 * self.V)).from_address(self.lib.tmref_hi())
+        return np.frombuffer(buf, dtype=np.int32).reshape(self.V, 16)
+
+    def eo2lexic(self):
+        buf = (C.c_int * self.V).from_address(self.lib.tmref_eo2lexic())
+        return np.frombuffer(buf, dtype=np.int32)
+
+    def random_fields(self, seed=123456):
+        self.lib.tmref_random_fields(seed)
+
+    def set_kappa_mu(self, kappa, mu):
+        self.lib.tmref_set_kappa_mu(kappa, mu)
+
+    def set_theta(self, x0, x1, x2, x3):
+        self.lib.tmref_set_theta(x0, x1, x2, x3)
+
+    def mark_gauge_dirty(self):
+        self.lib.tmref_mark_gauge_dirty()
+
+    def fnptr(self, name):
+        return C.cast(getattr(self.lib, name), C.c_void_p)

@@ -1,0 +1,647 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU oracle for the tmLQCD hot path (see tm_oracle.h).
+ *
+ * Restates, in plain C99, the algorithm of the reference's generic-C code path
+ * (_GAUGE_COPY build, no SSE/BG intrinsics).  Every function cites the reference
+ * file:line it follows (paths relative to /root/reference).  Floating-point
+ * operation order follows the reference macros so that, built without FMA
+ * contraction, results agree with oracle/_ref/libtmref.so to the last bit or two.
+ */
+#include "tm_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TMO_MAX_THREADS 1024
+static int tmo_threads = 1;
+
+void tmo_set_threads(int n) {
+  if (n < 1) n = 1;
+  if (n > TMO_MAX_THREADS) n = TMO_MAX_THREADS;
+  tmo_threads = n;
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#endif
+}
+int tmo_get_threads(void) { return tmo_threads; }
+
+/* ---------------------------------------------------------------- su3.h macros */
+/* su3.h:197-217 */
+static inline tmo_su3_vector v_add(tmo_su3_vector a, tmo_su3_vector b) {
+  tmo_su3_vector r = {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; return r; }
+static inline tmo_su3_vector v_sub(tmo_su3_vector a, tmo_su3_vector b) {
+  tmo_su3_vector r = {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; return r; }
+static inline tmo_su3_vector v_i_add(tmo_su3_vector a, tmo_su3_vector b) {
+  tmo_su3_vector r = {a.c0 + I * b.c0, a.c1 + I * b.c1, a.c2 + I * b.c2}; return r; }
+static inline tmo_su3_vector v_i_sub(tmo_su3_vector a, tmo_su3_vector b) {
+  tmo_su3_vector r = {a.c0 - I * b.c0, a.c1 - I * b.c1, a.c2 - I * b.c2}; return r; }
+/* su3.h:272-275 */
+static inline tmo_su3_vector c_times_v(double _Complex c, tmo_su3_vector s) {
+  tmo_su3_vector r = {c * s.c0, c * s.c1, c * s.c2}; return r; }
+static inline tmo_su3_vector cc_times_v(double _Complex c, tmo_su3_vector s) {
+  tmo_su3_vector r = {conj(c) * s.c0, conj(c) * s.c1, conj(c) * s.c2}; return r; }
+/* su3.h:308-311 */
+static inline tmo_su3_vector su3_mul(const tmo_su3 *u, tmo_su3_vector s) {
+  tmo_su3_vector r;
+  r.c0 = u->c00 * s.c0 + u->c01 * s.c1 + u->c02 * s.c2;
+  r.c1 = u->c10 * s.c0 + u->c11 * s.c1 + u->c12 * s.c2;
+  r.c2 = u->c20 * s.c0 + u->c21 * s.c1 + u->c22 * s.c2;
+  return r;
+}
+/* su3.h:313-316 */
+static inline tmo_su3_vector su3_inv_mul(const tmo_su3 *u, tmo_su3_vector s) {
+  tmo_su3_vector r;
+  r.c0 = conj(u->c00) * s.c0 + conj(u->c10) * s.c1 + conj(u->c20) * s.c2;
+  r.c1 = conj(u->c01) * s.c0 + conj(u->c11) * s.c1 + conj(u->c21) * s.c2;
+  r.c2 = conj(u->c02) * s.c0 + conj(u->c12) * s.c1 + conj(u->c22) * s.c2;
+  return r;
+}
+#define V_ADD_ASSIGN(r, s)   do { (r).c0 += (s).c0; (r).c1 += (s).c1; (r).c2 += (s).c2; } while (0)
+#define V_SUB_ASSIGN(r, s)   do { (r).c0 -= (s).c0; (r).c1 -= (s).c1; (r).c2 -= (s).c2; } while (0)
+#define V_IADD_ASSIGN(r, s)  do { (r).c0 += I * (s).c0; (r).c1 += I * (s).c1; (r).c2 += I * (s).c2; } while (0)
+#define V_ISUB_ASSIGN(r, s)  do { (r).c0 -= I * (s).c0; (r).c1 -= I * (s).c1; (r).c2 -= I * (s).c2; } while (0)
+
+/* ---------------------------------------------------------------- geometry */
+/* geometry_eo.c:279-299 (the "original" Index(): none / PARALLELT) */
+int tmo_index(const tmo_lattice *lat, int x0, int x1, int x2, int x3) {
+  const int T = lat->T, LX = lat->LX, LY = lat->LY, LZ = lat->LZ;
+  int y0 = (x0 + T) % T, y1 = (x1 + LX) % LX, y2 = (x2 + LY) % LY, y3 = (x3 + LZ) % LZ;
+  int ix = ((y0 * LX + y1) * LY + y2) * LZ + y3;
+  if (lat->nproc_t > 1) {
+    if (x0 == T) ix = lat->V + y3 + LZ * y2 + LZ * LY * y1;
+    else if (x0 == -1) ix = lat->V + LX * LY * LZ + y3 + LZ * y2 + LZ * LY * y1;
+  }
+  return ix;
+}
+
+/* geometry_eo.c:743-885 (index tables) and :1470-1535 (Hopping_Matrix_Indices) */
+static void tmo_build_geometry(tmo_lattice *lat) {
+  const int T = lat->T, LX = lat->LX, LY = lat->LY, LZ = lat->LZ, V = lat->V, VR = lat->V + lat->RAND;
+  const int st = lat->nproc_t > 1 ? 1 : 0;
+  int *xeven = (int *)malloc(sizeof(int) * VR);
+  for (int x0 = -st; x0 < T + st; x0++)
+    for (int x1 = 0; x1 < LX; x1++)
+      for (int x2 = 0; x2 < LY; x2++)
+        for (int x3 = 0; x3 < LZ; x3++) {
+          int ix = tmo_index(lat, x0, x1, x2, x3);
+          int s = x0 + x1 + x2 + x3 + lat->proc_t * T;       /* geometry_eo.c:807-811 */
+          xeven[ix] = (((s % 2) + 2) % 2 == 0);
+          if (ix < V) {
+            lat->iup[4 * ix + 0] = tmo_index(lat, x0 + 1, x1, x2, x3);
+            lat->idn[4 * ix + 0] = tmo_index(lat, x0 - 1, x1, x2, x3);
+            lat->iup[4 * ix + 1] = tmo_index(lat, x0, x1 + 1, x2, x3);
+            lat->idn[4 * ix + 1] = tmo_index(lat, x0, x1 - 1, x2, x3);
+            lat->iup[4 * ix + 2] = tmo_index(lat, x0, x1, x2 + 1, x3);
+            lat->idn[4 * ix + 2] = tmo_index(lat, x0, x1, x2 - 1, x3);
+            lat->iup[4 * ix + 3] = tmo_index(lat, x0, x1, x2, x3 + 1);
+            lat->idn[4 * ix + 3] = tmo_index(lat, x0, x1, x2, x3 - 1);
+          }
+        }
+  int i_even = 0, i_odd = 0;                                  /* geometry_eo.c:869-885 */
+  for (int ix = 0; ix < VR; ix++) {
+    if (xeven[ix]) {
+      lat->lexic2eo[ix] = i_even; lat->lexic2eosub[ix] = i_even; lat->eo2lexic[i_even] = ix; i_even++;
+    } else {
+      lat->lexic2eo[ix] = VR / 2 + i_odd; lat->lexic2eosub[ix] = i_odd; lat->eo2lexic[VR / 2 + i_odd] = ix; i_odd++;
+    }
+  }
+  free(xeven);
+  for (int par = 0; par < 2; par++)                           /* geometry_eo.c:1470-1535 */
+    for (int i = 0; i < V / 2; i++) {
+      int ic = par * (VR / 2) + i, ix = lat->eo2lexic[ic];
+      int *h = lat->hi + 16 * ic;
+      for (int mu = 0; mu < 4; mu++) {
+        h[4 * mu + 0] = lat->iup[4 * ix + mu];
+        h[4 * mu + 1] = lat->lexic2eosub[lat->iup[4 * ix + mu]];
+        h[4 * mu + 2] = lat->idn[4 * ix + mu];
+        h[4 * mu + 3] = lat->lexic2eosub[lat->idn[4 * ix + mu]];
+      }
+      h[0] = ix;
+    }
+  lat->hi[16 * VR] = 0; lat->hi[16 * VR + 1] = 0;
+}
+
+tmo_lattice *tmo_create(int T, int LX, int LY, int LZ, int nproc_t, int proc_t) {
+  tmo_lattice *lat = (tmo_lattice *)calloc(1, sizeof(*lat));
+  lat->T = T; lat->LX = LX; lat->LY = LY; lat->LZ = LZ;
+  lat->nproc_t = nproc_t < 1 ? 1 : nproc_t; lat->proc_t = proc_t;
+  lat->V = T * LX * LY * LZ;
+  lat->RAND = lat->nproc_t > 1 ? 2 * LX * LY * LZ : 0;       /* mpi_init.c:330-332 */
+  lat->VPR = lat->V + lat->RAND;
+  const int VR = lat->VPR;
+  lat->iup = (int *)calloc(4 * (size_t)VR, sizeof(int));
+  lat->idn = (int *)calloc(4 * (size_t)VR, sizeof(int));
+  lat->lexic2eo = (int *)calloc(VR, sizeof(int));
+  lat->lexic2eosub = (int *)calloc(VR, sizeof(int));
+  lat->eo2lexic = (int *)calloc(VR, sizeof(int));
+  lat->hi = (int *)calloc(16 * (size_t)VR + 2, sizeof(int));
+  lat->gauge_copy = (tmo_su3 *)calloc(8 * (size_t)VR + 1, sizeof(tmo_su3));
+  for (int i = 0; i < 3; i++) lat->scratch[i] = (tmo_spinor *)calloc((size_t)VR / 2 + 1, sizeof(tmo_spinor));
+  tmo_build_geometry(lat);
+  double th[4] = {0, 0, 0, 0};
+  tmo_boundary(lat, 0.125, th);
+  lat->gauge_dirty = 1;
+  return lat;
+}
+
+void tmo_destroy(tmo_lattice *lat) {
+  if (!lat) return;
+  free(lat->iup); free(lat->idn); free(lat->lexic2eo); free(lat->lexic2eosub); free(lat->eo2lexic);
+  free(lat->hi); free(lat->gauge_copy);
+  for (int i = 0; i < 3; i++) free(lat->scratch[i]);
+  free(lat);
+}
+
+/* boundary.c:36,40-55 */
+void tmo_boundary(tmo_lattice *lat, double kappa, const double theta[4]) {
+  const double PI_ = 3.14159265358979;
+  const int ext[4] = {lat->T * lat->nproc_t, lat->LX, lat->LY, lat->LZ};
+  lat->kappa = kappa;
+  for (int mu = 0; mu < 4; mu++) {
+    lat->theta[mu] = theta[mu];
+    double x = theta[mu] * PI_ / ext[mu];
+    lat->ka[mu] = kappa * cexp(x * I);
+  }
+}
+void tmo_set_mu(tmo_lattice *lat, double mu) { lat->mu = mu; }
+void tmo_set_gauge(tmo_lattice *lat, const tmo_su3 *g) { lat->gauge = g; lat->gauge_dirty = 1; }
+
+/* update_backward_gauge.c:185-242 (plain _GAUGE_COPY layout [V+RAND][8]) */
+static void tmo_update_backward_gauge(tmo_lattice *lat) {
+  const int V = lat->V, VR = lat->VPR;
+  const tmo_su3 *gf = lat->gauge;
+  for (int par = 0; par < 2; par++) {
+#pragma omp parallel for
+    for (int i = 0; i < V / 2; i++) {
+      int ix = par * (VR / 2) + i, kb2 = lat->eo2lexic[ix];
+      for (int mu = 0; mu < 4; mu++) {
+        int kb = lat->idn[4 * kb2 + mu];
+        lat->gauge_copy[8 * (size_t)ix + 2 * mu] = gf[4 * (size_t)kb2 + mu];
+        lat->gauge_copy[8 * (size_t)ix + 2 * mu + 1] = gf[4 * (size_t)kb + mu];
+      }
+    }
+  }
+  lat->gauge_dirty = 0;
+}
+
+/* ---------------------------------------------------------------- stencil */
+enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB = 2 };
+
+/* operator/hopping_body_dbl.c:27-181 with the generic macros of
+   operator/hopping.h:574-694.  NB the body's "sp/up" pair serves the +mu hops
+   and "sm/um" the -mu hops; with _GAUGE_COPY the links are the 8 consecutive
+   entries of gauge_copy[icx]. */
+static void tmo_hopping_generic(tmo_lattice *lat, int ieo, tmo_spinor *l, const tmo_spinor *p,
+                                const tmo_spinor *k, double _Complex cfactor, int epi) {
+  if (lat->gauge_dirty) tmo_update_backward_gauge(lat);     /* Hopping_Matrix.c:135-139 */
+  const int ioff = ieo == 0 ? 0 : lat->VPR / 2;             /* hopping_body_dbl.c:43-48 */
+  const int Vh = lat->V / 2;
+  const double _Complex ka0 = lat->ka[0], ka1 = lat->ka[1], ka2 = lat->ka[2], ka3 = lat->ka[3];
+#pragma omp parallel for
+  for (int icx = ioff; icx < Vh + ioff; icx++) {
+    const int *hi = lat->hi + 16 * (size_t)icx;
+    const tmo_su3 *u = lat->gauge_copy + 8 * (size_t)icx;
+    const tmo_spinor *s;
+    tmo_su3_vector psi, chi;
+    tmo_spinor temp;
+    /* +t  hopping.h:578-588 */
+    s = k + hi[1];
+    psi = v_add(s->s0, s->s2); chi = su3_mul(&u[0], psi); psi = c_times_v(ka0, chi);
+    temp.s0 = psi; temp.s2 = psi;
+    psi = v_add(s->s1, s->s3); chi = su3_mul(&u[0], psi); psi = c_times_v(ka0, chi);
+    temp.s1 = psi; temp.s3 = psi;
+    /* -t  hopping.h:590-600 */
+    s = k + hi[3];
+    psi = v_sub(s->s0, s->s2); chi = su3_inv_mul(&u[1], psi); psi = cc_times_v(ka0, chi);
+    V_ADD_ASSIGN(temp.s0, psi); V_SUB_ASSIGN(temp.s2, psi);
+    psi = v_sub(s->s1, s->s3); chi = su3_inv_mul(&u[1], psi); psi = cc_times_v(ka0, chi);
+    V_ADD_ASSIGN(temp.s1, psi); V_SUB_ASSIGN(temp.s3, psi);
+    /* +x  hopping.h:602-612 */
+    s = k + hi[5];
+    psi = v_i_add(s->s0, s->s3); chi = su3_mul(&u[2], psi); psi = c_times_v(ka1, chi);
+    V_ADD_ASSIGN(temp.s0, psi); V_ISUB_ASSIGN(temp.s3, psi);
+    psi = v_i_add(s->s1, s->s2); chi = su3_mul(&u[2], psi); psi = c_times_v(ka1, chi);
+    V_ADD_ASSIGN(temp.s1, psi); V_ISUB_ASSIGN(temp.s2, psi);
+    /* -x  hopping.h:614-624 */
+    s = k + hi[7];
+    psi = v_i_sub(s->s0, s->s3); chi = su3_inv_mul(&u[3], psi); psi = cc_times_v(ka1, chi);
+    V_ADD_ASSIGN(temp.s0, psi); V_IADD_ASSIGN(temp.s3, psi);
+    psi = v_i_sub(s->s1, s->s2); chi = su3_inv_mul(&u[3], psi); psi = cc_times_v(ka1, chi);
+    V_ADD_ASSIGN(temp.s1, psi); V_IADD_ASSIGN(temp.s2, psi);
+    /* +y  hopping.h:626-636 */
+    s = k + hi[9];
+    psi = v_add(s->s0, s->s3); chi = su3_mul(&u[4], psi); psi = c_times_v(ka2, chi);
+    V_ADD_ASSIGN(temp.s0, psi); V_ADD_ASSIGN(temp.s3, psi);
+    psi = v_sub(s->s1, s->s2); chi = su3_mul(&u[4], psi); psi = c_times_v(ka2, chi);
+    V_ADD_ASSIGN(temp.s1, psi); V_SUB_ASSIGN(temp.s2, psi);
+    /* -y  hopping.h:638-648 */
+    s = k + hi[11];
+    psi = v_sub(s->s0, s->s3); chi = su3_inv_mul(&u[5], psi); psi = cc_times_v(ka2, chi);
+    V_ADD_ASSIGN(temp.s0, psi); V_SUB_ASSIGN(temp.s3, psi);
+    psi = v_add(s->s1, s->s2); chi = su3_inv_mul(&u[5], psi); psi = cc_times_v(ka2, chi);
+    V_ADD_ASSIGN(temp.s1, psi); V_ADD_ASSIGN(temp.s2, psi);
+    /* +z  hopping.h:650-660 */
+    s = k + hi[13];
+    psi = v_i_add(s->s0, s->s2); chi = su3_mul(&u[6], psi); psi = c_times_v(ka3, chi);
+    V_ADD_ASSIGN(temp.s0, psi); V_ISUB_ASSIGN(temp.s2, psi);
+    psi = v_i_sub(s->s1, s->s3); chi = su3_mul(&u[6], psi); psi = c_times_v(ka3, chi);
+    V_ADD_ASSIGN(temp.s1, psi); V_IADD_ASSIGN(temp.s3, psi);
+    /* -z  hopping.h:662-672 */
+    s = k + hi[15];
+    psi = v_i_sub(s->s0, s->s2); chi = su3_inv_mul(&u[7], psi); psi = cc_times_v(ka3, chi);
+    V_ADD_ASSIGN(temp.s0, psi); V_IADD_ASSIGN(temp.s2, psi);
+    psi = v_i_add(s->s1, s->s3); chi = su3_inv_mul(&u[7], psi); psi = cc_times_v(ka3, chi);
+    V_ADD_ASSIGN(temp.s1, psi); V_ISUB_ASSIGN(temp.s3, psi);
+
+    tmo_spinor *rn = l + (icx - ioff);
+    if (epi == EPI_TM_TIMES) {                               /* hopping.h:674-678 */
+      rn->s0 = c_times_v(cfactor, temp.s0); rn->s1 = c_times_v(cfactor, temp.s1);
+      rn->s2 = cc_times_v(cfactor, temp.s2); rn->s3 = cc_times_v(cfactor, temp.s3);
+    } else if (epi == EPI_TM_SUB) {                          /* hopping.h:680-688 */
+      const tmo_spinor *pn = p + (icx - ioff);
+      psi = c_times_v(cfactor, pn->s0); rn->s0 = v_sub(psi, temp.s0);
+      chi = c_times_v(cfactor, pn->s1); rn->s1 = v_sub(chi, temp.s1);
+      psi = cc_times_v(cfactor, pn->s2); rn->s2 = v_sub(temp.s2, psi);
+      chi = cc_times_v(cfactor, pn->s3); rn->s3 = v_sub(temp.s3, chi);
+    } else {                                                 /* hopping.h:690-694 */
+      *rn = temp;
+    }
+  }
+}
+
+/* operator/Hopping_Matrix.c:131-156 (halo of k must already be filled: the oracle has no MPI) */
+void tmo_Hopping_Matrix(tmo_lattice *lat, int ieo, tmo_spinor *l, const tmo_spinor *k) {
+  tmo_hopping_generic(lat, ieo, l, NULL, k, 0, EPI_STORE);
+}
+/* operator/tm_times_Hopping_Matrix.c:72-153 */
+void tmo_tm_times_Hopping_Matrix(tmo_lattice *lat, int ieo, tmo_spinor *l, const tmo_spinor *k,
+                                 double cre, double cim) {
+  tmo_hopping_generic(lat, ieo, l, NULL, k, cre + cim * I, EPI_TM_TIMES);
+}
+/* operator/tm_sub_Hopping_Matrix.c:73-157 */
+void tmo_tm_sub_Hopping_Matrix(tmo_lattice *lat, int ieo, tmo_spinor *l, const tmo_spinor *p,
+                               const tmo_spinor *k, double cre, double cim) {
+  tmo_hopping_generic(lat, ieo, l, p, k, cre + cim * I, EPI_TM_SUB);
+}
+
+/* operator/D_psi_body.c:266-375 with the p?add/m?add helpers of :1-230; g_c_sw = 0 branch */
+void tmo_D_psi(tmo_lattice *lat, tmo_spinor *P, const tmo_spinor *Q) {
+  if (P == Q) {                                              /* D_psi_body.c:267-272 */
+    printf("Error in D_psi (operator.c):\nArguments must be different spinor fields\nProgram aborted\n");
+    exit(1);
+  }
+  const double _Complex ph0 = -lat->ka[0], ph1 = -lat->ka[1], ph2 = -lat->ka[2], ph3 = -lat->ka[3]; /* boundary.c:51-54 */
+  const double _Complex rho1 = 1. + lat->mu * I, rho2 = conj(rho1);
+  const tmo_su3 *g = lat->gauge;
+#pragma omp parallel for
+  for (int ix = 0; ix < lat->V; ix++) {
+    const tmo_spinor *s = Q + ix;
+    tmo_spinor t;
+    tmo_su3_vector psi, chi;
+    const tmo_su3 *u;
+    int iy;
+    t.s0 = c_times_v(rho1, s->s0); t.s1 = c_times_v(rho1, s->s1);
+    t.s2 = c_times_v(rho2, s->s2); t.s3 = c_times_v(rho2, s->s3);
+    /* +0 */
+    iy = lat->iup[4 * ix + 0]; s = Q + iy; u = &g[4 * (size_t)ix + 0];
+    psi = v_add(s->s0, s->s2); chi = su3_mul(u, psi); psi = c_times_v(ph0, chi);
+    V_ADD_ASSIGN(t.s0, psi); V_ADD_ASSIGN(t.s2, psi);
+    psi = v_add(s->s1, s->s3); chi = su3_mul(u, psi); psi = c_times_v(ph0, chi);
+    V_ADD_ASSIGN(t.s1, psi); V_ADD_ASSIGN(t.s3, psi);
+    /* -0 */
+    iy = lat->idn[4 * ix + 0]; s = Q + iy; u = &g[4 * (size_t)iy + 0];
+    psi = v_sub(s->s0, s->s2); chi = su3_inv_mul(u, psi); psi = cc_times_v(ph0, chi);
+    V_ADD_ASSIGN(t.s0, psi); V_SUB_ASSIGN(t.s2, psi);
+    psi = v_sub(s->s1, s->s3); chi = su3_inv_mul(u, psi); psi = cc_times_v(ph0, chi);
+    V_ADD_ASSIGN(t.s1, psi); V_SUB_ASSIGN(t.s3, psi);
+    /* +1 */
+    iy = lat->iup[4 * ix + 1]; s = Q + iy; u = &g[4 * (size_t)ix + 1];
+    psi = v_i_add(s->s0, s->s3); chi = su3_mul(u, psi); psi = c_times_v(ph1, chi);
+    V_ADD_ASSIGN(t.s0, psi); V_ISUB_ASSIGN(t.s3, psi);
+    psi = v_i_add(s->s1, s->s2); chi = su3_mul(u, psi); psi = c_times_v(ph1, chi);
+    V_ADD_ASSIGN(t.s1, psi); V_ISUB_ASSIGN(t.s2, psi);
+    /* -1 */
+    iy = lat->idn[4 * ix + 1]; s = Q + iy; u = &g[4 * (size_t)iy + 1];
+    psi = v_i_sub(s->s0, s->s3); chi = su3_inv_mul(u, psi); psi = cc_times_v(ph1, chi);
+    V_ADD_ASSIGN(t.s0, psi); V_IADD_ASSIGN(t.s3, psi);
+    psi = v_i_sub(s->s1, s->s2); chi = su3_inv_mul(u, psi); psi = cc_times_v(ph1, chi);
+    V_ADD_ASSIGN(t.s1, psi); V_IADD_ASSIGN(t.s2, psi);
+    /* +2 */
+    iy = lat->iup[4 * ix + 2]; s = Q + iy; u = &g[4 * (size_t)ix + 2];
+    psi = v_add(s->s0, s->s3); chi = su3_mul(u, psi); psi = c_times_v(ph2, chi);
+    V_ADD_ASSIGN(t.s0, psi); V_ADD_ASSIGN(t.s3, psi);
+    psi = v_sub(s->s1, s->s2); chi = su3_mul(u, psi); psi = c_times_v(ph2, chi);
+    V_ADD_ASSIGN(t.s1, psi); V_SUB_ASSIGN(t.s2, psi);
+    /* -2 */
+    iy = lat->idn[4 * ix + 2]; s = Q + iy; u = &g[4 * (size_t)iy + 2];
+    psi = v_sub(s->s0, s->s3); chi = su3_inv_mul(u, psi); psi = cc_times_v(ph2, chi);
+    V_ADD_ASSIGN(t.s0, psi); V_SUB_ASSIGN(t.s3, psi);
+    psi = v_add(s->s1, s->s2); chi = su3_inv_mul(u, psi); psi = cc_times_v(ph2, chi);
+    V_ADD_ASSIGN(t.s1, psi); V_ADD_ASSIGN(t.s2, psi);
+    /* +3 */
+    iy = lat->iup[4 * ix + 3]; s = Q + iy; u = &g[4 * (size_t)ix + 3];
+    psi = v_i_add(s->s0, s->s2); chi = su3_mul(u, psi); psi = c_times_v(ph3, chi);
+    V_ADD_ASSIGN(t.s0, psi); V_ISUB_ASSIGN(t.s2, psi);
+    psi = v_i_sub(s->s1, s->s3); chi = su3_mul(u, psi); psi = c_times_v(ph3, chi);
+    V_ADD_ASSIGN(t.s1, psi); V_IADD_ASSIGN(t.s3, psi);
+    /* -3 (m3addandstore, D_psi_body.c:206-230) */
+    iy = lat->idn[4 * ix + 3]; s = Q + iy; u = &g[4 * (size_t)iy + 3];
+    tmo_spinor *r = P + ix;
+    psi = v_i_sub(s->s0, s->s2); chi = su3_inv_mul(u, psi); psi = cc_times_v(ph3, chi);
+    r->s0 = v_add(t.s0, psi); r->s2 = v_i_add(t.s2, psi);
+    psi = v_i_add(s->s1, s->s3); chi = su3_inv_mul(u, psi); psi = cc_times_v(ph3, chi);
+    r->s1 = v_add(t.s1, psi); r->s3 = v_i_sub(t.s3, psi);
+  }
+}
+
+/* ---------------------------------------------------------------- site-diagonal */
+/* operator/mul_one_pm_imu_inv_body.c:1-41 */
+void tmo_mul_one_pm_imu_inv(tmo_lattice *lat, tmo_spinor *l, double _sign, int N) {
+  double nrm = 1. / (1. + lat->mu * lat->mu), sign = -1.;
+  if (_sign < 0.) sign = 1.;
+  double _Complex z = nrm + (sign * nrm * lat->mu) * I, w = conj(z);
+#pragma omp parallel for
+  for (int ix = 0; ix < N; ix++) {
+    tmo_spinor *r = l + ix;
+    r->s0 = c_times_v(z, r->s0); r->s1 = c_times_v(z, r->s1);
+    r->s2 = c_times_v(w, r->s2); r->s3 = c_times_v(w, r->s3);
+  }
+}
+/* operator/mul_one_pm_imu_inv_body.c:43-80 */
+void tmo_assign_mul_one_pm_imu_inv(tmo_lattice *lat, tmo_spinor *l, const tmo_spinor *k, double _sign, int N) {
+  double nrm = 1. / (1. + lat->mu * lat->mu), sign = -1.;
+  if (_sign < 0.) sign = 1.;
+  double _Complex z = nrm + (sign * nrm * lat->mu) * I, w = conj(z);
+#pragma omp parallel for
+  for (int ix = 0; ix < N; ix++) {
+    const tmo_spinor *r = k + ix; tmo_spinor *s = l + ix;
+    tmo_spinor o;
+    o.s0 = c_times_v(z, r->s0); o.s1 = c_times_v(z, r->s1);
+    o.s2 = c_times_v(w, r->s2); o.s3 = c_times_v(w, r->s3);
+    *s = o;
+  }
+}
+/* operator/tm_operators.c:669-720 */
+void tmo_assign_mul_one_pm_imu(tmo_lattice *lat, tmo_spinor *l, const tmo_spinor *k, double _sign, int N) {
+  double sign = 1.;
+  if (_sign < 0.) sign = -1.;
+  double _Complex z = 1. + (sign * lat->mu) * I, w = conj(z);
+#pragma omp parallel for
+  for (int ix = 0; ix < N; ix++) {
+    const tmo_spinor *r = k + ix; tmo_spinor *s = l + ix;
+    tmo_spinor o;
+    o.s0 = c_times_v(z, r->s0); o.s1 = c_times_v(z, r->s1);
+    o.s2 = c_times_v(w, r->s2); o.s3 = c_times_v(w, r->s3);
+    *s = o;
+  }
+}
+/* operator/mul_one_pm_imu_sub_mul_body.c:1-48 */
+void tmo_mul_one_pm_imu_sub_mul(tmo_lattice *lat, tmo_spinor *l, const tmo_spinor *k, const tmo_spinor *j,
+                                double _sign, int N) {
+  double sign = 1.;
+  if (_sign < 0.) sign = -1.;
+  double _Complex z = 1. + (sign * lat->mu) * I, w = conj(z);
+#pragma omp parallel for
+  for (int ix = 0; ix < N; ix++) {
+    const tmo_spinor *r = k + ix, *s = j + ix; tmo_spinor *t = l + ix;
+    tmo_su3_vector p1 = c_times_v(z, r->s0), p2 = c_times_v(z, r->s1), p3 = c_times_v(w, r->s2), p4 = c_times_v(w, r->s3);
+    tmo_spinor o;
+    o.s0 = v_sub(p1, s->s0); o.s1 = v_sub(p2, s->s1); o.s2 = v_sub(p3, s->s2); o.s3 = v_sub(p4, s->s3);
+    *t = o;
+  }
+}
+/* operator/tm_operators.c:813-858 */
+void tmo_mul_one_pm_imu_sub_mul_gamma5(tmo_lattice *lat, tmo_spinor *l, const tmo_spinor *k,
+                                       const tmo_spinor *j, double _sign) {
+  double sign = 1.;
+  if (_sign < 0.) sign = -1.;
+  double _Complex z = 1. + (sign * lat->mu) * I, w = conj(z);
+  const int N = lat->V / 2;
+#pragma omp parallel for
+  for (int ix = 0; ix < N; ix++) {
+    const tmo_spinor *r = k + ix, *s = j + ix; tmo_spinor *t = l + ix;
+    tmo_su3_vector p1 = c_times_v(z, r->s0), p2 = c_times_v(z, r->s1), p3 = c_times_v(w, r->s2), p4 = c_times_v(w, r->s3);
+    tmo_spinor o;
+    o.s0 = v_sub(p1, s->s0); o.s1 = v_sub(p2, s->s1); o.s2 = v_sub(s->s2, p3); o.s3 = v_sub(s->s3, p4);
+    *t = o;
+  }
+}
+/* gamma.c:77-98 */
+void tmo_gamma5(tmo_spinor *l, const tmo_spinor *k, int N) {
+#pragma omp parallel for
+  for (int ix = 0; ix < N; ix++) {
+    tmo_spinor o = k[ix];
+    o.s2.c0 = -o.s2.c0; o.s2.c1 = -o.s2.c1; o.s2.c2 = -o.s2.c2;
+    o.s3.c0 = -o.s3.c0; o.s3.c1 = -o.s3.c1; o.s3.c2 = -o.s3.c2;
+    l[ix] = o;
+  }
+}
+
+/* ---------------------------------------------------------------- e/o compositions */
+#define EO 0
+#define OE 1
+/* operator/tm_operators.c:508-526 (generic branch) */
+void tmo_H_eo_tm_inv_psi(tmo_lattice *lat, tmo_spinor *l, const tmo_spinor *k, int ieo, double _sign) {
+  double nrm = 1. / (1. + lat->mu * lat->mu), sign = -1.;
+  if (_sign < 0.) sign = 1.;
+  tmo_tm_times_Hopping_Matrix(lat, ieo, l, k, nrm, sign * nrm * lat->mu);
+}
+/* operator/tm_operators.c:528-546 */
+static void tmo_tm_sub_H_eo_gamma5(tmo_lattice *lat, tmo_spinor *l, const tmo_spinor *p, const tmo_spinor *k,
+                                   int ieo, double _sign) {
+  double sign = 1.;
+  if (_sign < 0.) sign = -1.;
+  tmo_tm_sub_Hopping_Matrix(lat, ieo, l, p, k, 1., sign * lat->mu);
+}
+/* operator/tm_operators.c:172-177 */
+void tmo_Qtm_plus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
+  tmo_mul_one_pm_imu_inv(lat, lat->scratch[1], +1., lat->V / 2);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
+  tmo_mul_one_pm_imu_sub_mul_gamma5(lat, l, k, lat->scratch[0], +1.);
+}
+/* operator/tm_operators.c:216-221 */
+void tmo_Qtm_minus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_H_eo_tm_inv_psi(lat, lat->scratch[1], k, EO, -1);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[2], lat->scratch[1]);
+  tmo_mul_one_pm_imu_sub_mul_gamma5(lat, l, k, lat->scratch[2], -1);
+}
+/* operator/tm_operators.c:245-250 */
+void tmo_Mtm_plus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
+  tmo_mul_one_pm_imu_inv(lat, lat->scratch[1], +1., lat->V / 2);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
+  tmo_mul_one_pm_imu_sub_mul(lat, l, k, lat->scratch[0], +1., lat->V / 2);
+}
+/* operator/tm_operators.c:289-294 */
+void tmo_Mtm_minus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
+  tmo_mul_one_pm_imu_inv(lat, lat->scratch[1], -1., lat->V / 2);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
+  tmo_mul_one_pm_imu_sub_mul(lat, l, k, lat->scratch[0], -1., lat->V / 2);
+}
+/* operator/tm_operators.c:338-345 */
+void tmo_Qtm_pm_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_H_eo_tm_inv_psi(lat, lat->scratch[1], k, EO, -1);
+  tmo_tm_sub_H_eo_gamma5(lat, lat->scratch[0], k, lat->scratch[1], OE, -1);
+  tmo_H_eo_tm_inv_psi(lat, lat->scratch[1], lat->scratch[0], EO, +1);
+  tmo_tm_sub_H_eo_gamma5(lat, l, lat->scratch[0], lat->scratch[1], OE, +1);
+}
+/* operator/tm_operators.c:117-128 */
+void tmo_M_full(tmo_lattice *lat, tmo_spinor *Even_new, tmo_spinor *Odd_new,
+                const tmo_spinor *Even, const tmo_spinor *Odd) {
+  const int N = lat->V / 2;
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[0], Odd);
+  tmo_assign_mul_one_pm_imu(lat, Even_new, Even, 1., N);
+  tmo_assign_add_mul_r(Even_new, lat->scratch[0], -1., N);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], Even);
+  tmo_assign_mul_one_pm_imu(lat, Odd_new, Odd, 1., N);
+  tmo_assign_add_mul_r(Odd_new, lat->scratch[0], -1., N);
+}
+
+/* ---------------------------------------------------------------- linalg */
+/* Per-thread Kahan partials summed in thread order, as the reference does with
+   g_omp_acc_re (linalg/square_norm.c:299-304). */
+static double tmo_sum_partials(const double *acc, int n) {
+  double res = 0.0;
+  for (int i = 0; i < n; i++) res += acc[i];
+  return res;
+}
+
+/* linalg/square_norm.c:253-320 */
+double tmo_square_norm(const tmo_spinor *P, int N) {
+  double acc[TMO_MAX_THREADS];
+  int nthr = 1;
+#pragma omp parallel
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#pragma omp single
+    nthr = omp_get_num_threads();
+#endif
+    double ks = 0.0, kc = 0.0, ds, tr, ts, tt;
+#pragma omp for
+    for (int ix = 0; ix < N; ix++) {
+      const tmo_spinor *s = P + ix;
+      ds = conj(s->s0.c0) * s->s0.c0 + conj(s->s0.c1) * s->s0.c1 + conj(s->s0.c2) * s->s0.c2 +
+           conj(s->s1.c0) * s->s1.c0 + conj(s->s1.c1) * s->s1.c1 + conj(s->s1.c2) * s->s1.c2 +
+           conj(s->s2.c0) * s->s2.c0 + conj(s->s2.c1) * s->s2.c1 + conj(s->s2.c2) * s->s2.c2 +
+           conj(s->s3.c0) * s->s3.c0 + conj(s->s3.c1) * s->s3.c1 + conj(s->s3.c2) * s->s3.c2;
+      tr = ds + kc; ts = tr + ks; tt = ts - ks; ks = ts; kc = tr - tt;
+    }
+    kc = ks + kc;
+    acc[tid] = kc;
+  }
+  return tmo_sum_partials(acc, nthr);
+}
+
+/* linalg/scalar_prod_r.c:135-197 */
+double tmo_scalar_prod_r(const tmo_spinor *S, const tmo_spinor *R, int N) {
+  double acc[TMO_MAX_THREADS];
+  int nthr = 1;
+#pragma omp parallel
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#pragma omp single
+    nthr = omp_get_num_threads();
+#endif
+    double ks = 0.0, kc = 0.0, ds, tr, ts, tt;
+#pragma omp for
+    for (int ix = 0; ix < N; ix++) {
+      const tmo_spinor *s = S + ix, *r = R + ix;
+      ds = creal(r->s0.c0 * conj(s->s0.c0)) + creal(r->s0.c1 * conj(s->s0.c1)) + creal(r->s0.c2 * conj(s->s0.c2)) +
+           creal(r->s1.c0 * conj(s->s1.c0)) + creal(r->s1.c1 * conj(s->s1.c1)) + creal(r->s1.c2 * conj(s->s1.c2)) +
+           creal(r->s2.c0 * conj(s->s2.c0)) + creal(r->s2.c1 * conj(s->s2.c1)) + creal(r->s2.c2 * conj(s->s2.c2)) +
+           creal(r->s3.c0 * conj(s->s3.c0)) + creal(r->s3.c1 * conj(s->s3.c1)) + creal(r->s3.c2 * conj(s->s3.c2));
+      tr = ds + kc; ts = tr + ks; tt = ts - ks; ks = ts; kc = tr - tt;
+    }
+    kc = ks + kc;
+    acc[tid] = kc;
+  }
+  return tmo_sum_partials(acc, nthr);
+}
+
+/* linalg/assign_add_mul_r.c:346-381  P += c Q */
+void tmo_assign_add_mul_r(tmo_spinor *P, const tmo_spinor *Q, double c, int N) {
+  double *p = (double *)P; const double *q = (const double *)Q;
+#pragma omp parallel for
+  for (long i = 0; i < 24L * N; i++) p[i] += c * q[i];
+}
+/* linalg/assign_mul_add_r.c:340-377  R = c R + S */
+void tmo_assign_mul_add_r(tmo_spinor *R, double c, const tmo_spinor *S, int N) {
+  double *r = (double *)R; const double *s = (const double *)S;
+#pragma omp parallel for
+  for (long i = 0; i < 24L * N; i++) r[i] = c * r[i] + s[i];
+}
+/* linalg/assign_mul_add_r_and_square.c:145-213 -- plain (non-Kahan) per-thread sum */
+double tmo_assign_mul_add_r_and_square(tmo_spinor *R, double c, const tmo_spinor *S, int N) {
+  double acc[TMO_MAX_THREADS];
+  int nthr = 1;
+#pragma omp parallel
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#pragma omp single
+    nthr = omp_get_num_threads();
+#endif
+    double ds = 0.0;
+#pragma omp for
+    for (int ix = 0; ix < N; ix++) {
+      double *r = (double *)(R + ix); const double *s = (const double *)(S + ix);
+      for (int j = 0; j < 12; j++) {
+        r[2 * j] = c * r[2 * j] + s[2 * j];
+        r[2 * j + 1] = c * r[2 * j + 1] + s[2 * j + 1];
+        ds += r[2 * j] * r[2 * j] + r[2 * j + 1] * r[2 * j + 1];
+      }
+    }
+    acc[tid] = ds;
+  }
+  return tmo_sum_partials(acc, nthr);
+}
+/* linalg/diff.c:270-309  Q = R - S */
+void tmo_diff(tmo_spinor *Q, const tmo_spinor *R, const tmo_spinor *S, int N) {
+  double *q = (double *)Q; const double *r = (const double *)R, *s = (const double *)S;
+#pragma omp parallel for
+  for (long i = 0; i < 24L * N; i++) q[i] = r[i] - s[i];
+}
+/* linalg/assign.c:42-46 */
+void tmo_assign(tmo_spinor *R, const tmo_spinor *S, int N) { memcpy(R, S, (size_t)N * sizeof(tmo_spinor)); }
+
+/* ---------------------------------------------------------------- solver */
+/* solver/cg_her.c:62-141.  res_hist[i] (i < hist_len) receives err after iteration i+1. */
+int tmo_cg_her(tmo_lattice *lat, tmo_spinor *P, tmo_spinor *Q, int max_iter, double eps_sq,
+               int rel_prec, int N, tmo_matrix_mult f, double *res_hist, int hist_len) {
+  const size_t Vf = (size_t)lat->VPR / 2 + 1;
+  tmo_spinor *blk = (tmo_spinor *)calloc(3 * Vf, sizeof(tmo_spinor)); /* solver_field.c:31-71 */
+  tmo_spinor *sf[3] = {blk, blk + Vf, blk + 2 * Vf}, *stmp;
+  double normsq, pro, err, alpha_cg, beta_cg, squarenorm;
+  int iteration;
+  squarenorm = tmo_square_norm(Q, N);
+  f(lat, sf[0], P);
+  tmo_diff(sf[1], Q, sf[0], N);
+  tmo_assign(sf[2], sf[1], N);
+  normsq = tmo_square_norm(sf[1], N);
+  for (iteration = 1; iteration <= max_iter; iteration++) {
+    f(lat, sf[0], sf[2]);
+    pro = tmo_scalar_prod_r(sf[2], sf[0], N);
+    alpha_cg = normsq / pro;
+    tmo_assign_add_mul_r(P, sf[2], alpha_cg, N);
+    err = tmo_assign_mul_add_r_and_square(sf[0], -alpha_cg, sf[1], N);
+    if (res_hist && iteration - 1 < hist_len) res_hist[iteration - 1] = err;
+    if (((err <= eps_sq) && (rel_prec == 0)) || ((err <= eps_sq * squarenorm) && (rel_prec == 1))) break;
+    beta_cg = err / normsq;
+    tmo_assign_mul_add_r(sf[2], beta_cg, sf[0], N);
+    stmp = sf[0]; sf[0] = sf[1]; sf[1] = stmp;
+    normsq = err;
+  }
+  free(blk);
+  if (iteration > max_iter) return -1;
+  return iteration;
+}
