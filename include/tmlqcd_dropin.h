@@ -1,0 +1,104 @@
+/* tmlqcd_dropin.h -- the reference's own symbols, implemented on MI355X (libtmlqcd_dropin.so).
+ *
+ * Every function below has EXACTLY the name, signature and argument meaning of the
+ * tmLQCD function cited next to it, so `benchmark`, `invert` and `hmc_tm` link against
+ * this library instead of the corresponding objects of liboperator.a / liblinalg.a /
+ * libsolver.a (link line configure.in:1074) with no source change.  Host arrays stay in
+ * the reference's AoS `spinor` / `su3` layouts (su3.h:40-63).
+ *
+ * The library reads these tmLQCD globals AT CALL TIME (never cached across calls):
+ *   T, LX, LY, LZ, VOLUME, RAND (global.h:82-84), g_nproc_t/x/y/z, g_proc_coords (global.h:206-207),
+ *   g_gauge_field, g_update_gauge_copy (global.h:176,73), ka0..ka3 (boundary.h:25), g_mu (global.h:198).
+ *
+ * Residency (SURVEY §7 "hard parts"): the reference API passes host pointers.  Two modes:
+ *   COHERENT (default) every call uploads its inputs and downloads its outputs: always
+ *            correct for unmodified callers, PCIe-bound.
+ *   RESIDENT           outputs stay in HBM; a host array is uploaded only when it has no
+ *            valid device mirror.  The host copy of an output is stale until
+ *            tmlqcd_hip_sync_to_host(); after the host writes an array call
+ *            tmlqcd_hip_host_modified().  cg_her() always runs device-resident
+ *            internally and returns with P valid on the host.
+ * Errors are fatal (print + exit), the reference's convention (fatal_error.c).
+ */
+#ifndef TMLQCD_DROPIN_H
+#define TMLQCD_DROPIN_H
+#ifdef __cplusplus
+extern "C" {
+#define TM_COMPLEX double _Complex
+#else
+#include <complex.h>
+#define TM_COMPLEX double _Complex
+#endif
+
+/* su3.h:40-63 -- layout is ABI */
+typedef struct { TM_COMPLEX c00, c01, c02, c10, c11, c12, c20, c21, c22; } su3;
+typedef struct { TM_COMPLEX c0, c1, c2; } su3_vector;
+typedef struct { su3_vector s0, s1, s2, s3; } spinor;
+typedef void (*matrix_mult)(spinor *const, spinor *const); /* solver/matrix_mult_typedef.h:30 */
+
+/* ---- stencil ------------------------------------------------------------- */
+void Hopping_Matrix(const int ieo, spinor *const l, spinor *const k);        /* operator/Hopping_Matrix.h:30 */
+void Hopping_Matrix_nocom(const int ieo, spinor *const l, spinor *const k);  /* operator/Hopping_Matrix_nocom.h */
+void tm_times_Hopping_Matrix(const int ieo, spinor *const l, spinor *const k, TM_COMPLEX const cfactor); /* operator/tm_times_Hopping_Matrix.h */
+void tm_sub_Hopping_Matrix(const int ieo, spinor *const l, spinor *p, spinor *const k, TM_COMPLEX const cfactor); /* operator/tm_sub_Hopping_Matrix.h */
+void D_psi(spinor *const P, spinor *const Q);                                 /* operator/D_psi.h:27 */
+
+/* ---- operator/tm_operators.h:26-77 ---------------------------------------- */
+void Qtm_plus_psi(spinor *const l, spinor *const k);
+void Qtm_plus_psi_nocom(spinor *const l, spinor *const k);
+void Qtm_minus_psi(spinor *const l, spinor *const k);
+void Mtm_plus_psi(spinor *const l, spinor *const k);
+void Mtm_plus_psi_nocom(spinor *const l, spinor *const k);
+void Mtm_minus_psi(spinor *const l, spinor *const k);
+void Qtm_pm_psi(spinor *const l, spinor *const k);
+void Qtm_pm_psi_nocom(spinor *const l, spinor *const k);
+void H_eo_tm_inv_psi(spinor *const l, spinor *const k, const int ieo, const double sign);
+void M_full(spinor *const Even_new, spinor *const Odd_new, spinor *const Even, spinor *const Odd);
+void Q_full(spinor *const Even_new, spinor *const Odd_new, spinor *const Even, spinor *const Odd);
+void M_minus_1_timesC(spinor *const Even_new, spinor *const Odd_new, spinor *const Even, spinor *const Odd);
+void mul_one_pm_imu_inv(spinor *const l, const double _sign, const int N);
+void assign_mul_one_pm_imu_inv(spinor *const l, spinor *const k, const double _sign, const int N);
+void assign_mul_one_pm_imu(spinor *const l, spinor *const k, const double _sign, const int N);
+void mul_one_pm_imu(spinor *const l, const double _sign);
+void mul_one_pm_imu_sub_mul(spinor *const l, spinor *const k, spinor *const j, const double _sign, const int N);
+void mul_one_pm_imu_sub_mul_gamma5(spinor *const l, spinor *const k, spinor *const j, const double _sign); /* tm_operators.c:813 */
+void Mee_psi(spinor *const l, spinor *const k, const double mu);
+void Mee_inv_psi(spinor *const l, spinor *const k, const double mu);
+void Q_pm_psi(spinor *const l, spinor *const k);
+void Q_plus_psi(spinor *const l, spinor *const k);
+void Q_minus_psi(spinor *const l, spinor *const k);
+void M_minus_psi(spinor *const l, spinor *const k);
+void D_dagg_psi(spinor *const l, spinor *const k);
+void Q_psi(spinor *const P, spinor *const Q);
+void gamma5(spinor *const l, spinor *const k, const int V);                   /* gamma.h */
+
+/* ---- linalg/*.h ------------------------------------------------------------ */
+double square_norm(const spinor *const P, const int N, const int parallel);
+double scalar_prod_r(const spinor *const S, const spinor *const R, const int N, const int parallel);
+void assign_add_mul_r(spinor *const P, spinor *const Q, const double c, const int N);
+void assign_mul_add_r(spinor *const R, const double c, const spinor *const S, const int N);
+double assign_mul_add_r_and_square(spinor *const R, const double c, const spinor *const S, const int N, const int parallel);
+void diff(spinor *const Q, const spinor *const R, const spinor *const S, const int N);
+void assign(spinor *const R, spinor *const S, const int N);
+
+/* ---- solver/cg_her.h ------------------------------------------------------- */
+int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, const int rel_prec,
+           const int N, matrix_mult f);
+
+/* ---- residency control (additions; not in the reference) ------------------- */
+enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1 };
+void tmlqcd_hip_set_residency(int mode);
+void tmlqcd_hip_sync_to_host(spinor *field);       /* download the device mirror of `field` if it is newer */
+void tmlqcd_hip_sync_all_to_host(void);
+void tmlqcd_hip_host_modified(spinor *field);      /* the host wrote `field`: drop its device mirror */
+void tmlqcd_hip_forget(spinor *field);             /* host memory is being freed: drop the mirror */
+void tmlqcd_hip_set_device(int device);            /* before the first call; default: $TMLQCD_HIP_DEVICE or 0 */
+void tmlqcd_hip_comm_init(const char unique_id[128]); /* ranks along T: id from tmhip_comm_get_unique_id, MPI_Bcast by the host */
+void tmlqcd_hip_finalize(void);
+/* benchmark.c:291-300 on device-resident mirrors; returns seconds for `iters` x {H(0,f1,f0); H(1,f2,f1)} */
+double tmlqcd_hip_benchmark_loop(spinor *f0, spinor *f1, spinor *f2, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,149 @@
+/* tmlqcd_hip.h -- C-ABI of the MI355X-native tmLQCD hot path (libtmlqcd_hip.so).
+ *
+ * Plain C: opaque handles, raw pointers and sizes only.  Host arrays use the
+ * reference's own AoS layouts (su3.h:40-43 `su3`, su3.h:60-63 `spinor`,
+ * global.h:176 `g_gauge_field[ix][mu]`, lexicographic ix of geometry_eo.c:290);
+ * device-side layouts are private.
+ *
+ * Two layers:
+ *   1. this header: explicit context + device-resident fields.  Every entry point
+ *      names the reference function (file:line under /root/reference) whose
+ *      semantics it reproduces.
+ *   2. include/tmlqcd_dropin.h: the reference's own symbol names and signatures
+ *      (Hopping_Matrix, Qtm_pm_psi, square_norm, cg_her, ...) implemented on top
+ *      of layer 1 so that benchmark / invert / hmc_tm link unchanged.
+ *
+ * All functions returning int return 0 on success; on failure they print a
+ * diagnostic to stderr and return non-zero (the drop-in layer turns that into
+ * exit(), the reference's own error convention, fatal_error.c).
+ */
+#ifndef TMLQCD_HIP_H
+#define TMLQCD_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tmhip_ctx tmhip_ctx;
+typedef struct tmhip_field tmhip_field;
+
+/* Local lattice of this rank.  Decomposition is T-only (the reference's
+ * PARALLELT, mpi_init.c:240-242,330-332): global T = nproc_t * T. */
+typedef struct {
+  int T, LX, LY, LZ; /* local extents; all even, T >= 2 (mpi_init.c:784-799) */
+  int nproc_t;       /* ranks along T (1 = single GPU, periodic wrap is local) */
+  int proc_t;        /* this rank's coordinate along T */
+} tmhip_geom;
+
+enum { TMHIP_EO = 0, TMHIP_OE = 1 };           /* global.h EO/OE */
+enum { TMHIP_FIELD_EO = 0, TMHIP_FIELD_FULL = 1 }; /* V/2 sites (one parity) | V sites */
+
+/* ---- context ------------------------------------------------------------ */
+/* device: HIP device ordinal.  Replaces the index-table / gauge-copy set-up of
+ * geometry() (geometry_eo.c:743) + init_gauge_field (init/init_gauge_field.c:41). */
+int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out);
+void tmhip_destroy(tmhip_ctx *ctx);
+int tmhip_sync(tmhip_ctx *ctx);
+const char *tmhip_version(void);
+int tmhip_device_count(void);
+
+/* boundary(kappa) with X0..X3 = theta (boundary.c:40-55) */
+int tmhip_set_boundary(tmhip_ctx *ctx, double kappa, const double theta[4]);
+/* Same, but takes the host's ka0..ka3 verbatim (boundary.h:25) as {re0,im0,..,re3,im3}: the
+ * drop-in layer re-reads the reference's globals at every call. */
+int tmhip_set_ka(tmhip_ctx *ctx, const double ka[8]);
+/* g_mu (global.h:198; = 2 kappa mu); read by the twisted-mass operators at call time */
+int tmhip_set_mu(tmhip_ctx *ctx, double mu);
+
+/* Upload g_gauge_field (host, su3[VOLUMEPLUSRAND][4], halo links included when
+ * nproc_t > 1) and re-sort it into the device gauge copy.  Replaces
+ * update_backward_gauge() (update_backward_gauge.c:185-242); call whenever
+ * g_update_gauge_copy is set (Hopping_Matrix.c:135-139). */
+int tmhip_set_gauge(tmhip_ctx *ctx, const void *gauge_field_lexic);
+
+/* ---- device fields ------------------------------------------------------ */
+int tmhip_field_alloc(tmhip_ctx *ctx, int kind, tmhip_field **out);
+void tmhip_field_free(tmhip_ctx *ctx, tmhip_field *f);
+/* host `spinor[nsites]` (AoS) <-> device.  EO fields: nsites <= V/2, e/o order of
+ * geometry_eo.c:869-885.  FULL fields: nsites = V, lexicographic order. */
+int tmhip_field_upload(tmhip_ctx *ctx, tmhip_field *f, const void *host_spinors, int nsites);
+int tmhip_field_download(tmhip_ctx *ctx, tmhip_field *f, void *host_spinors, int nsites);
+int tmhip_field_zero(tmhip_ctx *ctx, tmhip_field *f);
+/* FULL field <-> its two parities (linalg/convert_eo_to_lexic.c) -- views, no copy */
+tmhip_field *tmhip_field_even(tmhip_field *full);
+tmhip_field *tmhip_field_odd(tmhip_field *full);
+
+/* ---- stencil (EO fields) ------------------------------------------------ */
+/* Hopping_Matrix(ieo, l, k)            operator/Hopping_Matrix.c:131-156 */
+int tmhip_hopping_matrix(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k);
+/* Hopping_Matrix_nocom                  operator/Hopping_Matrix_nocom.c:48-56 (halo exchange skipped) */
+int tmhip_hopping_matrix_nocom(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k);
+/* tm_times_Hopping_Matrix(ieo,l,k,c)    operator/tm_times_Hopping_Matrix.c:72 ; epilogue hopping.h:674-678 */
+int tmhip_tm_times_hopping_matrix(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, double cre, double cim);
+/* tm_sub_Hopping_Matrix(ieo,l,p,k,c)    operator/tm_sub_Hopping_Matrix.c:73 ; epilogue hopping.h:680-688 */
+int tmhip_tm_sub_hopping_matrix(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *p, tmhip_field *k,
+                                double cre, double cim);
+/* D_psi(P,Q) on FULL fields             operator/D_psi.c:1133-1140, D_psi_body.c:266-375 */
+int tmhip_D_psi(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q);
+
+/* ---- site-diagonal twisted-mass ops (operator/tm_operators.h:26-77) ------ */
+int tmhip_mul_one_pm_imu_inv(tmhip_ctx *ctx, tmhip_field *l, double sign, int N);
+int tmhip_assign_mul_one_pm_imu_inv(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, double sign, int N);
+int tmhip_assign_mul_one_pm_imu(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, double sign, int N);
+int tmhip_mul_one_pm_imu(tmhip_ctx *ctx, tmhip_field *l, double sign);
+int tmhip_mul_one_pm_imu_sub_mul(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, tmhip_field *j, double sign, int N);
+int tmhip_mul_one_pm_imu_sub_mul_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, tmhip_field *j, double sign);
+int tmhip_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int N); /* gamma.c:77-98 */
+
+/* ---- e/o compositions (operator/tm_operators.c) -------------------------- */
+int tmhip_H_eo_tm_inv_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int ieo, double sign); /* :508-526 */
+int tmhip_Qtm_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);   /* :172-177 */
+int tmhip_Qtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);  /* :216-221 */
+int tmhip_Mtm_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);   /* :245-250 */
+int tmhip_Mtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);  /* :289-294 */
+int tmhip_Qtm_pm_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);     /* :338-345 */
+int tmhip_M_full(tmhip_ctx *ctx, tmhip_field *Even_new, tmhip_field *Odd_new,
+                 tmhip_field *Even, tmhip_field *Odd);                    /* :117-128 */
+
+/* ---- spinor linalg (linalg/ of the reference) ---------------------------- */
+/* `parallel` != 0 adds the cross-rank sum (MPI_Allreduce in the reference). */
+int tmhip_square_norm(tmhip_ctx *ctx, tmhip_field *P, int N, int parallel, double *out);                       /* square_norm.c:253 */
+int tmhip_scalar_prod_r(tmhip_ctx *ctx, tmhip_field *S, tmhip_field *R, int N, int parallel, double *out);     /* scalar_prod_r.c:135 */
+int tmhip_assign_add_mul_r(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, double c, int N);                   /* assign_add_mul_r.c:346 */
+int tmhip_assign_mul_add_r(tmhip_ctx *ctx, tmhip_field *R, double c, tmhip_field *S, int N);                   /* assign_mul_add_r.c:340 */
+int tmhip_assign_mul_add_r_and_square(tmhip_ctx *ctx, tmhip_field *R, double c, tmhip_field *S, int N,
+                                      int parallel, double *out);                                             /* assign_mul_add_r_and_square.c:145 */
+int tmhip_diff(tmhip_ctx *ctx, tmhip_field *Q, tmhip_field *R, tmhip_field *S, int N);                         /* diff.c:270 */
+int tmhip_assign(tmhip_ctx *ctx, tmhip_field *R, tmhip_field *S, int N);                                       /* assign.c:42 */
+
+/* ---- solver --------------------------------------------------------------- */
+enum { TMHIP_OP_QTM_PM = 0, TMHIP_OP_QTM_PLUS = 1, TMHIP_OP_QTM_MINUS = 2, TMHIP_OP_MTM_PLUS = 3, TMHIP_OP_MTM_MINUS = 4 };
+/* cg_her(P,Q,max_iter,eps_sq,rel_prec,N,f)   solver/cg_her.c:62-141.
+ * Device-resident: P, Q and the three work fields never leave HBM.  Returns the
+ * iteration count in *iters (-1 if not converged); res_hist (may be NULL) gets
+ * err after each iteration, up to hist_len entries. */
+int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec,
+                 int N, int op, int *iters, double *res_hist, int hist_len);
+
+/* ---- multi-GPU halo exchange (replaces xchange_field / xchange_halffield,
+ *      xchange/xchange_field.c:269-470, xchange/xchange_halffield.c:176-263) -- */
+#define TMHIP_UNIQUE_ID_BYTES 128
+int tmhip_comm_get_unique_id(char id[TMHIP_UNIQUE_ID_BYTES]);             /* rank 0, then broadcast by the host program */
+int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]); /* ring of nproc_t ranks along T over RCCL */
+/* Single-GPU self-test of the split-phase path: faces are packed, "exchanged"
+ * with this rank itself and consumed by the boundary kernel. */
+int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on);
+
+/* ---- measurement ---------------------------------------------------------- */
+/* The benchmark.c:291-300 loop on device-resident fields: iters x {H(0,f1,f0); H(1,f2,f1)},
+ * timed with HIP events on the context's stream.  ms_total = elapsed milliseconds. */
+int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_field *f2, int iters, double *ms_total);
+/* generic event slots (0..15) recorded on the context's compute stream */
+int tmhip_event_record(tmhip_ctx *ctx, int slot);
+int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double *ms);
+/* kernel variant selection for A/B measurements (0 = default). */
+int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,496 @@
+// Context, device fields, host<->device layout conversion, operator compositions, CG,
+// halo exchange and the benchmark loop of libtmlqcd_hip.so (gfx950).
+#include "tmhip_internal.h"
+#include <cmath>
+#include <cstring>
+#include <new>
+
+// ------------------------------------------------------------------ layout kernels
+// host AoS spinor[n] = v2d[n][12]  <->  device SoA [12][ns]
+__global__ __launch_bounds__(256) void aos_to_soa_kernel(const v2d *__restrict__ aos, v2d *__restrict__ soa, int ns, int n) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (tid >= 12L * n) return;
+  const int site = (int)(tid / 12), c = (int)(tid % 12);
+  soa[(size_t)c * ns + site] = aos[tid];
+}
+__global__ __launch_bounds__(256) void soa_to_aos_kernel(const v2d *__restrict__ soa, v2d *__restrict__ aos, int ns, int n) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (tid >= 12L * n) return;
+  const int site = (int)(tid / 12), c = (int)(tid % 12);
+  aos[tid] = soa[(size_t)c * ns + site];
+}
+// lexicographic spinor[V] <-> two e/o halves (even at soa, odd at soa + 12*ns).
+// parity from global coordinates (geometry_eo.c:807-811); e/o sub-index = ix/2 (LZ even).
+template <bool TO_DEVICE>
+__global__ __launch_bounds__(256) void lexic_eo_kernel(v2d *aos, v2d *soa, int ns, int V, int LX, int LY, int LZ, int toff) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (tid >= 12L * V) return;
+  const int ix = (int)(tid / 12), c = (int)(tid % 12);
+  const int z = ix % LZ;
+  int r = ix / LZ;
+  const int y = r % LY;
+  r /= LY;
+  const int x = r % LX, t = r / LX;
+  const int par = (t + x + y + z + toff) & 1;
+  v2d *dst = soa + (size_t)par * 12 * ns + (size_t)c * ns + (ix >> 1);
+  if (TO_DEVICE) *dst = aos[tid];
+  else aos[tid] = *dst;
+}
+
+// raw g_gauge_field (su3[VPR][4] = v2d[VPR][4][9]) -> device gauge copy g[par][dir][e][i]
+//   dir 2mu   : U_mu(x)        = raw[ix][mu]
+//   dir 2mu+1 : U_mu(x - mu)   = raw[idn(ix,mu)][mu]     (update_backward_gauge.c:185-242)
+__global__ __launch_bounds__(256) void gauge_sort_kernel(const v2d *__restrict__ raw, v2d *__restrict__ g, int gs, int Vh, int T,
+                                                         int LX, int LY, int LZ, int toff, int split) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Vh) return;
+  const int par = blockIdx.y;
+  const int LZh = LZ / 2;
+  const int k = i % LZh;
+  int r = i / LZh;
+  const int y = r % LY;
+  r /= LY;
+  const int x = r % LX, t = r / LX;
+  const int o = (t + x + y + toff + par) & 1;
+  const int z = 2 * k + o;
+  const int XYZ = LX * LY * LZ, V = T * XYZ;
+  const int ix = 2 * i + o;
+  int dn[4];
+  if (t > 0) dn[0] = ix - XYZ;
+  else dn[0] = split ? V + XYZ + (ix % XYZ) : ix + (T - 1) * XYZ;  // t = -1 halo slab: geometry_eo.c:296-298
+  dn[1] = (x > 0) ? ix - LY * LZ : ix + (LX - 1) * LY * LZ;
+  dn[2] = (y > 0) ? ix - LZ : ix + (LY - 1) * LZ;
+  dn[3] = (z > 0) ? ix - 1 : ix + (LZ - 1);
+  v2d *gp = g + (size_t)par * 72 * gs + i;
+#pragma unroll
+  for (int mu = 0; mu < 4; mu++) {
+    const v2d *uf = raw + ((size_t)ix * 4 + mu) * 9;
+    const v2d *ub = raw + ((size_t)dn[mu] * 4 + mu) * 9;
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+      gp[(size_t)((2 * mu) * 9 + e) * gs] = uf[e];
+      gp[(size_t)((2 * mu + 1) * 9 + e) * gs] = ub[e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ helpers
+int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes) {
+  if (ctx->stage_bytes >= bytes) return 0;
+  if (ctx->stage) { TMHIP_CHECK(hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+  TMHIP_CHECK(hipMalloc(&ctx->stage, bytes));
+  ctx->stage_bytes = bytes;
+  return 0;
+}
+
+static int field_alloc_impl(tmhip_ctx *ctx, int kind, tmhip_field **out) {
+  tmhip_field *f = new (std::nothrow) tmhip_field();
+  if (!f) TMHIP_FAIL("out of host memory");
+  f->kind = kind; f->ns = ctx->ns; f->view = false; f->half[0] = f->half[1] = nullptr; f->d = nullptr;
+  const size_t elems = (size_t)12 * ctx->ns * (kind == TMHIP_FIELD_FULL ? 2 : 1);
+  TMHIP_CHECK(hipMalloc((void **)&f->d, elems * sizeof(v2d)));
+  TMHIP_CHECK(hipMemsetAsync(f->d, 0, elems * sizeof(v2d), ctx->stream));
+  if (kind == TMHIP_FIELD_FULL) {
+    for (int p = 0; p < 2; p++) {
+      tmhip_field *h = new tmhip_field();
+      h->kind = TMHIP_FIELD_EO; h->ns = ctx->ns; h->view = true; h->half[0] = h->half[1] = nullptr;
+      h->d = f->d + (size_t)p * 12 * ctx->ns;
+      f->half[p] = h;
+    }
+  }
+  *out = f;
+  return 0;
+}
+
+extern "C" {
+
+const char *tmhip_version(void) { return "tmlqcd_hip 0.1 (gfx950)"; }
+
+int tmhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
+  if (!geom || !out) TMHIP_FAIL("tmhip_create: null argument");
+  const tmhip_geom g = *geom;
+  // same constraints as the reference's e/o build (mpi_init.c:784-799: LZ even; e/o needs even extents)
+  if (g.T < 2 || g.LX < 2 || g.LY < 2 || g.LZ < 2 || (g.T & 1) || (g.LX & 1) || (g.LY & 1) || (g.LZ & 1))
+    TMHIP_FAIL("tmhip_create: local extents must be even and >= 2 (got %d %d %d %d)", g.T, g.LX, g.LY, g.LZ);
+  if (g.nproc_t < 1 || g.proc_t < 0 || g.proc_t >= g.nproc_t) TMHIP_FAIL("tmhip_create: bad T decomposition");
+  if ((double)g.T * g.LX * g.LY * g.LZ > 1.0e9) TMHIP_FAIL("tmhip_create: local volume too large for 32-bit site indices");
+  TMHIP_CHECK(hipSetDevice(device));
+  tmhip_ctx *ctx = new (std::nothrow) tmhip_ctx();
+  if (!ctx) TMHIP_FAIL("out of host memory");
+  memset(ctx, 0, sizeof(*ctx));
+  ctx->g = g; ctx->device = device;
+  ctx->V = g.T * g.LX * g.LY * g.LZ; ctx->Vh = ctx->V / 2; ctx->face = g.LX * g.LY * g.LZ / 2;
+  ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
+  ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
+  ctx->opt_block = 128; ctx->opt_xcd = 0; ctx->opt_nt = 1; ctx->opt_variant = 0;
+  TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  TMHIP_CHECK(hipEventCreateWithFlags(&ctx->ev_pack, hipEventDisableTiming));
+  TMHIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
+  for (int i = 0; i < 16; i++) TMHIP_CHECK(hipEventCreate(&ctx->ev_slots[i]));
+  TMHIP_CHECK(hipMalloc((void **)&ctx->gauge, (size_t)2 * 72 * ctx->gs * sizeof(v2d)));
+  ctx->max_partials = 12 * ((ctx->ns + 1023) / 1024 + 1);
+  TMHIP_CHECK(hipMalloc((void **)&ctx->partials, ctx->max_partials * sizeof(double)));
+  TMHIP_CHECK(hipMalloc((void **)&ctx->result_dev, 4 * sizeof(double)));
+  TMHIP_CHECK(hipHostMalloc((void **)&ctx->result_host, 4 * sizeof(double)));
+  const size_t fb = (size_t)6 * ctx->face * sizeof(v2d);
+  TMHIP_CHECK(hipMalloc((void **)&ctx->send_up, fb));
+  TMHIP_CHECK(hipMalloc((void **)&ctx->send_dn, fb));
+  TMHIP_CHECK(hipMalloc((void **)&ctx->recv_up, fb));
+  TMHIP_CHECK(hipMalloc((void **)&ctx->recv_dn, fb));
+  TMHIP_CHECK(hipMemsetAsync(ctx->recv_up, 0, fb, ctx->stream));
+  TMHIP_CHECK(hipMemsetAsync(ctx->recv_dn, 0, fb, ctx->stream));
+  for (int i = 0; i < 3; i++) {
+    if (field_alloc_impl(ctx, TMHIP_FIELD_EO, &ctx->scratch[i])) return 1;
+    if (field_alloc_impl(ctx, TMHIP_FIELD_EO, &ctx->sf[i])) return 1;
+  }
+  const double th[4] = {0, 0, 0, 0};
+  tmhip_set_boundary(ctx, 0.125, th);
+  ctx->mu = 0.0;
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *out = ctx;
+  return 0;
+}
+
+void tmhip_destroy(tmhip_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < 3; i++) { tmhip_field_free(ctx, ctx->scratch[i]); tmhip_field_free(ctx, ctx->sf[i]); }
+  if (ctx->comm_ready) ncclCommDestroy(ctx->comm);
+  (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
+  (void)hipHostFree(ctx->result_host);
+  (void)hipFree(ctx->send_up); (void)hipFree(ctx->send_dn); (void)hipFree(ctx->recv_up); (void)hipFree(ctx->recv_dn);
+  if (ctx->stage) (void)hipFree(ctx->stage);
+  (void)hipEventDestroy(ctx->ev_pack); (void)hipEventDestroy(ctx->ev_comm);
+  for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev_slots[i]);
+  (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->comm_stream);
+  delete ctx;
+}
+
+int tmhip_sync(tmhip_ctx *ctx) {
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->comm_stream));
+  return 0;
+}
+
+/* boundary.c:40-55 */
+int tmhip_set_boundary(tmhip_ctx *ctx, double kappa, const double theta[4]) {
+  const double PI_ = 3.14159265358979;  // boundary.c:36 (the reference's own truncated pi)
+  const int ext[4] = {ctx->g.T * ctx->g.nproc_t, ctx->g.LX, ctx->g.LY, ctx->g.LZ};
+  ctx->kappa = kappa;
+  for (int m = 0; m < 4; m++) {
+    ctx->theta[m] = theta[m];
+    const double x = theta[m] * PI_ / ext[m];
+    ctx->ka[m][0] = kappa * cos(x);
+    ctx->ka[m][1] = kappa * sin(x);
+  }
+  return 0;
+}
+
+int tmhip_set_ka(tmhip_ctx *ctx, const double ka[8]) {
+  for (int m = 0; m < 4; m++) { ctx->ka[m][0] = ka[2 * m]; ctx->ka[m][1] = ka[2 * m + 1]; }
+  return 0;
+}
+
+int tmhip_set_mu(tmhip_ctx *ctx, double mu) { ctx->mu = mu; return 0; }
+
+int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
+  if (!strcmp(name, "block")) { if (value != 64 && value != 128 && value != 256) TMHIP_FAIL("block must be 64/128/256"); ctx->opt_block = value; }
+  else if (!strcmp(name, "xcd")) ctx->opt_xcd = value;
+  else if (!strcmp(name, "nt")) ctx->opt_nt = value;
+  else if (!strcmp(name, "variant")) ctx->opt_variant = value;
+  else TMHIP_FAIL("unknown option %s", name);
+  return 0;
+}
+
+int tmhip_set_gauge(tmhip_ctx *ctx, const void *host) {
+  if (!host) TMHIP_FAIL("tmhip_set_gauge: null gauge field");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)ctx->VPR * 4 * 9 * sizeof(v2d);
+  // the raw copy is only needed during the re-sort: use a temporary, not the persistent staging buffer
+  void *raw = nullptr;
+  TMHIP_CHECK(hipMalloc(&raw, bytes));
+  TMHIP_CHECK(hipMemcpyAsync(raw, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  const int toff = ctx->g.proc_t * ctx->g.T;
+  hipLaunchKernelGGL(gauge_sort_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (const v2d *)raw, ctx->gauge,
+                     ctx->gs, ctx->Vh, ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, toff, ctx->g.nproc_t > 1 ? 1 : 0);
+  TMHIP_CHECK(hipGetLastError());
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  TMHIP_CHECK(hipFree(raw));
+  ctx->gauge_set = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------ fields
+int tmhip_field_alloc(tmhip_ctx *ctx, int kind, tmhip_field **out) {
+  if (kind != TMHIP_FIELD_EO && kind != TMHIP_FIELD_FULL) TMHIP_FAIL("tmhip_field_alloc: bad kind %d", kind);
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  return field_alloc_impl(ctx, kind, out);
+}
+
+void tmhip_field_free(tmhip_ctx *ctx, tmhip_field *f) {
+  if (!f || f->view) return;
+  (void)ctx;
+  (void)hipFree(f->d);
+  if (f->half[0]) delete f->half[0];
+  if (f->half[1]) delete f->half[1];
+  delete f;
+}
+
+tmhip_field *tmhip_field_even(tmhip_field *full) { return (full && full->kind == TMHIP_FIELD_FULL) ? full->half[0] : nullptr; }
+tmhip_field *tmhip_field_odd(tmhip_field *full) { return (full && full->kind == TMHIP_FIELD_FULL) ? full->half[1] : nullptr; }
+
+int tmhip_field_zero(tmhip_ctx *ctx, tmhip_field *f) {
+  const size_t elems = (size_t)12 * f->ns * (f->kind == TMHIP_FIELD_FULL ? 2 : 1);
+  TMHIP_CHECK(hipMemsetAsync(f->d, 0, elems * sizeof(v2d), ctx->stream));
+  return 0;
+}
+
+int tmhip_field_upload(tmhip_ctx *ctx, tmhip_field *f, const void *host, int nsites) {
+  if (!f || !host) TMHIP_FAIL("tmhip_field_upload: null argument");
+  const int maxn = f->kind == TMHIP_FIELD_FULL ? ctx->V : ctx->Vh;
+  if (nsites <= 0 || nsites > maxn) TMHIP_FAIL("tmhip_field_upload: nsites %d out of range (max %d)", nsites, maxn);
+  if (f->kind == TMHIP_FIELD_FULL && nsites != ctx->V) TMHIP_FAIL("tmhip_field_upload: FULL fields take exactly V sites");
+  const size_t bytes = (size_t)nsites * 12 * sizeof(v2d);
+  if (tmhip_stage_reserve(ctx, bytes)) return 1;
+  TMHIP_CHECK(hipMemcpyAsync(ctx->stage, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  const int nb = (int)((12L * nsites + 255) / 256);
+  if (f->kind == TMHIP_FIELD_EO)
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const v2d *)ctx->stage, f->d, f->ns, nsites);
+  else
+    hipLaunchKernelGGL(lexic_eo_kernel<true>, dim3(nb), dim3(256), 0, ctx->stream, (v2d *)ctx->stage, f->d, f->ns, ctx->V,
+                       ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.proc_t * ctx->g.T);
+  TMHIP_CHECK(hipGetLastError());
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));  // staging buffer is reused by the next call
+  return 0;
+}
+
+int tmhip_field_download(tmhip_ctx *ctx, tmhip_field *f, void *host, int nsites) {
+  if (!f || !host) TMHIP_FAIL("tmhip_field_download: null argument");
+  const int maxn = f->kind == TMHIP_FIELD_FULL ? ctx->V : ctx->Vh;
+  if (nsites <= 0 || nsites > maxn) TMHIP_FAIL("tmhip_field_download: nsites %d out of range (max %d)", nsites, maxn);
+  if (f->kind == TMHIP_FIELD_FULL && nsites != ctx->V) TMHIP_FAIL("tmhip_field_download: FULL fields take exactly V sites");
+  const size_t bytes = (size_t)nsites * 12 * sizeof(v2d);
+  if (tmhip_stage_reserve(ctx, bytes)) return 1;
+  const int nb = (int)((12L * nsites + 255) / 256);
+  if (f->kind == TMHIP_FIELD_EO)
+    hipLaunchKernelGGL(soa_to_aos_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const v2d *)f->d, (v2d *)ctx->stage, f->ns, nsites);
+  else
+    hipLaunchKernelGGL(lexic_eo_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, (v2d *)ctx->stage, f->d, f->ns, ctx->V,
+                       ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.proc_t * ctx->g.T);
+  TMHIP_CHECK(hipGetLastError());
+  TMHIP_CHECK(hipMemcpyAsync(host, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------ stencil entry points
+static int need_eo(const tmhip_field *f, const char *who) {
+  if (!f || f->kind != TMHIP_FIELD_EO) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity (EO) field\n", who); return 1; }
+  return 0;
+}
+
+int tmhip_hopping_matrix(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k) {
+  if (need_eo(l, "Hopping_Matrix") || need_eo(k, "Hopping_Matrix")) return 1;
+  return tmhip_launch_hopping(ctx, ieo, l->d, k->d, nullptr, EPI_STORE, 0, 0, true);
+}
+int tmhip_hopping_matrix_nocom(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k) {
+  if (need_eo(l, "Hopping_Matrix_nocom") || need_eo(k, "Hopping_Matrix_nocom")) return 1;
+  return tmhip_launch_hopping(ctx, ieo, l->d, k->d, nullptr, EPI_STORE, 0, 0, false);
+}
+int tmhip_tm_times_hopping_matrix(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, double cre, double cim) {
+  if (need_eo(l, "tm_times_Hopping_Matrix") || need_eo(k, "tm_times_Hopping_Matrix")) return 1;
+  return tmhip_launch_hopping(ctx, ieo, l->d, k->d, nullptr, EPI_TM_TIMES, cre, cim, true);
+}
+int tmhip_tm_sub_hopping_matrix(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *p, tmhip_field *k, double cre, double cim) {
+  if (need_eo(l, "tm_sub_Hopping_Matrix") || need_eo(p, "tm_sub_Hopping_Matrix") || need_eo(k, "tm_sub_Hopping_Matrix")) return 1;
+  return tmhip_launch_hopping(ctx, ieo, l->d, k->d, p->d, EPI_TM_SUB_G5, cre, cim, true);
+}
+
+/* D_psi_body.c:266-375: P = (1 + i mu g5) Q + sum phase_mu hop_mu(Q), phase_mu = -ka_mu (boundary.c:51-54)
+ * => per parity:  P_p = (1 + i mu g5) Q_p - H_{p,1-p} Q_{1-p}  = the tm_sub epilogue without g5. */
+int tmhip_D_psi(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q) {
+  if (!P || !Q || P->kind != TMHIP_FIELD_FULL || Q->kind != TMHIP_FIELD_FULL) TMHIP_FAIL("D_psi needs FULL fields");
+  if (P == Q || P->d == Q->d) {  // D_psi_body.c:267-272
+    fprintf(stderr, "Error in D_psi (operator.c):\nArguments must be different spinor fields\nProgram aborted\n");
+    return 1;
+  }
+  for (int par = 0; par < 2; par++)
+    if (tmhip_launch_hopping(ctx, par, P->half[par]->d, Q->half[1 - par]->d, Q->half[par]->d, EPI_TM_SUB, 1.0, ctx->mu, true))
+      return 1;
+  return 0;
+}
+
+// ------------------------------------------------------------------ e/o compositions (tm_operators.c)
+/* tm_operators.c:508-526 */
+int tmhip_H_eo_tm_inv_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int ieo, double _sign) {
+  const double nrm = 1. / (1. + ctx->mu * ctx->mu), sign = _sign < 0. ? 1. : -1.;
+  return tmhip_tm_times_hopping_matrix(ctx, ieo, l, k, nrm, sign * nrm * ctx->mu);
+}
+/* tm_operators.c:528-546 */
+static int tm_sub_H_eo_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *p, tmhip_field *k, int ieo, double _sign) {
+  const double sign = _sign < 0. ? -1. : 1.;
+  return tmhip_tm_sub_hopping_matrix(ctx, ieo, l, p, k, 1., sign * ctx->mu);
+}
+/* l may alias k for these (invert_eo.c:270 calls Qtm_minus_psi in place): the last stencil reads
+ * k only through the element-wise epilogue `p`, never as a gathered neighbour field. */
+/* tm_operators.c:172-177 */
+int tmhip_Qtm_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  return tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, +1.) ||
+         tm_sub_H_eo_gamma5(ctx, l, k, ctx->scratch[1], TMHIP_OE, +1.);
+}
+/* tm_operators.c:216-221 */
+int tmhip_Qtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  return tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, -1.) ||
+         tm_sub_H_eo_gamma5(ctx, l, k, ctx->scratch[1], TMHIP_OE, -1.);
+}
+/* tm_operators.c:245-250 */
+int tmhip_Mtm_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, +1.)) return 1;
+  return tmhip_launch_hopping(ctx, TMHIP_OE, l->d, ctx->scratch[1]->d, k->d, EPI_TM_SUB, 1., ctx->mu, true);
+}
+/* tm_operators.c:289-294 */
+int tmhip_Mtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, -1.)) return 1;
+  return tmhip_launch_hopping(ctx, TMHIP_OE, l->d, ctx->scratch[1]->d, k->d, EPI_TM_SUB, 1., -ctx->mu, true);
+}
+/* tm_operators.c:338-345 : 4 stencil launches, twists fused into the epilogues */
+int tmhip_Qtm_pm_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  return tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, -1.) ||
+         tm_sub_H_eo_gamma5(ctx, ctx->scratch[0], k, ctx->scratch[1], TMHIP_OE, -1.) ||
+         tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], ctx->scratch[0], TMHIP_EO, +1.) ||
+         tm_sub_H_eo_gamma5(ctx, l, ctx->scratch[0], ctx->scratch[1], TMHIP_OE, +1.);
+}
+/* tm_operators.c:117-128 :  X_new = (1 + i mu g5) X - H Y */
+int tmhip_M_full(tmhip_ctx *ctx, tmhip_field *En, tmhip_field *On, tmhip_field *E, tmhip_field *O) {
+  if (need_eo(En, "M_full") || need_eo(On, "M_full") || need_eo(E, "M_full") || need_eo(O, "M_full")) return 1;
+  return tmhip_launch_hopping(ctx, TMHIP_EO, En->d, O->d, E->d, EPI_TM_SUB, 1., ctx->mu, true) ||
+         tmhip_launch_hopping(ctx, TMHIP_OE, On->d, E->d, O->d, EPI_TM_SUB, 1., ctx->mu, true);
+}
+
+// ------------------------------------------------------------------ solver
+static int apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k) {
+  switch (op) {
+    case TMHIP_OP_QTM_PM: return tmhip_Qtm_pm_psi(ctx, l, k);
+    case TMHIP_OP_QTM_PLUS: return tmhip_Qtm_plus_psi(ctx, l, k);
+    case TMHIP_OP_QTM_MINUS: return tmhip_Qtm_minus_psi(ctx, l, k);
+    case TMHIP_OP_MTM_PLUS: return tmhip_Mtm_plus_psi(ctx, l, k);
+    case TMHIP_OP_MTM_MINUS: return tmhip_Mtm_minus_psi(ctx, l, k);
+  }
+  fprintf(stderr, "[tmlqcd_hip] cg_her: unknown operator id %d\n", op);
+  return 1;
+}
+
+/* solver/cg_her.c:62-141, same recurrences and stopping rule; all fields stay in HBM */
+int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N, int op,
+                 int *iters, double *res_hist, int hist_len) {
+  if (need_eo(P, "cg_her") || need_eo(Q, "cg_her")) return 1;
+  tmhip_field *sf0 = ctx->sf[0], *sf1 = ctx->sf[1], *sf2 = ctx->sf[2], *stmp;
+  double normsq, pro, err = 0, alpha_cg, beta_cg, squarenorm;
+  int iteration;
+  if (tmhip_square_norm(ctx, Q, N, 1, &squarenorm)) return 1;
+  if (apply_op(ctx, op, sf0, P)) return 1;
+  if (tmhip_diff(ctx, sf1, Q, sf0, N)) return 1;
+  if (tmhip_assign(ctx, sf2, sf1, N)) return 1;
+  if (tmhip_square_norm(ctx, sf1, N, 1, &normsq)) return 1;
+  for (iteration = 1; iteration <= max_iter; iteration++) {
+    if (apply_op(ctx, op, sf0, sf2)) return 1;
+    if (tmhip_scalar_prod_r(ctx, sf2, sf0, N, 1, &pro)) return 1;
+    alpha_cg = normsq / pro;
+    if (tmhip_assign_add_mul_r(ctx, P, sf2, alpha_cg, N)) return 1;
+    if (tmhip_assign_mul_add_r_and_square(ctx, sf0, -alpha_cg, sf1, N, 1, &err)) return 1;
+    if (res_hist && iteration - 1 < hist_len) res_hist[iteration - 1] = err;
+    if (((err <= eps_sq) && (rel_prec == 0)) || ((err <= eps_sq * squarenorm) && (rel_prec == 1))) break;
+    beta_cg = err / normsq;
+    if (tmhip_assign_mul_add_r(ctx, sf2, beta_cg, sf0, N)) return 1;
+    stmp = sf0; sf0 = sf1; sf1 = stmp;
+    normsq = err;
+  }
+  *iters = iteration > max_iter ? -1 : iteration;
+  return 0;
+}
+
+// ------------------------------------------------------------------ halo exchange
+int tmhip_comm_get_unique_id(char id[TMHIP_UNIQUE_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) <= TMHIP_UNIQUE_ID_BYTES, "unique id does not fit");
+  ncclUniqueId u;
+  TMHIP_NCCL_CHECK(ncclGetUniqueId(&u));
+  memset(id, 0, TMHIP_UNIQUE_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]) {
+  if (ctx->g.nproc_t < 2) return 0;
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  TMHIP_NCCL_CHECK(ncclCommInitRank(&ctx->comm, ctx->g.nproc_t, u, ctx->g.proc_t));
+  ctx->comm_ready = true;
+  return 0;
+}
+
+int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
+  if (ctx->g.nproc_t > 1) TMHIP_FAIL("loopback is a single-rank self-test");
+  ctx->loopback = on != 0;
+  return 0;
+}
+
+}  // extern "C"
+
+// Runs on ctx->comm_stream.  Ring along T (mpi_init.c:391-394 g_nb_t_up/dn):
+//   send_dn -> rank-1 (lands in its recv_up),  send_up -> rank+1 (lands in its recv_dn).
+int tmhip_halo_exchange(tmhip_ctx *ctx) {
+  const size_t n = (size_t)6 * ctx->face * 2;  // doubles per face
+  if (ctx->g.nproc_t == 1) {  // periodic wrap onto ourselves (loopback self-test)
+    TMHIP_CHECK(hipMemcpyAsync(ctx->recv_up, ctx->send_dn, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm_stream));
+    TMHIP_CHECK(hipMemcpyAsync(ctx->recv_dn, ctx->send_up, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm_stream));
+    return 0;
+  }
+  if (!ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
+  const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
+  TMHIP_NCCL_CHECK(ncclGroupStart());
+  TMHIP_NCCL_CHECK(ncclSend(ctx->send_dn, n, ncclDouble, dn, ctx->comm, ctx->comm_stream));
+  TMHIP_NCCL_CHECK(ncclRecv(ctx->recv_up, n, ncclDouble, up, ctx->comm, ctx->comm_stream));
+  TMHIP_NCCL_CHECK(ncclSend(ctx->send_up, n, ncclDouble, up, ctx->comm, ctx->comm_stream));
+  TMHIP_NCCL_CHECK(ncclRecv(ctx->recv_dn, n, ncclDouble, dn, ctx->comm, ctx->comm_stream));
+  TMHIP_NCCL_CHECK(ncclGroupEnd());
+  return 0;
+}
+
+// ------------------------------------------------------------------ measurement
+extern "C" {
+
+int tmhip_event_record(tmhip_ctx *ctx, int slot) {
+  if (slot < 0 || slot >= 16) TMHIP_FAIL("event slot out of range");
+  TMHIP_CHECK(hipEventRecord(ctx->ev_slots[slot], ctx->stream));
+  return 0;
+}
+int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int a, int b, double *ms) {
+  if (a < 0 || a >= 16 || b < 0 || b >= 16) TMHIP_FAIL("event slot out of range");
+  TMHIP_CHECK(hipEventSynchronize(ctx->ev_slots[b]));
+  float f = 0;
+  TMHIP_CHECK(hipEventElapsedTime(&f, ctx->ev_slots[a], ctx->ev_slots[b]));
+  *ms = f;
+  return 0;
+}
+
+/* benchmark.c:291-300 */
+int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_field *f2, int iters, double *ms_total) {
+  if (tmhip_event_record(ctx, 14)) return 1;
+  for (int j = 0; j < iters; j++) {
+    if (tmhip_hopping_matrix(ctx, 0, f1, f0)) return 1;
+    if (tmhip_hopping_matrix(ctx, 1, f2, f1)) return 1;
+  }
+  if (tmhip_event_record(ctx, 15)) return 1;
+  return tmhip_event_elapsed_ms(ctx, 14, 15, ms_total);
+}
+
+}  // extern "C"

@@ -1,0 +1,534 @@
+// libtmlqcd_dropin.so -- tmLQCD's own hot-path symbols on top of the HIP core library.
+//
+// Host side only (no device code here): reads the reference's globals at call time, keeps
+// a registry host-pointer -> device mirror, and forwards to include/tmlqcd_hip.h.
+// Each entry point cites the reference function it replaces (paths under /root/reference).
+#include "../../include/tmlqcd_dropin.h"
+#include "../../include/tmlqcd_hip.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+extern "C" {
+// ---- globals owned by the host program (global.h, boundary.h) ----
+extern int T, LX, LY, LZ, VOLUME, RAND, VOLUMEPLUSRAND;         /* global.h:82-84 */
+extern int g_nproc_t, g_nproc_x, g_nproc_y, g_nproc_z;           /* global.h:206 */
+extern int g_proc_coords[4];                                      /* global.h:207 */
+extern su3 **g_gauge_field;                                       /* global.h:176 */
+extern int g_update_gauge_copy;                                   /* global.h:73  */
+extern double g_mu;                                               /* global.h:198 */
+extern TM_COMPLEX ka0, ka1, ka2, ka3;                             /* boundary.h:25 */
+// Present in a full tmLQCD link (update_backward_gauge.c, libhmc.a); refreshes the HOST gauge
+// copy that deriv_Sb.c:405-408,472 still reads, and clears g_update_gauge_copy.
+void update_backward_gauge(su3 **const gf) __attribute__((weak));
+}
+
+namespace {
+
+struct Mirror {
+  tmhip_field *f = nullptr;
+  int kind = TMHIP_FIELD_EO;
+  bool dev_valid = false;   // device copy holds the current data
+  bool host_valid = true;   // host copy holds the current data
+};
+
+tmhip_ctx *g_ctx = nullptr;
+int g_device = -1;
+int g_mode = TMLQCD_HIP_COHERENT;
+int g_dims[6] = {0, 0, 0, 0, 0, 0};
+std::unordered_map<const void *, Mirror> g_reg;
+
+[[noreturn]] void die(const char *what) {
+  fprintf(stderr, "[tmlqcd_dropin] fatal: %s\n", what);
+  exit(1);  // the reference's error convention (fatal_error.c)
+}
+#define CK(call) do { if ((call) != 0) die(#call); } while (0)
+
+tmhip_ctx *ctx() {
+  if (!g_ctx) {
+    if (g_nproc_x != 1 || g_nproc_y != 1 || g_nproc_z != 1)
+      die("only T-direction decomposition is supported (g_nproc_x/y/z must be 1)");
+    if (g_device < 0) {
+      const char *e = getenv("TMLQCD_HIP_DEVICE");
+      g_device = e ? atoi(e) : 0;
+    }
+    tmhip_geom g = {T, LX, LY, LZ, g_nproc_t < 1 ? 1 : g_nproc_t, g_proc_coords[0]};
+    CK(tmhip_create(&g, g_device, &g_ctx));
+    g_dims[0] = T; g_dims[1] = LX; g_dims[2] = LY; g_dims[3] = LZ; g_dims[4] = g.nproc_t; g_dims[5] = g.proc_t;
+  } else if (g_dims[0] != T || g_dims[1] != LX || g_dims[2] != LY || g_dims[3] != LZ) {
+    die("lattice extents changed after the first call");
+  }
+  return g_ctx;
+}
+
+// Re-read everything the reference reads through globals (SURVEY §8b "Data it reads through globals").
+tmhip_ctx *refresh(bool need_gauge) {
+  tmhip_ctx *c = ctx();
+  const double ka[8] = {__real__ ka0, __imag__ ka0, __real__ ka1, __imag__ ka1,
+                        __real__ ka2, __imag__ ka2, __real__ ka3, __imag__ ka3};
+  CK(tmhip_set_ka(c, ka));
+  CK(tmhip_set_mu(c, g_mu));
+  static bool gauge_uploaded = false;
+  if (need_gauge && (g_update_gauge_copy || !gauge_uploaded)) {   /* Hopping_Matrix.c:135-139 */
+    if (update_backward_gauge) update_backward_gauge(g_gauge_field);  // host copy + flag, as the reference
+    else g_update_gauge_copy = 0;
+    CK(tmhip_set_gauge(c, &g_gauge_field[0][0]));
+    gauge_uploaded = true;
+  }
+  return c;
+}
+
+int kind_of_N(int N) {
+  if (N == VOLUME / 2) return TMHIP_FIELD_EO;
+  if (N == VOLUME) return TMHIP_FIELD_FULL;
+  die("linalg/operator call with N that is neither VOLUME/2 nor VOLUME is not supported on the device");
+}
+
+int nsites(int kind) { return kind == TMHIP_FIELD_FULL ? VOLUME : VOLUME / 2; }
+
+void download(tmhip_ctx *c, const void *host, Mirror &m) {
+  CK(tmhip_field_download(c, m.f, const_cast<void *>(host), nsites(m.kind)));
+  m.host_valid = true;
+}
+
+Mirror &mirror(tmhip_ctx *c, const void *host, int kind) {
+  Mirror &m = g_reg[host];
+  if (m.f && m.kind != kind) {   // same host buffer re-used with another shape
+    if (m.dev_valid && !m.host_valid) download(c, host, m);
+    tmhip_field_free(c, m.f);
+    m = Mirror();
+  }
+  if (!m.f) {
+    CK(tmhip_field_alloc(c, kind, &m.f));
+    m.kind = kind; m.dev_valid = false; m.host_valid = true;
+  }
+  return m;
+}
+
+tmhip_field *in(tmhip_ctx *c, const void *host, int kind) {
+  Mirror &m = mirror(c, host, kind);
+  if (g_mode == TMLQCD_HIP_COHERENT || !m.dev_valid) {
+    if (!(m.dev_valid && !m.host_valid))   // never overwrite newer device data with a stale host copy
+      CK(tmhip_field_upload(c, m.f, host, nsites(kind)));
+    m.dev_valid = true;
+  }
+  return m.f;
+}
+
+tmhip_field *out(tmhip_ctx *c, const void *host, int kind) { return mirror(c, host, kind).f; }
+
+void done(tmhip_ctx *c, const void *host) {
+  Mirror &m = g_reg[host];
+  m.dev_valid = true; m.host_valid = false;
+  if (g_mode == TMLQCD_HIP_COHERENT) download(c, host, m);
+}
+
+tmhip_field *half(tmhip_field *f, int kind, int par) {
+  if (kind == TMHIP_FIELD_EO) return f;
+  return par ? tmhip_field_odd(f) : tmhip_field_even(f);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ residency control
+void tmlqcd_hip_set_device(int device) { g_device = device; }
+void tmlqcd_hip_set_residency(int mode) {
+  if (mode == TMLQCD_HIP_COHERENT && g_mode == TMLQCD_HIP_RESIDENT) tmlqcd_hip_sync_all_to_host();
+  g_mode = mode;
+}
+void tmlqcd_hip_sync_to_host(spinor *field) {
+  auto it = g_reg.find(field);
+  if (it == g_reg.end() || !it->second.f) return;
+  if (it->second.dev_valid && !it->second.host_valid) download(ctx(), field, it->second);
+}
+void tmlqcd_hip_sync_all_to_host(void) {
+  for (auto &kv : g_reg)
+    if (kv.second.f && kv.second.dev_valid && !kv.second.host_valid) download(ctx(), kv.first, kv.second);
+}
+void tmlqcd_hip_host_modified(spinor *field) {
+  auto it = g_reg.find(field);
+  if (it != g_reg.end()) { it->second.dev_valid = false; it->second.host_valid = true; }
+}
+void tmlqcd_hip_forget(spinor *field) {
+  auto it = g_reg.find(field);
+  if (it == g_reg.end()) return;
+  if (it->second.f) tmhip_field_free(g_ctx, it->second.f);
+  g_reg.erase(it);
+}
+void tmlqcd_hip_comm_init(const char unique_id[128]) { CK(tmhip_comm_init(ctx(), unique_id)); }
+void tmlqcd_hip_finalize(void) {
+  if (!g_ctx) return;
+  tmlqcd_hip_sync_all_to_host();
+  for (auto &kv : g_reg) if (kv.second.f) tmhip_field_free(g_ctx, kv.second.f);
+  g_reg.clear();
+  tmhip_destroy(g_ctx);
+  g_ctx = nullptr;
+}
+
+// ------------------------------------------------------------------ stencil
+/* operator/Hopping_Matrix.c:131-156 */
+void Hopping_Matrix(const int ieo, spinor *const l, spinor *const k) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_hopping_matrix(c, ieo, fl, fk));
+  done(c, l);
+}
+/* operator/Hopping_Matrix_nocom.c:48-56 */
+void Hopping_Matrix_nocom(const int ieo, spinor *const l, spinor *const k) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_hopping_matrix_nocom(c, ieo, fl, fk));
+  done(c, l);
+}
+/* operator/tm_times_Hopping_Matrix.c:72-153 */
+void tm_times_Hopping_Matrix(const int ieo, spinor *const l, spinor *const k, TM_COMPLEX const cfactor) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_tm_times_hopping_matrix(c, ieo, fl, fk, __real__ cfactor, __imag__ cfactor));
+  done(c, l);
+}
+/* operator/tm_sub_Hopping_Matrix.c:73-157 */
+void tm_sub_Hopping_Matrix(const int ieo, spinor *const l, spinor *p, spinor *const k, TM_COMPLEX const cfactor) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fp = in(c, p, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_tm_sub_hopping_matrix(c, ieo, fl, fp, fk, __real__ cfactor, __imag__ cfactor));
+  done(c, l);
+}
+/* operator/D_psi.c:1133-1140 -> D_psi_body.c:266-375 (g_c_sw = 0 branch) */
+void D_psi(spinor *const P, spinor *const Q) {
+  if (P == Q) {   /* D_psi_body.c:267-272 */
+    printf("Error in D_psi (operator.c):\nArguments must be different spinor fields\nProgram aborted\n");
+    exit(1);
+  }
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fq = in(c, Q, TMHIP_FIELD_FULL), *fp = out(c, P, TMHIP_FIELD_FULL);
+  CK(tmhip_D_psi(c, fp, fq));
+  done(c, P);
+}
+
+// ------------------------------------------------------------------ e/o operators (tm_operators.c)
+#define EO_OP(NAME, CORE)                                                                  \
+  void NAME(spinor *const l, spinor *const k) {                                            \
+    tmhip_ctx *c = refresh(true);                                                          \
+    tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);           \
+    CK(CORE(c, fl, fk));                                                                   \
+    done(c, l);                                                                            \
+  }
+EO_OP(Qtm_plus_psi, tmhip_Qtm_plus_psi)        /* tm_operators.c:172-177 */
+EO_OP(Qtm_minus_psi, tmhip_Qtm_minus_psi)      /* tm_operators.c:216-221 */
+EO_OP(Mtm_plus_psi, tmhip_Mtm_plus_psi)        /* tm_operators.c:245-250 */
+EO_OP(Mtm_minus_psi, tmhip_Mtm_minus_psi)      /* tm_operators.c:289-294 */
+EO_OP(Qtm_pm_psi, tmhip_Qtm_pm_psi)            /* tm_operators.c:338-345 */
+/* The _nocom variants differ from the above only by skipping the halo exchange
+ * (tm_operators.c:179-184,252-257,369-379); on one GPU they are the same function. */
+void Qtm_plus_psi_nocom(spinor *const l, spinor *const k) { Qtm_plus_psi(l, k); }
+void Mtm_plus_psi_nocom(spinor *const l, spinor *const k) { Mtm_plus_psi(l, k); }
+void Qtm_pm_psi_nocom(spinor *const l, spinor *const k) { Qtm_pm_psi(l, k); }
+
+/* tm_operators.c:508-526 */
+void H_eo_tm_inv_psi(spinor *const l, spinor *const k, const int ieo, const double sign) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_H_eo_tm_inv_psi(c, fl, fk, ieo, sign));
+  done(c, l);
+}
+/* tm_operators.c:117-128 */
+void M_full(spinor *const En, spinor *const On, spinor *const E, spinor *const O) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fe = in(c, E, TMHIP_FIELD_EO), *fo = in(c, O, TMHIP_FIELD_EO);
+  tmhip_field *fen = out(c, En, TMHIP_FIELD_EO), *fon = out(c, On, TMHIP_FIELD_EO);
+  CK(tmhip_M_full(c, fen, fon, fe, fo));
+  done(c, En); done(c, On);
+}
+/* tm_operators.c:130-143 */
+void Q_full(spinor *const En, spinor *const On, spinor *const E, spinor *const O) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fe = in(c, E, TMHIP_FIELD_EO), *fo = in(c, O, TMHIP_FIELD_EO);
+  tmhip_field *fen = out(c, En, TMHIP_FIELD_EO), *fon = out(c, On, TMHIP_FIELD_EO);
+  CK(tmhip_M_full(c, fen, fon, fe, fo));
+  CK(tmhip_gamma5(c, fen, fen, VOLUME / 2));
+  CK(tmhip_gamma5(c, fon, fon, VOLUME / 2));
+  done(c, En); done(c, On);
+}
+/* tm_operators.c:145-155 */
+void M_minus_1_timesC(spinor *const En, spinor *const On, spinor *const E, spinor *const O) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fe = in(c, E, TMHIP_FIELD_EO), *fo = in(c, O, TMHIP_FIELD_EO);
+  tmhip_field *fen = out(c, En, TMHIP_FIELD_EO), *fon = out(c, On, TMHIP_FIELD_EO);
+  CK(tmhip_H_eo_tm_inv_psi(c, fen, fo, TMHIP_EO, +1.));
+  CK(tmhip_H_eo_tm_inv_psi(c, fon, fe, TMHIP_OE, +1.));
+  done(c, En); done(c, On);
+}
+
+// ------------------------------------------------------------------ site-diagonal ops
+/* mul_one_pm_imu_inv_body.c:1-41 */
+void mul_one_pm_imu_inv(spinor *const l, const double _sign, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fl = in(c, l, kind);
+  for (int p = 0; p <= kind; p++) CK(tmhip_mul_one_pm_imu_inv(c, half(fl, kind, p), _sign, VOLUME / 2));
+  done(c, l);
+}
+/* mul_one_pm_imu_inv_body.c:43-80 */
+void assign_mul_one_pm_imu_inv(spinor *const l, spinor *const k, const double _sign, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fk = in(c, k, kind), *fl = out(c, l, kind);
+  for (int p = 0; p <= kind; p++) CK(tmhip_assign_mul_one_pm_imu_inv(c, half(fl, kind, p), half(fk, kind, p), _sign, VOLUME / 2));
+  done(c, l);
+}
+/* tm_operators.c:669-720 */
+void assign_mul_one_pm_imu(spinor *const l, spinor *const k, const double _sign, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fk = in(c, k, kind), *fl = out(c, l, kind);
+  for (int p = 0; p <= kind; p++) CK(tmhip_assign_mul_one_pm_imu(c, half(fl, kind, p), half(fk, kind, p), _sign, VOLUME / 2));
+  done(c, l);
+}
+/* tm_operators.c:627-667 */
+void mul_one_pm_imu(spinor *const l, const double _sign) {
+  tmhip_ctx *c = refresh(false);
+  tmhip_field *fl = in(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_mul_one_pm_imu(c, fl, _sign));
+  done(c, l);
+}
+/* mul_one_pm_imu_sub_mul_body.c:1-48 */
+void mul_one_pm_imu_sub_mul(spinor *const l, spinor *const k, spinor *const j, const double _sign, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fk = in(c, k, kind), *fj = in(c, j, kind), *fl = out(c, l, kind);
+  for (int p = 0; p <= kind; p++)
+    CK(tmhip_mul_one_pm_imu_sub_mul(c, half(fl, kind, p), half(fk, kind, p), half(fj, kind, p), _sign, VOLUME / 2));
+  done(c, l);
+}
+/* tm_operators.c:813-858 */
+void mul_one_pm_imu_sub_mul_gamma5(spinor *const l, spinor *const k, spinor *const j, const double _sign) {
+  tmhip_ctx *c = refresh(false);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fj = in(c, j, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_mul_one_pm_imu_sub_mul_gamma5(c, fl, fk, fj, _sign));
+  done(c, l);
+}
+/* tm_operators.c:723-775: l = (1 + i mu g5) k with an explicit mu */
+void Mee_psi(spinor *const l, spinor *const k, const double mu) {
+  tmhip_ctx *c = refresh(false);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_set_mu(c, mu));
+  CK(tmhip_assign_mul_one_pm_imu(c, fl, fk, +1., VOLUME / 2));
+  CK(tmhip_set_mu(c, g_mu));
+  done(c, l);
+}
+/* tm_operators.c:587-625: l = (1 - i mu g5)/(1+mu^2) k with an explicit mu */
+void Mee_inv_psi(spinor *const l, spinor *const k, const double mu) {
+  tmhip_ctx *c = refresh(false);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_set_mu(c, mu));
+  CK(tmhip_assign_mul_one_pm_imu_inv(c, fl, fk, +1., VOLUME / 2));
+  CK(tmhip_set_mu(c, g_mu));
+  done(c, l);
+}
+/* gamma.c:77-98 */
+void gamma5(spinor *const l, spinor *const k, const int V) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(V);
+  tmhip_field *fk = in(c, k, kind), *fl = out(c, l, kind);
+  for (int p = 0; p <= kind; p++) CK(tmhip_gamma5(c, half(fl, kind, p), half(fk, kind, p), VOLUME / 2));
+  done(c, l);
+}
+
+// ------------------------------------------------------------------ full-lattice operators
+/* The reference toggles g_mu's sign around D_psi (tm_operators.c:380-492); refresh() re-reads it. */
+static tmhip_field *g_full_tmp = nullptr;
+static tmhip_field *full_tmp(tmhip_ctx *c) {
+  if (!g_full_tmp) CK(tmhip_field_alloc(c, TMHIP_FIELD_FULL, &g_full_tmp));
+  return g_full_tmp;
+}
+static void g5_full(tmhip_ctx *c, tmhip_field *l, tmhip_field *k) {
+  CK(tmhip_gamma5(c, tmhip_field_even(l), tmhip_field_even(k), VOLUME / 2));
+  CK(tmhip_gamma5(c, tmhip_field_odd(l), tmhip_field_odd(k), VOLUME / 2));
+}
+/* tm_operators.c:111-114 */
+void Q_psi(spinor *const P, spinor *const Q) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fq = in(c, Q, TMHIP_FIELD_FULL), *fp = out(c, P, TMHIP_FIELD_FULL);
+  CK(tmhip_D_psi(c, fp, fq)); g5_full(c, fp, fp);
+  done(c, P);
+}
+/* tm_operators.c:486-490 */
+void Q_plus_psi(spinor *const l, spinor *const k) { Q_psi(l, k); }
+/* tm_operators.c:460-466 */
+void Q_minus_psi(spinor *const l, spinor *const k) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL);
+  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, fl, fk)); CK(tmhip_set_mu(c, g_mu));
+  g5_full(c, fl, fl);
+  done(c, l);
+}
+/* tm_operators.c:468-473 */
+void M_minus_psi(spinor *const l, spinor *const k) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL);
+  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, fl, fk)); CK(tmhip_set_mu(c, g_mu));
+  done(c, l);
+}
+/* tm_operators.c:380-388 : Q_+ Q_- on the full lattice */
+void Q_pm_psi(spinor *const l, spinor *const k) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL), *tmp = full_tmp(c);
+  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, fl, fk));
+  g5_full(c, tmp, fl);
+  CK(tmhip_set_mu(c, g_mu)); CK(tmhip_D_psi(c, fl, tmp));
+  g5_full(c, fl, fl);
+  done(c, l);
+}
+/* tm_operators.c:390-397 */
+void D_dagg_psi(spinor *const l, spinor *const k) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL), *tmp = full_tmp(c);
+  g5_full(c, fl, fk);
+  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, tmp, fl)); CK(tmhip_set_mu(c, g_mu));
+  g5_full(c, fl, tmp);
+  done(c, l);
+}
+
+// ------------------------------------------------------------------ linalg
+/* linalg/square_norm.c:253-320 */
+double square_norm(const spinor *const P, const int N, const int parallel) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fp = in(c, P, kind);
+  double res = 0, r;
+  for (int p = 0; p <= kind; p++) { CK(tmhip_square_norm(c, half(fp, kind, p), VOLUME / 2, parallel, &r)); res += r; }
+  return res;
+}
+/* linalg/scalar_prod_r.c:135-197 */
+double scalar_prod_r(const spinor *const S, const spinor *const R, const int N, const int parallel) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fs = in(c, S, kind), *fr = in(c, R, kind);
+  double res = 0, r;
+  for (int p = 0; p <= kind; p++) { CK(tmhip_scalar_prod_r(c, half(fs, kind, p), half(fr, kind, p), VOLUME / 2, parallel, &r)); res += r; }
+  return res;
+}
+/* linalg/assign_add_mul_r.c:346-381 */
+void assign_add_mul_r(spinor *const P, spinor *const Q, const double cc, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fp = in(c, P, kind), *fq = in(c, Q, kind);
+  for (int p = 0; p <= kind; p++) CK(tmhip_assign_add_mul_r(c, half(fp, kind, p), half(fq, kind, p), cc, VOLUME / 2));
+  done(c, P);
+}
+/* linalg/assign_mul_add_r.c:340-377 */
+void assign_mul_add_r(spinor *const R, const double cc, const spinor *const S, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fr = in(c, R, kind), *fs = in(c, S, kind);
+  for (int p = 0; p <= kind; p++) CK(tmhip_assign_mul_add_r(c, half(fr, kind, p), cc, half(fs, kind, p), VOLUME / 2));
+  done(c, R);
+}
+/* linalg/assign_mul_add_r_and_square.c:145-213 */
+double assign_mul_add_r_and_square(spinor *const R, const double cc, const spinor *const S, const int N, const int parallel) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fr = in(c, R, kind), *fs = in(c, S, kind);
+  double res = 0, r;
+  for (int p = 0; p <= kind; p++) {
+    CK(tmhip_assign_mul_add_r_and_square(c, half(fr, kind, p), cc, half(fs, kind, p), VOLUME / 2, parallel, &r));
+    res += r;
+  }
+  done(c, R);
+  return res;
+}
+/* linalg/diff.c:270-309 */
+void diff(spinor *const Q, const spinor *const R, const spinor *const S, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fr = in(c, R, kind), *fs = in(c, S, kind), *fq = out(c, Q, kind);
+  for (int p = 0; p <= kind; p++) CK(tmhip_diff(c, half(fq, kind, p), half(fr, kind, p), half(fs, kind, p), VOLUME / 2));
+  done(c, Q);
+}
+/* linalg/assign.c:42-46 */
+void assign(spinor *const R, spinor *const S, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fs = in(c, S, kind), *fr = out(c, R, kind);
+  for (int p = 0; p <= kind; p++) CK(tmhip_assign(c, half(fr, kind, p), half(fs, kind, p), VOLUME / 2));
+  done(c, R);
+}
+
+// ------------------------------------------------------------------ solver
+/* solver/cg_her.c:62-141.  For the e/o operators of this library the whole solve runs
+ * device-resident (tmhip_cg_her); for any other `f` the reference loop is executed with the
+ * drop-in linalg in COHERENT mode, which is correct for an arbitrary host-side f. */
+int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, const int rel_prec, const int N,
+           matrix_mult f) {
+  int op = -1;
+  if (f == &Qtm_pm_psi) op = TMHIP_OP_QTM_PM;
+  else if (f == &Qtm_plus_psi) op = TMHIP_OP_QTM_PLUS;
+  else if (f == &Qtm_minus_psi) op = TMHIP_OP_QTM_MINUS;
+  else if (f == &Mtm_plus_psi) op = TMHIP_OP_MTM_PLUS;
+  else if (f == &Mtm_minus_psi) op = TMHIP_OP_MTM_MINUS;
+  if (op >= 0 && N == VOLUME / 2) {
+    tmhip_ctx *c = refresh(true);
+    tmhip_field *fq = in(c, Q, TMHIP_FIELD_EO), *fp = in(c, P, TMHIP_FIELD_EO);
+    int iters = -1;
+    CK(tmhip_cg_her(c, fp, fq, max_iter, eps_sq, rel_prec, N, op, &iters, nullptr, 0));
+    Mirror &m = g_reg[P];
+    m.dev_valid = true; m.host_valid = false;
+    download(c, P, m);   // the solution is always handed back on the host
+    return iters;
+  }
+  // generic path: reference algorithm verbatim on host-visible fields
+  const int saved = g_mode;
+  tmlqcd_hip_set_residency(TMLQCD_HIP_COHERENT);
+  const size_t Vf = (size_t)(N == VOLUME ? VOLUMEPLUSRAND : VOLUMEPLUSRAND / 2);
+  spinor *blk = (spinor *)calloc(3 * Vf + 1, sizeof(spinor));   /* solver_field.c:31-71 */
+  if (!blk) die("cg_her: out of memory");
+  spinor *sf[3] = {blk, blk + Vf, blk + 2 * Vf}, *stmp;
+  double normsq, pro, err, alpha_cg, beta_cg, squarenorm;
+  int iteration;
+  squarenorm = square_norm(Q, N, 1);
+  f(sf[0], P);
+  diff(sf[1], Q, sf[0], N);
+  assign(sf[2], sf[1], N);
+  normsq = square_norm(sf[1], N, 1);
+  for (iteration = 1; iteration <= max_iter; iteration++) {
+    f(sf[0], sf[2]);
+    pro = scalar_prod_r(sf[2], sf[0], N, 1);
+    alpha_cg = normsq / pro;
+    assign_add_mul_r(P, sf[2], alpha_cg, N);
+    err = assign_mul_add_r_and_square(sf[0], -alpha_cg, sf[1], N, 1);
+    if (((err <= eps_sq) && (rel_prec == 0)) || ((err <= eps_sq * squarenorm) && (rel_prec == 1))) break;
+    beta_cg = err / normsq;
+    assign_mul_add_r(sf[2], beta_cg, sf[0], N);
+    stmp = sf[0]; sf[0] = sf[1]; sf[1] = stmp;
+    normsq = err;
+  }
+  for (int i = 0; i < 3; i++) tmlqcd_hip_forget(blk + i * Vf);  // addresses are about to be recycled
+  free(blk);
+  g_mode = saved;
+  if (iteration > max_iter) return -1;
+  return iteration;
+}
+
+// ------------------------------------------------------------------ benchmark helper
+/* benchmark.c:291-300 with the three fields resident in HBM */
+double tmlqcd_hip_benchmark_loop(spinor *f0, spinor *f1, spinor *f2, int iters) {
+  tmhip_ctx *c = refresh(true);
+  const int saved = g_mode;
+  g_mode = TMLQCD_HIP_RESIDENT;
+  tmhip_field *d0 = in(c, f0, TMHIP_FIELD_EO), *d1 = out(c, f1, TMHIP_FIELD_EO), *d2 = out(c, f2, TMHIP_FIELD_EO);
+  double ms = 0;
+  CK(tmhip_bench_hopping(c, d0, d1, d2, iters, &ms));
+  g_reg[f1].dev_valid = true; g_reg[f1].host_valid = false;
+  g_reg[f2].dev_valid = true; g_reg[f2].host_valid = false;
+  g_mode = saved;
+  if (g_mode == TMLQCD_HIP_COHERENT) { tmlqcd_hip_sync_to_host(f1); tmlqcd_hip_sync_to_host(f2); }
+  return ms * 1e-3;
+}
+
+}  // extern "C"

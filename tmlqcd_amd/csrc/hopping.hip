@@ -1,0 +1,299 @@
+// Even/odd Wilson twisted-mass hopping stencil for gfx950 (MI355X), fp64.
+//
+// Computes, for every site x of parity ieo,
+//   l(x) = sum_mu [ ka_mu U_mu(x) (1+g_mu) k(x+mu) + conj(ka_mu) U_mu(x-mu)^dag (1-g_mu) k(x-mu) ]
+// exactly as the reference's generic body (operator/hopping_body_dbl.c:27-181 with the
+// macros of operator/hopping.h:574-694), optionally followed by the fused epilogues of
+// tm_times_Hopping_Matrix (hopping.h:674-678) and tm_sub_Hopping_Matrix (hopping.h:680-688).
+//
+// MI355X mapping:
+//  * one thread per output site, lanes consecutive in the e/o sub-index -> every global
+//    load is a 16 B/lane, 1 KiB/wave coalesced read of one SoA plane (12 spinor planes,
+//    72 gauge planes); the z/y/x/t neighbours of a wave are contiguous runs of the same
+//    planes, so the 8-fold spinor re-use is served by L1/L2/Infinity Cache and HBM sees
+//    each input spinor ~once.
+//  * neighbour indices are computed arithmetically from (t,x,y,k): the reference's
+//    g_hi gather table (64 B/site, geometry_eo.c:1470-1535) is never read.
+//  * gauge links are used exactly once per call -> loaded non-temporally so they do
+//    not evict the re-used spinor lines from L2.
+//  * MFMA is not used: 3x3 complex mat-vec at 1 flop/B, HBM-bound by ~10x.
+#include "tmhip_internal.h"
+
+struct HopArgs {
+  v2d *out;
+  const v2d *in;
+  const v2d *p;
+  const v2d *gauge;  // already offset to the parity of the output sites
+  const v2d *halo_up, *halo_dn;
+  int ns, gs;
+  int T, LX, LY, LZh;
+  int Vh, face, YZh;
+  int i_begin, i_end;
+  int par_off;  // (proc_t*T + ieo) & 1
+  int nxcd_chunk;  // >0: XCD-aware block remap, blocks per XCD chunk
+  double ka[4][2];
+  double cre, cim;
+};
+
+__device__ __forceinline__ v2d cmul(v2d a, v2d b) { return v2d{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ v2d cmulc(v2d a, v2d b) {  // conj(a) * b
+  return v2d{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ v2d cfma(v2d a, v2d b, v2d c) {  // c + a*b
+  return v2d{c.x + a.x * b.x - a.y * b.y, c.y + a.x * b.y + a.y * b.x};
+}
+__device__ __forceinline__ v2d cfmac(v2d a, v2d b, v2d c) {  // c + conj(a)*b
+  return v2d{c.x + a.x * b.x + a.y * b.y, c.y + a.x * b.y - a.y * b.x};
+}
+
+template <bool NT>
+__device__ __forceinline__ v2d ldg(const v2d *p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+// One of the 8 hops.  D = 2*mu + (0: +mu, 1: -mu), mu = t,x,y,z.
+// HALO: the projected half-spinor comes from an exchanged face buffer [6][face] instead of `in`.
+template <int D, bool HALO, bool NT>
+__device__ __forceinline__ void hop_dir(v2d (&acc)[12], const v2d *__restrict__ in, int ns, int j,
+                                        const v2d *__restrict__ halo, int face,
+                                        const v2d *__restrict__ g, size_t gs, int i, v2d ka) {
+  v2d pa[3], pb[3];
+  if (HALO) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      pa[c] = halo[(size_t)c * face + j];
+      pb[c] = halo[(size_t)(3 + c) * face + j];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const v2d s0 = in[(size_t)(0 + c) * ns + j], s1 = in[(size_t)(3 + c) * ns + j];
+      const v2d s2 = in[(size_t)(6 + c) * ns + j], s3 = in[(size_t)(9 + c) * ns + j];
+      if (D == 0) { pa[c] = s0 + s2; pb[c] = s1 + s3; }                                           // hopping.h:579,584
+      if (D == 1) { pa[c] = s0 - s2; pb[c] = s1 - s3; }                                           // hopping.h:591,596
+      if (D == 2) { pa[c] = v2d{s0.x - s3.y, s0.y + s3.x}; pb[c] = v2d{s1.x - s2.y, s1.y + s2.x}; }  // s0+i s3, s1+i s2
+      if (D == 3) { pa[c] = v2d{s0.x + s3.y, s0.y - s3.x}; pb[c] = v2d{s1.x + s2.y, s1.y - s2.x}; }  // s0-i s3, s1-i s2
+      if (D == 4) { pa[c] = s0 + s3; pb[c] = s1 - s2; }                                           // hopping.h:627,632
+      if (D == 5) { pa[c] = s0 - s3; pb[c] = s1 + s2; }                                           // hopping.h:639,644
+      if (D == 6) { pa[c] = v2d{s0.x - s2.y, s0.y + s2.x}; pb[c] = v2d{s1.x + s3.y, s1.y - s3.x}; }  // s0+i s2, s1-i s3
+      if (D == 7) { pa[c] = v2d{s0.x + s2.y, s0.y - s2.x}; pb[c] = v2d{s1.x - s3.y, s1.y + s3.x}; }  // s0-i s2, s1+i s3
+    }
+  }
+  const v2d *gd = g + (size_t)D * 9 * gs + i;
+  v2d u[9];
+#pragma unroll
+  for (int e = 0; e < 9; e++) u[e] = ldg<NT>(gd + (size_t)e * gs);
+  v2d ca[3], cb[3];
+  if ((D & 1) == 0) {  // chi = U psi           (su3.h:308-311)
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      ca[r] = cfma(u[3 * r + 2], pa[2], cfma(u[3 * r + 1], pa[1], cmul(u[3 * r], pa[0])));
+      cb[r] = cfma(u[3 * r + 2], pb[2], cfma(u[3 * r + 1], pb[1], cmul(u[3 * r], pb[0])));
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) { ca[r] = cmul(ka, ca[r]); cb[r] = cmul(ka, cb[r]); }
+  } else {  // chi = U^dagger psi     (su3.h:313-316)
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      ca[r] = cfmac(u[6 + r], pa[2], cfmac(u[3 + r], pa[1], cmulc(u[r], pa[0])));
+      cb[r] = cfmac(u[6 + r], pb[2], cfmac(u[3 + r], pb[1], cmulc(u[r], pb[0])));
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) { ca[r] = cmulc(ka, ca[r]); cb[r] = cmulc(ka, cb[r]); }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const v2d a = ca[c], b = cb[c];
+    acc[c] += a;      // s0 += a
+    acc[3 + c] += b;  // s1 += b
+    if (D == 0) { acc[6 + c] += a; acc[9 + c] += b; }
+    if (D == 1) { acc[6 + c] -= a; acc[9 + c] -= b; }
+    if (D == 2) { acc[9 + c] += v2d{a.y, -a.x}; acc[6 + c] += v2d{b.y, -b.x}; }   // s3 -= i a ; s2 -= i b
+    if (D == 3) { acc[9 + c] += v2d{-a.y, a.x}; acc[6 + c] += v2d{-b.y, b.x}; }   // s3 += i a ; s2 += i b
+    if (D == 4) { acc[9 + c] += a; acc[6 + c] -= b; }
+    if (D == 5) { acc[9 + c] -= a; acc[6 + c] += b; }
+    if (D == 6) { acc[6 + c] += v2d{a.y, -a.x}; acc[9 + c] += v2d{-b.y, b.x}; }   // s2 -= i a ; s3 += i b
+    if (D == 7) { acc[6 + c] += v2d{-a.y, a.x}; acc[9 + c] += v2d{b.y, -b.x}; }   // s2 += i a ; s3 -= i b
+  }
+}
+
+// TFACE: 0 = t-neighbours are local (interior, or unsplit lattice with periodic wrap)
+//        1 = sites of the t=0 slab:   -t half-spinors come from halo_dn
+//        2 = sites of the t=T-1 slab: +t half-spinors come from halo_up
+template <int EPI, int TFACE, bool NT, int BS>
+__global__ __launch_bounds__(BS) void hop_kernel(const HopArgs a) {
+  int bid = blockIdx.x;
+  if (a.nxcd_chunk > 0) {
+    // XCD-aware remap: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD a
+    // contiguous chunk of the lattice so neighbouring tiles hit the same L2.
+    const int xcd = bid & 7, q = bid >> 3;
+    bid = xcd * a.nxcd_chunk + q;
+  }
+  const int i = a.i_begin + bid * BS + threadIdx.x;
+  if (i >= a.i_end) return;
+
+  const int LZh = a.LZh;
+  const int k = i % LZh;
+  int r = i / LZh;
+  const int y = r % a.LY;
+  r /= a.LY;
+  const int x = r % a.LX;
+  const int t = r / a.LX;
+  const int o = (t + x + y + a.par_off) & 1;  // z = 2k + o  (geometry_eo.c:807-811)
+  const int XYZh = a.face, YZh = a.YZh;
+
+  const int jtp = (t + 1 < a.T) ? i + XYZh : i - (a.T - 1) * XYZh;
+  const int jtm = (t > 0) ? i - XYZh : i + (a.T - 1) * XYZh;
+  const int jxp = (x + 1 < a.LX) ? i + YZh : i - (a.LX - 1) * YZh;
+  const int jxm = (x > 0) ? i - YZh : i + (a.LX - 1) * YZh;
+  const int jyp = (y + 1 < a.LY) ? i + LZh : i - (a.LY - 1) * LZh;
+  const int jym = (y > 0) ? i - LZh : i + (a.LY - 1) * LZh;
+  const int jzp = o ? ((k + 1 < LZh) ? i + 1 : i - (LZh - 1)) : i;
+  const int jzm = o ? i : ((k > 0) ? i - 1 : i + (LZh - 1));
+  const int jf = i - t * XYZh;  // index inside a t-face
+
+  v2d acc[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) acc[c] = v2d{0.0, 0.0};
+
+  const v2d ka0 = v2d{a.ka[0][0], a.ka[0][1]}, ka1 = v2d{a.ka[1][0], a.ka[1][1]};
+  const v2d ka2 = v2d{a.ka[2][0], a.ka[2][1]}, ka3 = v2d{a.ka[3][0], a.ka[3][1]};
+  const v2d *__restrict__ in = a.in;
+  const v2d *__restrict__ g = a.gauge;
+
+  if (TFACE == 2) hop_dir<0, true, NT>(acc, in, a.ns, jf, a.halo_up, a.face, g, a.gs, i, ka0);
+  else            hop_dir<0, false, NT>(acc, in, a.ns, jtp, nullptr, 0, g, a.gs, i, ka0);
+  if (TFACE == 1) hop_dir<1, true, NT>(acc, in, a.ns, jf, a.halo_dn, a.face, g, a.gs, i, ka0);
+  else            hop_dir<1, false, NT>(acc, in, a.ns, jtm, nullptr, 0, g, a.gs, i, ka0);
+  hop_dir<2, false, NT>(acc, in, a.ns, jxp, nullptr, 0, g, a.gs, i, ka1);
+  hop_dir<3, false, NT>(acc, in, a.ns, jxm, nullptr, 0, g, a.gs, i, ka1);
+  hop_dir<4, false, NT>(acc, in, a.ns, jyp, nullptr, 0, g, a.gs, i, ka2);
+  hop_dir<5, false, NT>(acc, in, a.ns, jym, nullptr, 0, g, a.gs, i, ka2);
+  hop_dir<6, false, NT>(acc, in, a.ns, jzp, nullptr, 0, g, a.gs, i, ka3);
+  hop_dir<7, false, NT>(acc, in, a.ns, jzm, nullptr, 0, g, a.gs, i, ka3);
+
+  v2d *__restrict__ out = a.out;
+  const v2d cf = v2d{a.cre, a.cim};
+  if (EPI == EPI_STORE) {  // hopping.h:690-694
+#pragma unroll
+    for (int c = 0; c < 12; c++) out[(size_t)c * a.ns + i] = acc[c];
+  } else if (EPI == EPI_TM_TIMES) {  // hopping.h:674-678
+#pragma unroll
+    for (int c = 0; c < 6; c++) out[(size_t)c * a.ns + i] = cmul(cf, acc[c]);
+#pragma unroll
+    for (int c = 6; c < 12; c++) out[(size_t)c * a.ns + i] = cmulc(cf, acc[c]);
+  } else {
+    // EPI_TM_SUB_G5: hopping.h:680-688  l = g5[(cf,cf*) p - H k];  EPI_TM_SUB: same without g5
+    const v2d *__restrict__ p = a.p;
+#pragma unroll
+    for (int c = 0; c < 6; c++) out[(size_t)c * a.ns + i] = cmul(cf, p[(size_t)c * a.ns + i]) - acc[c];
+#pragma unroll
+    for (int c = 6; c < 12; c++) {
+      const v2d zp = cmulc(cf, p[(size_t)c * a.ns + i]);
+      out[(size_t)c * a.ns + i] = (EPI == EPI_TM_SUB_G5) ? acc[c] - zp : zp - acc[c];
+    }
+  }
+}
+
+// Project the two t-faces of the input field to half-spinors for the neighbours
+// (what xchange_halffield ships, xchange/xchange_halffield.c:199-255; projections of
+// operator/halfspinor_hopping.h:1279-1293):
+//   send_dn[j] = (s0+s2, s1+s3)(t=0)      -> down neighbour, consumed by its +t hop at t=T-1
+//   send_up[j] = (s0-s2, s1-s3)(t=T-1)    -> up neighbour,   consumed by its -t hop at t=0
+__global__ __launch_bounds__(256) void pack_faces_kernel(const v2d *__restrict__ in, int ns, int Vh, int face,
+                                                         v2d *__restrict__ send_dn, v2d *__restrict__ send_up) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= face) return;
+  const int which = blockIdx.y;  // 0: t=0 face -> send_dn, 1: t=T-1 face -> send_up
+  const int i = which ? Vh - face + j : j;
+  v2d *dst = which ? send_up : send_dn;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const v2d s0 = in[(size_t)(0 + c) * ns + i], s1 = in[(size_t)(3 + c) * ns + i];
+    const v2d s2 = in[(size_t)(6 + c) * ns + i], s3 = in[(size_t)(9 + c) * ns + i];
+    dst[(size_t)c * face + j] = which ? s0 - s2 : s0 + s2;
+    dst[(size_t)(3 + c) * face + j] = which ? s1 - s3 : s1 + s3;
+  }
+}
+
+template <int EPI, int TFACE, bool NT, int BS>
+static void launch_one(const HopArgs &a, hipStream_t st, bool xcd) {
+  const int n = a.i_end - a.i_begin;
+  if (n <= 0) return;
+  int nb = (n + BS - 1) / BS;
+  HopArgs b = a;
+  b.nxcd_chunk = 0;
+  if (xcd && nb >= 64) {
+    const int chunk = (nb + 7) / 8;
+    b.nxcd_chunk = chunk;
+    nb = chunk * 8;  // blocks past i_end exit immediately
+  }
+  hipLaunchKernelGGL((hop_kernel<EPI, TFACE, NT, BS>), dim3(nb), dim3(BS), 0, st, b);
+}
+
+template <int EPI, int TFACE>
+static void launch_variant(const HopArgs &a, hipStream_t st, int block, bool nt, bool xcd) {
+  if (nt) {
+    if (block == 64) launch_one<EPI, TFACE, true, 64>(a, st, xcd);
+    else if (block == 256) launch_one<EPI, TFACE, true, 256>(a, st, xcd);
+    else launch_one<EPI, TFACE, true, 128>(a, st, xcd);
+  } else {
+    if (block == 64) launch_one<EPI, TFACE, false, 64>(a, st, xcd);
+    else if (block == 256) launch_one<EPI, TFACE, false, 256>(a, st, xcd);
+    else launch_one<EPI, TFACE, false, 128>(a, st, xcd);
+  }
+}
+
+template <int TFACE>
+static void launch_epi(const HopArgs &a, int epi, hipStream_t st, int block, bool nt, bool xcd) {
+  switch (epi) {
+    case EPI_STORE: launch_variant<EPI_STORE, TFACE>(a, st, block, nt, xcd); break;
+    case EPI_TM_TIMES: launch_variant<EPI_TM_TIMES, TFACE>(a, st, block, nt, xcd); break;
+    case EPI_TM_SUB_G5: launch_variant<EPI_TM_SUB_G5, TFACE>(a, st, block, nt, xcd); break;
+    default: launch_variant<EPI_TM_SUB, TFACE>(a, st, block, nt, xcd); break;
+  }
+}
+
+int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
+                         double cre, double cim, bool comm) {
+  if (!ctx->gauge_set) TMHIP_FAIL("Hopping_Matrix called before tmhip_set_gauge");
+  if (out == in) TMHIP_FAIL("Hopping_Matrix: l and k must differ (operator/D_psi_body.c:267-272 convention)");
+  HopArgs a;
+  a.out = out; a.in = in; a.p = p;
+  a.gauge = ctx->gauge + (size_t)(ieo ? 1 : 0) * 72 * ctx->gs;
+  a.halo_up = ctx->recv_up; a.halo_dn = ctx->recv_dn;
+  a.ns = ctx->ns; a.gs = ctx->gs;
+  a.T = ctx->g.T; a.LX = ctx->g.LX; a.LY = ctx->g.LY; a.LZh = ctx->g.LZ / 2;
+  a.Vh = ctx->Vh; a.face = ctx->face; a.YZh = ctx->g.LY * ctx->g.LZ / 2;
+  a.par_off = (ctx->g.proc_t * ctx->g.T + ieo) & 1;
+  a.nxcd_chunk = 0;
+  for (int m = 0; m < 4; m++) { a.ka[m][0] = ctx->ka[m][0]; a.ka[m][1] = ctx->ka[m][1]; }
+  a.cre = cre; a.cim = cim;
+  const int block = ctx->opt_block;
+  const bool nt = ctx->opt_nt != 0, xcd = ctx->opt_xcd != 0;
+  const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
+  if (!split) {
+    a.i_begin = 0; a.i_end = ctx->Vh;
+    launch_epi<0>(a, epi, ctx->stream, block, nt, xcd);
+  } else {
+    if (comm) {
+      // split-phase: pack faces -> exchange on comm stream || interior kernel -> boundary kernels
+      hipLaunchKernelGGL(pack_faces_kernel, dim3((ctx->face + 255) / 256, 2), dim3(256), 0, ctx->stream,
+                         in, ctx->ns, ctx->Vh, ctx->face, ctx->send_dn, ctx->send_up);
+      TMHIP_CHECK(hipEventRecord(ctx->ev_pack, ctx->stream));
+      TMHIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_pack, 0));
+      if (tmhip_halo_exchange(ctx)) return 1;
+      TMHIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
+    }
+    a.i_begin = ctx->face; a.i_end = ctx->Vh - ctx->face;
+    launch_epi<0>(a, epi, ctx->stream, block, nt, xcd);
+    if (comm) TMHIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_comm, 0));
+    a.i_begin = 0; a.i_end = ctx->face;
+    launch_epi<1>(a, epi, ctx->stream, block, nt, false);
+    a.i_begin = ctx->Vh - ctx->face; a.i_end = ctx->Vh;
+    launch_epi<2>(a, epi, ctx->stream, block, nt, false);
+  }
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}

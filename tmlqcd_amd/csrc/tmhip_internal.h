@@ -1,0 +1,85 @@
+// Internal definitions shared by the HIP translation units of libtmlqcd_hip.so.
+// gfx950 only.  Device layouts:
+//   spinor, one parity : v2d d[12][ns]        comp c = 3*spin + colour, site = e/o sub-index
+//   gauge copy         : v2d g[2][8][9][gs]   [parity of the output site][dir +t,-t,+x,-x,+y,-y,+z,-z][row-major su3 element][site]
+//   half-spinor faces  : v2d h[6][face]       comp c = 3*half + colour
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include "../../include/tmlqcd_hip.h"
+
+typedef double v2d __attribute__((ext_vector_type(2)));  // one complex double: .x = re, .y = im
+
+#define TMHIP_CHECK(expr)                                                                           \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      fprintf(stderr, "[tmlqcd_hip] %s:%d: %s failed: %s\n", __FILE__, __LINE__, #expr,             \
+              hipGetErrorString(_e));                                                               \
+      return 1;                                                                                     \
+    }                                                                                               \
+  } while (0)
+
+#define TMHIP_NCCL_CHECK(expr)                                                                      \
+  do {                                                                                              \
+    ncclResult_t _r = (expr);                                                                       \
+    if (_r != ncclSuccess) {                                                                        \
+      fprintf(stderr, "[tmlqcd_hip] %s:%d: %s failed: %s\n", __FILE__, __LINE__, #expr,             \
+              ncclGetErrorString(_r));                                                              \
+      return 1;                                                                                     \
+    }                                                                                               \
+  } while (0)
+
+#define TMHIP_FAIL(...)                                                                             \
+  do {                                                                                              \
+    fprintf(stderr, "[tmlqcd_hip] " __VA_ARGS__);                                                   \
+    fprintf(stderr, "\n");                                                                          \
+    return 1;                                                                                       \
+  } while (0)
+
+struct tmhip_field {
+  int kind;            // TMHIP_FIELD_EO | TMHIP_FIELD_FULL
+  v2d *d;              // EO: [12][ns]; FULL: even half then odd half, each [12][ns]
+  int ns;              // site stride of one parity
+  bool view;           // true for the even/odd views of a FULL field
+  tmhip_field *half[2];  // FULL only: views
+};
+
+struct tmhip_ctx {
+  tmhip_geom g;
+  int device;
+  int V, Vh, face;     // VOLUME, VOLUME/2, LX*LY*LZ/2
+  int ns;              // padded spinor stride: Vh (+ 2*face reserved) rounded up to 64
+  int gs;              // padded gauge stride
+  int VPR;             // host VOLUMEPLUSRAND
+  double kappa, mu, theta[4];
+  double ka[4][2];     // ka0..ka3 (re, im)
+  hipStream_t stream, comm_stream;
+  hipEvent_t ev_pack, ev_comm, ev_slots[16];
+  v2d *gauge;          // [2][8][9][gs]
+  bool gauge_set;
+  // staging for host<->device layout conversion
+  void *stage; size_t stage_bytes;
+  // reductions
+  double *partials; int max_partials; double *result_dev; double *result_host;
+  // private scratch = DUM_MATRIX..DUM_MATRIX+2 of tm_operators.c:173-176
+  tmhip_field *scratch[3];
+  // solver work fields
+  tmhip_field *sf[3];
+  // halo exchange
+  ncclComm_t comm; bool comm_ready; bool loopback;
+  v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
+  // options
+  int opt_block; int opt_xcd; int opt_nt; int opt_variant;
+};
+
+// ---- launch helpers implemented across the .hip files ----
+enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3 };
+int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
+                         double cre, double cim, bool comm);
+int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out);
+int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes);
+int tmhip_halo_exchange(tmhip_ctx *ctx);

@@ -1,0 +1,325 @@
+"""ctypes mirror of include/tmlqcd_hip.h (host-side plumbing only; no numerics here).
+
+Function names follow the reference (operator/tm_operators.h, linalg/*.h, solver/cg_her.h);
+host arrays are numpy float64 in the reference's AoS layouts:
+  spinor field [nsites][4][3][2]  (su3.h:60-63),  gauge field [VPR][4][3][3][2]  (su3.h:40-43).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+EO, OE = 0, 1
+FIELD_EO, FIELD_FULL = 0, 1
+OPS = {"Qtm_pm_psi": 0, "Qtm_plus_psi": 1, "Qtm_minus_psi": 2, "Mtm_plus_psi": 3, "Mtm_minus_psi": 4}
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class TmHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libtmlqcd_hip.so")
+
+
+class _Geom(C.Structure):
+    _fields_ = [("T", C.c_int), ("LX", C.c_int), ("LY", C.c_int), ("LZ", C.c_int),
+                ("nproc_t", C.c_int), ("proc_t", C.c_int)]
+
+
+def load_library():
+    """Load libtmlqcd_hip.so.  Fails loudly: there is no fallback path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise TmHipError("%s not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(or make -C tmlqcd_amd/csrc); there is no CPU fallback" % path)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, i, d = C.c_void_p, C.c_int, C.c_double
+    pd = C.POINTER(C.c_double)
+    sig = {
+        "tmhip_create": [C.POINTER(_Geom), i, C.POINTER(vp)],
+        "tmhip_sync": [vp],
+        "tmhip_set_boundary": [vp, d, pd],
+        "tmhip_set_mu": [vp, d],
+        "tmhip_set_gauge": [vp, vp],
+        "tmhip_field_alloc": [vp, i, C.POINTER(vp)],
+        "tmhip_field_upload": [vp, vp, vp, i],
+        "tmhip_field_download": [vp, vp, vp, i],
+        "tmhip_field_zero": [vp, vp],
+        "tmhip_hopping_matrix": [vp, i, vp, vp],
+        "tmhip_hopping_matrix_nocom": [vp, i, vp, vp],
+        "tmhip_tm_times_hopping_matrix": [vp, i, vp, vp, d, d],
+        "tmhip_tm_sub_hopping_matrix": [vp, i, vp, vp, vp, d, d],
+        "tmhip_D_psi": [vp, vp, vp],
+        "tmhip_mul_one_pm_imu_inv": [vp, vp, d, i],
+        "tmhip_assign_mul_one_pm_imu_inv": [vp, vp, vp, d, i],
+        "tmhip_assign_mul_one_pm_imu": [vp, vp, vp, d, i],
+        "tmhip_mul_one_pm_imu": [vp, vp, d],
+        "tmhip_mul_one_pm_imu_sub_mul": [vp, vp, vp, vp, d, i],
+        "tmhip_mul_one_pm_imu_sub_mul_gamma5": [vp, vp, vp, vp, d],
+        "tmhip_gamma5": [vp, vp, vp, i],
+        "tmhip_H_eo_tm_inv_psi": [vp, vp, vp, i, d],
+        "tmhip_Qtm_plus_psi": [vp, vp, vp], "tmhip_Qtm_minus_psi": [vp, vp, vp],
+        "tmhip_Mtm_plus_psi": [vp, vp, vp], "tmhip_Mtm_minus_psi": [vp, vp, vp],
+        "tmhip_Qtm_pm_psi": [vp, vp, vp],
+        "tmhip_M_full": [vp, vp, vp, vp, vp],
+        "tmhip_square_norm": [vp, vp, i, i, pd],
+        "tmhip_scalar_prod_r": [vp, vp, vp, i, i, pd],
+        "tmhip_assign_add_mul_r": [vp, vp, vp, d, i],
+        "tmhip_assign_mul_add_r": [vp, vp, d, vp, i],
+        "tmhip_assign_mul_add_r_and_square": [vp, vp, d, vp, i, i, pd],
+        "tmhip_diff": [vp, vp, vp, vp, i],
+        "tmhip_assign": [vp, vp, vp, i],
+        "tmhip_cg_her": [vp, vp, vp, i, d, i, i, i, C.POINTER(i), pd, i],
+        "tmhip_comm_get_unique_id": [C.c_char_p],
+        "tmhip_comm_init": [vp, C.c_char_p],
+        "tmhip_comm_set_loopback": [vp, i],
+        "tmhip_bench_hopping": [vp, vp, vp, vp, i, pd],
+        "tmhip_event_record": [vp, i],
+        "tmhip_event_elapsed_ms": [vp, i, i, pd],
+        "tmhip_set_option": [vp, C.c_char_p, i],
+    }
+    for name, args in sig.items():
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = i
+    lib.tmhip_destroy.argtypes = [vp]
+    lib.tmhip_destroy.restype = None
+    lib.tmhip_field_free.argtypes = [vp, vp]
+    lib.tmhip_field_free.restype = None
+    lib.tmhip_field_even.argtypes = [vp]
+    lib.tmhip_field_even.restype = vp
+    lib.tmhip_field_odd.argtypes = [vp]
+    lib.tmhip_field_odd.restype = vp
+    lib.tmhip_version.restype = C.c_char_p
+    lib.tmhip_device_count.restype = i
+    _LIB = lib
+    return lib
+
+
+def _ck(rc, what):
+    if rc != 0:
+        raise TmHipError("%s failed (rc=%d); see stderr" % (what, rc))
+
+
+def _hp(a):
+    if a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"]:
+        raise TmHipError("host arrays must be C-contiguous float64")
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Field:
+    """A device-resident spinor field (opaque handle)."""
+
+    def __init__(self, lat, kind=FIELD_EO, handle=None, owner=True):
+        self.lat, self.kind, self.owner = lat, kind, owner
+        if handle is None:
+            h = C.c_void_p()
+            _ck(lat.lib.tmhip_field_alloc(lat.h, kind, C.byref(h)), "tmhip_field_alloc")
+            handle = h
+        self.h = handle
+
+    def upload(self, host, nsites=None):
+        nsites = nsites if nsites is not None else (self.lat.V if self.kind == FIELD_FULL else self.lat.Vh)
+        _ck(self.lat.lib.tmhip_field_upload(self.lat.h, self.h, _hp(host), nsites), "tmhip_field_upload")
+        return self
+
+    def download(self, nsites=None):
+        nsites = nsites if nsites is not None else (self.lat.V if self.kind == FIELD_FULL else self.lat.Vh)
+        out = np.empty((nsites, 4, 3, 2), dtype=np.float64)
+        _ck(self.lat.lib.tmhip_field_download(self.lat.h, self.h, _hp(out), nsites), "tmhip_field_download")
+        return out
+
+    def zero(self):
+        _ck(self.lat.lib.tmhip_field_zero(self.lat.h, self.h), "tmhip_field_zero")
+        return self
+
+    def even(self):
+        return Field(self.lat, FIELD_EO, C.c_void_p(self.lat.lib.tmhip_field_even(self.h)), owner=False)
+
+    def odd(self):
+        return Field(self.lat, FIELD_EO, C.c_void_p(self.lat.lib.tmhip_field_odd(self.h)), owner=False)
+
+    def free(self):
+        if self.owner and self.h is not None and self.lat.h is not None:
+            self.lat.lib.tmhip_field_free(self.lat.h, self.h)
+        self.h = None
+
+
+class Lattice:
+    """One rank's lattice on one MI355X: context + operators, mirroring the reference's names."""
+
+    def __init__(self, T, LX, LY, LZ, kappa=0.125, mu=0.0, theta=(0, 0, 0, 0), nproc_t=1, proc_t=0, device=0):
+        self.lib = load_library()
+        self.T, self.LX, self.LY, self.LZ = T, LX, LY, LZ
+        self.nproc_t, self.proc_t = nproc_t, proc_t
+        self.V = T * LX * LY * LZ
+        self.Vh = self.V // 2
+        self.VPR = self.V + (2 * LX * LY * LZ if nproc_t > 1 else 0)
+        g = _Geom(T, LX, LY, LZ, nproc_t, proc_t)
+        h = C.c_void_p()
+        self.h = None
+        _ck(self.lib.tmhip_create(C.byref(g), device, C.byref(h)), "tmhip_create")
+        self.h = h
+        self.set_boundary(kappa, theta)
+        self.set_mu(mu)
+
+    def close(self):
+        if self.h is not None:
+            self.lib.tmhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- parameters -------------------------------------------------------
+    def set_boundary(self, kappa, theta=(0, 0, 0, 0)):
+        th = (C.c_double * 4)(*theta)
+        _ck(self.lib.tmhip_set_boundary(self.h, kappa, th), "tmhip_set_boundary")
+
+    def set_mu(self, mu):
+        self.mu = mu
+        _ck(self.lib.tmhip_set_mu(self.h, mu), "tmhip_set_mu")
+
+    def set_gauge(self, g):
+        if g.shape != (self.VPR, 4, 3, 3, 2):
+            raise TmHipError("gauge field must be [VPR=%d][4][3][3][2], got %s" % (self.VPR, g.shape))
+        _ck(self.lib.tmhip_set_gauge(self.h, _hp(g)), "tmhip_set_gauge")
+
+    def set_option(self, name, value):
+        _ck(self.lib.tmhip_set_option(self.h, name.encode(), int(value)), "tmhip_set_option")
+
+    def sync(self):
+        _ck(self.lib.tmhip_sync(self.h), "tmhip_sync")
+
+    # --- fields -----------------------------------------------------------
+    def field(self, host=None, kind=FIELD_EO):
+        f = Field(self, kind)
+        if host is not None:
+            f.upload(host, host.shape[0])
+        return f
+
+    def full_field(self, host=None):
+        return self.field(host, FIELD_FULL)
+
+    # --- stencil ----------------------------------------------------------
+    def Hopping_Matrix(self, ieo, l, k):
+        _ck(self.lib.tmhip_hopping_matrix(self.h, ieo, l.h, k.h), "Hopping_Matrix")
+
+    def Hopping_Matrix_nocom(self, ieo, l, k):
+        _ck(self.lib.tmhip_hopping_matrix_nocom(self.h, ieo, l.h, k.h), "Hopping_Matrix_nocom")
+
+    def tm_times_Hopping_Matrix(self, ieo, l, k, c):
+        _ck(self.lib.tmhip_tm_times_hopping_matrix(self.h, ieo, l.h, k.h, c.real, c.imag), "tm_times_Hopping_Matrix")
+
+    def tm_sub_Hopping_Matrix(self, ieo, l, p, k, c):
+        _ck(self.lib.tmhip_tm_sub_hopping_matrix(self.h, ieo, l.h, p.h, k.h, c.real, c.imag), "tm_sub_Hopping_Matrix")
+
+    def D_psi(self, P, Q):
+        _ck(self.lib.tmhip_D_psi(self.h, P.h, Q.h), "D_psi")
+
+    # --- site-diagonal ----------------------------------------------------
+    def mul_one_pm_imu_inv(self, l, sign, N):
+        _ck(self.lib.tmhip_mul_one_pm_imu_inv(self.h, l.h, sign, N), "mul_one_pm_imu_inv")
+
+    def assign_mul_one_pm_imu_inv(self, l, k, sign, N):
+        _ck(self.lib.tmhip_assign_mul_one_pm_imu_inv(self.h, l.h, k.h, sign, N), "assign_mul_one_pm_imu_inv")
+
+    def assign_mul_one_pm_imu(self, l, k, sign, N):
+        _ck(self.lib.tmhip_assign_mul_one_pm_imu(self.h, l.h, k.h, sign, N), "assign_mul_one_pm_imu")
+
+    def mul_one_pm_imu(self, l, sign):
+        _ck(self.lib.tmhip_mul_one_pm_imu(self.h, l.h, sign), "mul_one_pm_imu")
+
+    def mul_one_pm_imu_sub_mul(self, l, k, j, sign, N):
+        _ck(self.lib.tmhip_mul_one_pm_imu_sub_mul(self.h, l.h, k.h, j.h, sign, N), "mul_one_pm_imu_sub_mul")
+
+    def mul_one_pm_imu_sub_mul_gamma5(self, l, k, j, sign):
+        _ck(self.lib.tmhip_mul_one_pm_imu_sub_mul_gamma5(self.h, l.h, k.h, j.h, sign), "mul_one_pm_imu_sub_mul_gamma5")
+
+    def gamma5(self, l, k, N):
+        _ck(self.lib.tmhip_gamma5(self.h, l.h, k.h, N), "gamma5")
+
+    # --- compositions -----------------------------------------------------
+    def H_eo_tm_inv_psi(self, l, k, ieo, sign):
+        _ck(self.lib.tmhip_H_eo_tm_inv_psi(self.h, l.h, k.h, ieo, sign), "H_eo_tm_inv_psi")
+
+    def op(self, name, l, k):
+        _ck(getattr(self.lib, "tmhip_" + name)(self.h, l.h, k.h), name)
+
+    def Qtm_pm_psi(self, l, k):
+        self.op("Qtm_pm_psi", l, k)
+
+    def M_full(self, en, on, e, o):
+        _ck(self.lib.tmhip_M_full(self.h, en.h, on.h, e.h, o.h), "M_full")
+
+    # --- linalg -----------------------------------------------------------
+    def square_norm(self, P, N, parallel=0):
+        out = C.c_double()
+        _ck(self.lib.tmhip_square_norm(self.h, P.h, N, parallel, C.byref(out)), "square_norm")
+        return out.value
+
+    def scalar_prod_r(self, S, R, N, parallel=0):
+        out = C.c_double()
+        _ck(self.lib.tmhip_scalar_prod_r(self.h, S.h, R.h, N, parallel, C.byref(out)), "scalar_prod_r")
+        return out.value
+
+    def assign_add_mul_r(self, P, Q, c, N):
+        _ck(self.lib.tmhip_assign_add_mul_r(self.h, P.h, Q.h, c, N), "assign_add_mul_r")
+
+    def assign_mul_add_r(self, R, c, S, N):
+        _ck(self.lib.tmhip_assign_mul_add_r(self.h, R.h, c, S.h, N), "assign_mul_add_r")
+
+    def assign_mul_add_r_and_square(self, R, c, S, N, parallel=0):
+        out = C.c_double()
+        _ck(self.lib.tmhip_assign_mul_add_r_and_square(self.h, R.h, c, S.h, N, parallel, C.byref(out)),
+            "assign_mul_add_r_and_square")
+        return out.value
+
+    def diff(self, Q, R, S, N):
+        _ck(self.lib.tmhip_diff(self.h, Q.h, R.h, S.h, N), "diff")
+
+    def assign(self, R, S, N):
+        _ck(self.lib.tmhip_assign(self.h, R.h, S.h, N), "assign")
+
+    # --- solver -----------------------------------------------------------
+    def cg_her(self, P, Q, max_iter, eps_sq, rel_prec, N, op="Qtm_pm_psi"):
+        it = C.c_int()
+        hist = np.zeros(max(max_iter, 1), dtype=np.float64)
+        _ck(self.lib.tmhip_cg_her(self.h, P.h, Q.h, max_iter, eps_sq, rel_prec, N, OPS[op], C.byref(it),
+                                  hist.ctypes.data_as(C.POINTER(C.c_double)), hist.size), "cg_her")
+        n = it.value if it.value > 0 else max_iter
+        return it.value, hist[:n]
+
+    # --- multi-GPU --------------------------------------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        _ck(self.lib.tmhip_comm_get_unique_id(buf), "tmhip_comm_get_unique_id")
+        return buf.raw
+
+    def comm_init(self, uid):
+        _ck(self.lib.tmhip_comm_init(self.h, uid), "tmhip_comm_init")
+
+    def set_loopback(self, on):
+        _ck(self.lib.tmhip_comm_set_loopback(self.h, int(on)), "tmhip_comm_set_loopback")
+
+    # --- measurement ------------------------------------------------------
+    def bench_hopping(self, f0, f1, f2, iters):
+        ms = C.c_double()
+        _ck(self.lib.tmhip_bench_hopping(self.h, f0.h, f1.h, f2.h, iters, C.byref(ms)), "tmhip_bench_hopping")
+        return ms.value
+
+    def event_record(self, slot):
+        _ck(self.lib.tmhip_event_record(self.h, slot), "tmhip_event_record")
+
+    def event_elapsed_ms(self, a, b):
+        ms = C.c_double()
+        _ck(self.lib.tmhip_event_elapsed_ms(self.h, a, b, C.byref(ms)), "tmhip_event_elapsed_ms")
+        return ms.value
