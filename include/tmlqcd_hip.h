@@ -130,7 +130,8 @@ int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, d
 int tmhip_comm_get_unique_id(char id[TMHIP_UNIQUE_ID_BYTES]);             /* rank 0, then broadcast by the host program */
 int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]); /* ring of nproc_t ranks along T over RCCL */
 /* Single-GPU self-test of the split-phase path: faces are packed, "exchanged"
- * with this rank itself and consumed by the boundary kernel. */
+ * with this rank itself and consumed by the boundary kernel.  on = 1: device-to-device
+ * copies; on = 2: through a one-rank RCCL communicator (ncclSend/ncclRecv to self). */
 int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on);
 
 /* ---- measurement ---------------------------------------------------------- */

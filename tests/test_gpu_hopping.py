@@ -36,18 +36,21 @@ def test_hopping_matrix_16(setup16, ieo):
     dk.free(); dl.free()
 
 
-@pytest.mark.parametrize("block,nt,xcd", [(64, 0, 0), (128, 1, 0), (256, 1, 1), (128, 0, 1)])
-def test_kernel_variants_agree(setup16, block, nt, xcd):
+@pytest.mark.parametrize("block,nt,xcd,minw,occ", [(64, 0, 0, 0, 0), (64, 1, 2, 4, 2), (256, 1, 1, 0, 3), (256, 0, 2, 4, 0)])
+def test_kernel_variants_agree(setup16, block, nt, xcd, minw, occ):
     orc, lat = setup16
     N = orc.Vh
     k = random_spinor(9, N)
     ref = orc.new_field()
     orc.Hopping_Matrix(1, ref, k)
-    lat.set_option("block", block); lat.set_option("nt", nt); lat.set_option("xcd", xcd)
+    defaults = dict(block=256, nt=1, xcd=2, minw=0, occ=3)
+    for name, val in dict(block=block, nt=nt, xcd=xcd, minw=minw, occ=occ).items():
+        lat.set_option(name, val)
     dk, dl = lat.field(k), lat.field()
     lat.Hopping_Matrix(1, dl, dk)
     assert rel_err(dl.download(), ref[:N]) < TOL
-    lat.set_option("block", 128); lat.set_option("nt", 1); lat.set_option("xcd", 0)
+    for name, val in defaults.items():
+        lat.set_option(name, val)
     dk.free(); dl.free()
 
 
@@ -69,7 +72,8 @@ def test_fused_epilogues(setup16, ieo):
         f.free()
 
 
-def test_loopback_split_path_matches(setup16):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_loopback_split_path_matches(setup16, mode):
     """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self,
     consumed by the boundary kernels -- must equal the plain periodic stencil."""
     orc, lat = setup16
@@ -77,7 +81,7 @@ def test_loopback_split_path_matches(setup16):
     k = random_spinor(31, N)
     ref = orc.new_field()
     dk, dl = lat.field(k), lat.field()
-    lat.set_loopback(1)
+    lat.set_loopback(mode)  # 1: D2D copies, 2: one-rank RCCL communicator (ncclSend/Recv to self)
     try:
         for ieo in (0, 1):
             orc.Hopping_Matrix(ieo, ref, k)

@@ -128,7 +128,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->V = g.T * g.LX * g.LY * g.LZ; ctx->Vh = ctx->V / 2; ctx->face = g.LX * g.LY * g.LZ / 2;
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
-  ctx->opt_block = 128; ctx->opt_xcd = 0; ctx->opt_nt = 1; ctx->opt_variant = 0;
+  ctx->opt_block = 256; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_variant = 0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
   TMHIP_CHECK(hipEventCreateWithFlags(&ctx->ev_pack, hipEventDisableTiming));
@@ -202,7 +202,9 @@ int tmhip_set_ka(tmhip_ctx *ctx, const double ka[8]) {
 int tmhip_set_mu(tmhip_ctx *ctx, double mu) { ctx->mu = mu; return 0; }
 
 int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
-  if (!strcmp(name, "block")) { if (value != 64 && value != 128 && value != 256) TMHIP_FAIL("block must be 64/128/256"); ctx->opt_block = value; }
+  if (!strcmp(name, "block")) { if (value != 64 && value != 256) TMHIP_FAIL("block must be 64 or 256"); ctx->opt_block = value; }
+  else if (!strcmp(name, "minw")) ctx->opt_minw = value;
+  else if (!strcmp(name, "occ")) ctx->opt_occ = value;
   else if (!strcmp(name, "xcd")) ctx->opt_xcd = value;
   else if (!strcmp(name, "nt")) ctx->opt_nt = value;
   else if (!strcmp(name, "variant")) ctx->opt_variant = value;
@@ -440,6 +442,14 @@ int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]) {
 int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
   if (ctx->g.nproc_t > 1) TMHIP_FAIL("loopback is a single-rank self-test");
   ctx->loopback = on != 0;
+  ctx->loopback_rccl = on == 2;
+  if (on == 2 && !ctx->comm_ready) {  // one-rank RCCL communicator: faces travel through ncclSend/ncclRecv to self
+    TMHIP_CHECK(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    TMHIP_NCCL_CHECK(ncclGetUniqueId(&u));
+    TMHIP_NCCL_CHECK(ncclCommInitRank(&ctx->comm, 1, u, 0));
+    ctx->comm_ready = true;
+  }
   return 0;
 }
 
@@ -449,7 +459,7 @@ int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
 //   send_dn -> rank-1 (lands in its recv_up),  send_up -> rank+1 (lands in its recv_dn).
 int tmhip_halo_exchange(tmhip_ctx *ctx) {
   const size_t n = (size_t)6 * ctx->face * 2;  // doubles per face
-  if (ctx->g.nproc_t == 1) {  // periodic wrap onto ourselves (loopback self-test)
+  if (ctx->g.nproc_t == 1 && !ctx->loopback_rccl) {  // periodic wrap onto ourselves (loopback self-test)
     TMHIP_CHECK(hipMemcpyAsync(ctx->recv_up, ctx->send_dn, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm_stream));
     TMHIP_CHECK(hipMemcpyAsync(ctx->recv_dn, ctx->send_up, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm_stream));
     return 0;

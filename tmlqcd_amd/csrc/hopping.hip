@@ -31,6 +31,8 @@ struct HopArgs {
   int i_begin, i_end;
   int par_off;  // (proc_t*T + ieo) & 1
   int nxcd_chunk;  // >0: XCD-aware block remap, blocks per XCD chunk
+  int map_tc;      // >0: within an XCD chunk walk t fastest over map_tc time-slices (tile order)
+  int map_bpt;     // blocks per time-slice (face / BS) for the tile order
   double ka[4][2];
   double cre, cim;
 };
@@ -50,6 +52,12 @@ template <bool NT>
 __device__ __forceinline__ v2d ldg(const v2d *p) {
   if (NT) return __builtin_nontemporal_load(p);
   return *p;
+}
+
+template <bool NT>
+__device__ __forceinline__ void stg(v2d *p, v2d v) {
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
 }
 
 // One of the 8 hops.  D = 2*mu + (0: +mu, 1: -mu), mu = t,x,y,z.
@@ -121,13 +129,21 @@ __device__ __forceinline__ void hop_dir(v2d (&acc)[12], const v2d *__restrict__ 
 // TFACE: 0 = t-neighbours are local (interior, or unsplit lattice with periodic wrap)
 //        1 = sites of the t=0 slab:   -t half-spinors come from halo_dn
 //        2 = sites of the t=T-1 slab: +t half-spinors come from halo_up
-template <int EPI, int TFACE, bool NT, int BS>
-__global__ __launch_bounds__(BS) void hop_kernel(const HopArgs a) {
+template <int EPI, int TFACE, bool NTIO, int BS, int MINW>
+__global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
+  constexpr bool NT = true;  // gauge links: used once per call -> non-temporal (measured 0.19 -> 0.16 ms at 32^4)
   int bid = blockIdx.x;
   if (a.nxcd_chunk > 0) {
     // XCD-aware remap: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD a
     // contiguous chunk of the lattice so neighbouring tiles hit the same L2.
-    const int xcd = bid & 7, q = bid >> 3;
+    const int xcd = bid & 7;
+    int q = bid >> 3;
+    if (a.map_tc > 0) {
+      // tile order inside the chunk: the same spatial tile at t, t+1, .. is dispatched
+      // back to back, so the +-t (and +-x) users of an input line run close in time.
+      const int tl = q % a.map_tc, sp = q / a.map_tc;
+      q = tl * a.map_bpt + sp;
+    }
     bid = xcd * a.nxcd_chunk + q;
   }
   const int i = a.i_begin + bid * BS + threadIdx.x;
@@ -177,21 +193,21 @@ __global__ __launch_bounds__(BS) void hop_kernel(const HopArgs a) {
   const v2d cf = v2d{a.cre, a.cim};
   if (EPI == EPI_STORE) {  // hopping.h:690-694
 #pragma unroll
-    for (int c = 0; c < 12; c++) out[(size_t)c * a.ns + i] = acc[c];
+    for (int c = 0; c < 12; c++) stg<NTIO>(out + (size_t)c * a.ns + i, acc[c]);
   } else if (EPI == EPI_TM_TIMES) {  // hopping.h:674-678
 #pragma unroll
-    for (int c = 0; c < 6; c++) out[(size_t)c * a.ns + i] = cmul(cf, acc[c]);
+    for (int c = 0; c < 6; c++) stg<NTIO>(out + (size_t)c * a.ns + i, cmul(cf, acc[c]));
 #pragma unroll
-    for (int c = 6; c < 12; c++) out[(size_t)c * a.ns + i] = cmulc(cf, acc[c]);
+    for (int c = 6; c < 12; c++) stg<NTIO>(out + (size_t)c * a.ns + i, cmulc(cf, acc[c]));
   } else {
     // EPI_TM_SUB_G5: hopping.h:680-688  l = g5[(cf,cf*) p - H k];  EPI_TM_SUB: same without g5
     const v2d *__restrict__ p = a.p;
 #pragma unroll
-    for (int c = 0; c < 6; c++) out[(size_t)c * a.ns + i] = cmul(cf, p[(size_t)c * a.ns + i]) - acc[c];
+    for (int c = 0; c < 6; c++) stg<NTIO>(out + (size_t)c * a.ns + i, cmul(cf, ldg<NTIO>(p + (size_t)c * a.ns + i)) - acc[c]);
 #pragma unroll
     for (int c = 6; c < 12; c++) {
-      const v2d zp = cmulc(cf, p[(size_t)c * a.ns + i]);
-      out[(size_t)c * a.ns + i] = (EPI == EPI_TM_SUB_G5) ? acc[c] - zp : zp - acc[c];
+      const v2d zp = cmulc(cf, ldg<NTIO>(p + (size_t)c * a.ns + i));
+      stg<NTIO>(out + (size_t)c * a.ns + i, (EPI == EPI_TM_SUB_G5) ? acc[c] - zp : zp - acc[c]);
     }
   }
 }
@@ -217,41 +233,55 @@ __global__ __launch_bounds__(256) void pack_faces_kernel(const v2d *__restrict__
   }
 }
 
-template <int EPI, int TFACE, bool NT, int BS>
-static void launch_one(const HopArgs &a, hipStream_t st, bool xcd) {
+struct HopLaunch { int block; bool ntio; int minw; int xcd; int occ; };
+
+template <int EPI, int TFACE, bool NTIO, int BS, int MINW>
+static void launch_one(const HopArgs &a, hipStream_t st, const HopLaunch &o, bool allow_map) {
   const int n = a.i_end - a.i_begin;
   if (n <= 0) return;
   int nb = (n + BS - 1) / BS;
   HopArgs b = a;
-  b.nxcd_chunk = 0;
-  if (xcd && nb >= 64) {
+  b.nxcd_chunk = 0; b.map_tc = 0; b.map_bpt = 0;
+  if (allow_map && o.xcd && nb >= 64) {
     const int chunk = (nb + 7) / 8;
     b.nxcd_chunk = chunk;
+    // tile order needs whole time-slices per block row: T % 8 == 0 and face % BS == 0
+    if (o.xcd >= 2 && a.i_begin == 0 && n == a.Vh && a.T % 8 == 0 && a.face % BS == 0) {
+      b.map_tc = a.T / 8;
+      b.map_bpt = a.face / BS;
+    }
     nb = chunk * 8;  // blocks past i_end exit immediately
   }
-  hipLaunchKernelGGL((hop_kernel<EPI, TFACE, NT, BS>), dim3(nb), dim3(BS), 0, st, b);
+  // occupancy cap for A/B runs: dynamic LDS sized so that only `occ` waves per SIMD fit on a CU
+  size_t lds = 0;
+  if (o.occ > 0) {
+    const int blocks_per_cu = o.occ * 4 * 64 / BS;
+    lds = (size_t)(163840 / (blocks_per_cu > 0 ? blocks_per_cu : 1)) / 256 * 256;
+    if (lds > 65536) lds = 65536;  // default dynamic-LDS limit without an attribute opt-in
+  }
+  hipLaunchKernelGGL((hop_kernel<EPI, TFACE, NTIO, BS, MINW>), dim3(nb), dim3(BS), lds, st, b);
 }
 
 template <int EPI, int TFACE>
-static void launch_variant(const HopArgs &a, hipStream_t st, int block, bool nt, bool xcd) {
-  if (nt) {
-    if (block == 64) launch_one<EPI, TFACE, true, 64>(a, st, xcd);
-    else if (block == 256) launch_one<EPI, TFACE, true, 256>(a, st, xcd);
-    else launch_one<EPI, TFACE, true, 128>(a, st, xcd);
+static void launch_variant(const HopArgs &a, hipStream_t st, const HopLaunch &o, bool allow_map) {
+#define TMHIP_L(NTIO, BS, MINW) launch_one<EPI, TFACE, NTIO, BS, MINW>(a, st, o, allow_map)
+  if (o.block == 64) {
+    if (o.ntio) { if (o.minw >= 4) TMHIP_L(true, 64, 4); else TMHIP_L(true, 64, 1); }
+    else        { if (o.minw >= 4) TMHIP_L(false, 64, 4); else TMHIP_L(false, 64, 1); }
   } else {
-    if (block == 64) launch_one<EPI, TFACE, false, 64>(a, st, xcd);
-    else if (block == 256) launch_one<EPI, TFACE, false, 256>(a, st, xcd);
-    else launch_one<EPI, TFACE, false, 128>(a, st, xcd);
+    if (o.ntio) { if (o.minw >= 4) TMHIP_L(true, 256, 4); else TMHIP_L(true, 256, 1); }
+    else        { if (o.minw >= 4) TMHIP_L(false, 256, 4); else TMHIP_L(false, 256, 1); }
   }
+#undef TMHIP_L
 }
 
 template <int TFACE>
-static void launch_epi(const HopArgs &a, int epi, hipStream_t st, int block, bool nt, bool xcd) {
+static void launch_epi(const HopArgs &a, int epi, hipStream_t st, const HopLaunch &o, bool allow_map) {
   switch (epi) {
-    case EPI_STORE: launch_variant<EPI_STORE, TFACE>(a, st, block, nt, xcd); break;
-    case EPI_TM_TIMES: launch_variant<EPI_TM_TIMES, TFACE>(a, st, block, nt, xcd); break;
-    case EPI_TM_SUB_G5: launch_variant<EPI_TM_SUB_G5, TFACE>(a, st, block, nt, xcd); break;
-    default: launch_variant<EPI_TM_SUB, TFACE>(a, st, block, nt, xcd); break;
+    case EPI_STORE: launch_variant<EPI_STORE, TFACE>(a, st, o, allow_map); break;
+    case EPI_TM_TIMES: launch_variant<EPI_TM_TIMES, TFACE>(a, st, o, allow_map); break;
+    case EPI_TM_SUB_G5: launch_variant<EPI_TM_SUB_G5, TFACE>(a, st, o, allow_map); break;
+    default: launch_variant<EPI_TM_SUB, TFACE>(a, st, o, allow_map); break;
   }
 }
 
@@ -267,15 +297,14 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
   a.T = ctx->g.T; a.LX = ctx->g.LX; a.LY = ctx->g.LY; a.LZh = ctx->g.LZ / 2;
   a.Vh = ctx->Vh; a.face = ctx->face; a.YZh = ctx->g.LY * ctx->g.LZ / 2;
   a.par_off = (ctx->g.proc_t * ctx->g.T + ieo) & 1;
-  a.nxcd_chunk = 0;
+  a.nxcd_chunk = 0; a.map_tc = 0; a.map_bpt = 0;
   for (int m = 0; m < 4; m++) { a.ka[m][0] = ctx->ka[m][0]; a.ka[m][1] = ctx->ka[m][1]; }
   a.cre = cre; a.cim = cim;
-  const int block = ctx->opt_block;
-  const bool nt = ctx->opt_nt != 0, xcd = ctx->opt_xcd != 0;
+  const HopLaunch o = {ctx->opt_block, ctx->opt_nt != 0, ctx->opt_minw, ctx->opt_xcd, ctx->opt_occ};
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
   if (!split) {
     a.i_begin = 0; a.i_end = ctx->Vh;
-    launch_epi<0>(a, epi, ctx->stream, block, nt, xcd);
+    launch_epi<0>(a, epi, ctx->stream, o, true);
   } else {
     if (comm) {
       // split-phase: pack faces -> exchange on comm stream || interior kernel -> boundary kernels
@@ -287,12 +316,12 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
       TMHIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
     }
     a.i_begin = ctx->face; a.i_end = ctx->Vh - ctx->face;
-    launch_epi<0>(a, epi, ctx->stream, block, nt, xcd);
+    launch_epi<0>(a, epi, ctx->stream, o, true);
     if (comm) TMHIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_comm, 0));
     a.i_begin = 0; a.i_end = ctx->face;
-    launch_epi<1>(a, epi, ctx->stream, block, nt, false);
+    launch_epi<1>(a, epi, ctx->stream, o, false);
     a.i_begin = ctx->Vh - ctx->face; a.i_end = ctx->Vh;
-    launch_epi<2>(a, epi, ctx->stream, block, nt, false);
+    launch_epi<2>(a, epi, ctx->stream, o, false);
   }
   TMHIP_CHECK(hipGetLastError());
   return 0;

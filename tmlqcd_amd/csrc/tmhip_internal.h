@@ -70,10 +70,10 @@ struct tmhip_ctx {
   // solver work fields
   tmhip_field *sf[3];
   // halo exchange
-  ncclComm_t comm; bool comm_ready; bool loopback;
+  ncclComm_t comm; bool comm_ready; bool loopback; bool loopback_rccl;
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
   // options
-  int opt_block; int opt_xcd; int opt_nt; int opt_variant;
+  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_variant;
 };
 
 // ---- launch helpers implemented across the .hip files ----

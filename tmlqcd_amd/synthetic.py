@@ -1,0 +1,54 @@
+"""Seeded synthetic inputs in the reference's host layouts (host-side utility; numpy only).
+
+The gauge field is defined per *global* time-slice, so every rank of a T-split lattice can build
+its own slab -- including the two halo slices the reference obtains through xchange_gauge
+(benchmark.c:250-253) -- without communication, and a single-rank run of the same global
+lattice sees identical links.  Link construction follows random_su3 (start.c:387-425):
+two random vectors, Gram-Schmidt, third row = conj(cross product).
+"""
+import numpy as np
+
+
+def _su3(rng, n):
+    z1 = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    z2 = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    z1 /= np.linalg.norm(z1, axis=1, keepdims=True)
+    z2 -= (np.conj(z1) * z2).sum(axis=1, keepdims=True) * z1
+    z2 /= np.linalg.norm(z2, axis=1, keepdims=True)
+    u = np.stack([z1, z2, np.conj(np.cross(z1, z2))], axis=1)
+    out = np.empty((n, 3, 3, 2), dtype=np.float64)
+    out[..., 0], out[..., 1] = u.real, u.imag
+    return out
+
+
+def gauge_slice(seed, t_global, LX, LY, LZ):
+    """Links of one global time-slice: [LX*LY*LZ][4][3][3][2]."""
+    rng = np.random.default_rng([seed, 1, t_global])
+    return _su3(rng, LX * LY * LZ * 4).reshape(LX * LY * LZ, 4, 3, 3, 2)
+
+
+def gauge_field(seed, T, LX, LY, LZ, nproc_t=1, proc_t=0):
+    """g_gauge_field of one rank: [VOLUMEPLUSRAND][4][3][3][2], lexicographic (geometry_eo.c:290),
+    with the t = T and t = -1 halo slabs appended when nproc_t > 1 (geometry_eo.c:292-299)."""
+    Tg, XYZ = T * nproc_t, LX * LY * LZ
+    ts = [proc_t * T + t for t in range(T)]
+    if nproc_t > 1:
+        ts += [(proc_t * T + T) % Tg, (proc_t * T - 1) % Tg]
+    return np.concatenate([gauge_slice(seed, t, LX, LY, LZ) for t in ts], axis=0)
+
+
+def spinor_slice(seed, t_global, LX, LY, LZ):
+    rng = np.random.default_rng([seed, 2, t_global])
+    return rng.standard_normal((LX * LY * LZ, 4, 3, 2))
+
+
+def spinor_field_eo(seed, parity, T, LX, LY, LZ, nproc_t=1, proc_t=0):
+    """Gaussian spinor on the sites of one parity, e/o order (geometry_eo.c:869-885): [V/2][4][3][2]."""
+    out = []
+    z, y, x = np.meshgrid(np.arange(LZ), np.arange(LY), np.arange(LX), indexing="ij")
+    sxyz = (x + y + z).transpose(2, 1, 0).reshape(-1)  # lexicographic x,y,z with z fastest
+    for t in range(T):
+        tg = proc_t * T + t
+        full = spinor_slice(seed, tg, LX, LY, LZ)
+        out.append(full[((sxyz + tg) & 1) == parity])
+    return np.ascontiguousarray(np.concatenate(out, axis=0))
