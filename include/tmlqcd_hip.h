@@ -134,6 +134,11 @@ int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]); /* ri
  * copies; on = 2: through a one-rank RCCL communicator (ncclSend/ncclRecv to self). */
 int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on);
 
+/* Single-process ring of n contexts (ctxs[r] = rank r of an n-way T split; one per GPU, or several
+ * on one GPU as a self-test): Hopping_Matrix on every slab with the faces moved by peer copies
+ * (hipMemcpyPeerAsync) instead of RCCL.  Same pack / interior / boundary kernels as the RCCL path. */
+int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhip_field **l, tmhip_field **k);
+
 /* ---- measurement ---------------------------------------------------------- */
 /* The benchmark.c:291-300 loop on device-resident fields: iters x {H(0,f1,f0); H(1,f2,f1)},
  * timed with HIP events on the context's stream.  ms_total = elapsed milliseconds. */

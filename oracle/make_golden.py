@@ -1,0 +1,90 @@
+"""TEST INFRASTRUCTURE ONLY.  Regenerates tests/golden/*.npz|json from the reference's own
+object code (oracle/_ref/libtmref.so, built in place from /root/reference by `make -C oracle ref`).
+
+Each lattice size runs in its own subprocess because the reference keeps its state in globals.
+Fixtures are data only: inputs (RANLUX-seeded random_gauge_field / random_spinor_field_eo,
+benchmark.c:247-259, seed 123456) and the reference's outputs.
+
+    python oracle/make_golden.py
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def gen(T, L, full):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle.refbind import RefLattice
+    kappa, mu = 0.125, 0.01
+    r = RefLattice(T, L, L, L, kappa=kappa, mu=mu, nfields=14)
+    r.random_fields(123456)
+    lib, N, V = r.lib, r.V // 2, r.V
+    sp = r.sp
+    scal = {"T": T, "L": L, "kappa": kappa, "mu": mu, "seed": 123456}
+    scal["norm_in"] = lib.square_norm(sp(0), N, 0)
+    lib.Hopping_Matrix(0, sp(1), sp(0))
+    scal["norm_Heo"] = lib.square_norm(sp(1), N, 0)
+    lib.Hopping_Matrix(1, sp(2), sp(1))
+    scal["norm_HoeHeo"] = lib.square_norm(sp(2), N, 0)
+    scal["HoeHeo_site0_s0c0"] = [float(x) for x in r.spinor(2, N)[0, 0, 0]]
+    arrs = {}
+    if full:
+        arrs["gauge"] = r.gauge().copy()
+        arrs["in"] = r.spinor(0, N).copy()
+        arrs["Heo"] = r.spinor(1, N).copy()
+        arrs["HoeHeo"] = r.spinor(2, N).copy()
+        c = 0.83 - 0.41j
+        lib.tm_times_Hopping_Matrix(1, sp(3), sp(1), c.real, c.imag)
+        arrs["tm_times_OE_of_Heo"] = r.spinor(3, N).copy()
+        lib.tm_sub_Hopping_Matrix(1, sp(3), sp(0), sp(1), c.real, c.imag)
+        arrs["tm_sub_OE_p_in_k_Heo"] = r.spinor(3, N).copy()
+        scal["cfactor"] = [c.real, c.imag]
+        for name in ("Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi"):
+            getattr(lib, name)(sp(3), sp(0))
+            arrs[name] = r.spinor(3, N).copy()
+        # M_full on (even = in, odd = Heo)
+        lib.M_full(sp(4), sp(5), sp(0), sp(1))
+        arrs["M_full_even"] = r.spinor(4, N).copy()
+        arrs["M_full_odd"] = r.spinor(5, N).copy()
+        # D_psi on a lexicographic field built from the two parities
+        e2l = r.eo2lexic()
+        lex = np.zeros((V, 4, 3, 2))
+        lex[e2l[:N]] = r.spinor(0, N)
+        lex[e2l[N:2 * N]] = r.spinor(1, N)
+        r.spinor(6, V)[:] = lex
+        lib.D_psi(sp(7), sp(6))
+        arrs["D_psi_in_lexic"] = lex
+        arrs["D_psi_out_lexic"] = r.spinor(7, V).copy()
+        arrs["eo2lexic"] = e2l.copy()
+        # linalg
+        scal["scalar_prod_r_in_Qpm"] = lib.scalar_prod_r(sp(0), sp(3), N, 0)
+    # CG on Qtm_pm_psi, source = in, eps_sq 1e-20 relative
+    lib.assign(sp(8), sp(0), N)
+    r.spinor(9)[:] = 0
+    it = lib.cg_her(sp(9), sp(8), 1000, 1e-20, 1, N, r.fnptr("Qtm_pm_psi"))
+    scal["cg_iters"] = it
+    lib.Qtm_pm_psi(sp(10), sp(9))
+    lib.diff(sp(10), sp(8), sp(10), N)
+    scal["cg_true_res_sq"] = lib.square_norm(sp(10), N, 0)
+    scal["cg_sol_norm"] = lib.square_norm(sp(9), N, 0)
+    if full:
+        arrs["cg_solution"] = r.spinor(9, N).copy()
+    os.makedirs(GOLD, exist_ok=True)
+    tag = "%dx%d" % (T, L)
+    json.dump(scal, open(os.path.join(GOLD, "ref_scalars_%s.json" % tag), "w"), indent=1)
+    if full:
+        np.savez_compressed(os.path.join(GOLD, "ref_fields_%s.npz" % tag), **arrs)
+    print(tag, scal)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 4:
+        gen(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "1")
+    else:
+        for T, L, full in ((4, 4, 1), (8, 8, 0), (6, 4, 0)):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), str(T), str(L), str(full)])

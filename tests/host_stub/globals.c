@@ -1,0 +1,38 @@
+/* Test stand-in for the HOST PROGRAM (benchmark / invert / hmc_tm): defines the tmLQCD globals
+ * that libtmlqcd_dropin.so reads at call time (global.h:73-207, boundary.h:25) and lets a test
+ * fill them the way tmlqcd_mpi_init (mpi_init.c:748-778), init_gauge_field
+ * (init/init_gauge_field.c:51-68) and boundary() (boundary.c:40-55) would.  Not part of the product. */
+#include <complex.h>
+#include <math.h>
+#include <stdlib.h>
+
+typedef struct { double _Complex c00, c01, c02, c10, c11, c12, c20, c21, c22; } su3;
+
+int T, LX, LY, LZ, VOLUME, RAND, VOLUMEPLUSRAND;
+int g_nproc_t = 1, g_nproc_x = 1, g_nproc_y = 1, g_nproc_z = 1;
+int g_proc_coords[4] = {0, 0, 0, 0};
+su3 **g_gauge_field = NULL;
+int g_update_gauge_copy = 1;
+double g_mu = 0.0, g_kappa = 0.125;
+double _Complex ka0, ka1, ka2, ka3;
+static su3 *gauge_block = NULL;
+
+su3 *stub_init(int T_, int LX_, int LY_, int LZ_) {
+  T = T_; LX = LX_; LY = LY_; LZ = LZ_;
+  VOLUME = T * LX * LY * LZ; RAND = 0; VOLUMEPLUSRAND = VOLUME;
+  free(gauge_block); free(g_gauge_field);
+  gauge_block = (su3 *)calloc(4 * (size_t)VOLUMEPLUSRAND + 1, sizeof(su3));
+  g_gauge_field = (su3 **)calloc(VOLUMEPLUSRAND, sizeof(su3 *));
+  for (int i = 0; i < VOLUMEPLUSRAND; i++) g_gauge_field[i] = gauge_block + 4 * (size_t)i;
+  g_update_gauge_copy = 1;
+  return gauge_block;
+}
+void stub_boundary(double kappa, double x0, double x1, double x2, double x3) {
+  const double PI_ = 3.14159265358979;
+  g_kappa = kappa;
+  ka0 = kappa * cexp(x0 * PI_ / T * I); ka1 = kappa * cexp(x1 * PI_ / LX * I);
+  ka2 = kappa * cexp(x2 * PI_ / LY * I); ka3 = kappa * cexp(x3 * PI_ / LZ * I);
+}
+void stub_set_mu(double mu) { g_mu = mu; }
+void stub_mark_gauge_dirty(void) { g_update_gauge_copy = 1; }
+int stub_gauge_flag(void) { return g_update_gauge_copy; }

@@ -1,0 +1,77 @@
+"""CPU: the C-ABI libraries load and export every symbol their headers declare (no compute calls)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tmlqcd_amd", "lib")
+
+
+def declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//.*", "", txt)
+    txt = re.sub(r"typedef[^;]*;", "", txt)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", txt)
+    return sorted(set(n for n in names if n not in ("defined", "matrix_mult")))
+
+
+def exported(lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    return set(l.split()[-1] for l in out.splitlines() if l.strip())
+
+
+def test_core_library_exports_header():
+    names = declared_functions("tmlqcd_hip.h")
+    assert len(names) > 40
+    exp = exported(os.path.join(LIB, "libtmlqcd_hip.so"))
+    missing = [n for n in names if n not in exp]
+    assert not missing, missing
+
+
+def test_dropin_library_exports_reference_symbols():
+    names = declared_functions("tmlqcd_dropin.h")
+    for must in ("Hopping_Matrix", "Hopping_Matrix_nocom", "tm_times_Hopping_Matrix", "tm_sub_Hopping_Matrix", "D_psi",
+                 "Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi", "M_full", "Q_full",
+                 "H_eo_tm_inv_psi", "mul_one_pm_imu_inv", "assign_mul_one_pm_imu_inv", "assign_mul_one_pm_imu",
+                 "mul_one_pm_imu_sub_mul", "square_norm", "scalar_prod_r", "assign_add_mul_r", "assign_mul_add_r",
+                 "assign_mul_add_r_and_square", "diff", "assign", "cg_her", "gamma5"):
+        assert must in names, must
+    exp = exported(os.path.join(LIB, "libtmlqcd_dropin.so"))
+    missing = [n for n in names if n not in exp]
+    assert not missing, missing
+
+
+def test_core_library_loads_and_reports_version():
+    import tmlqcd_amd
+    lib = tmlqcd_amd.load_library()
+    assert b"gfx950" in lib.tmhip_version()
+    assert lib.tmhip_device_count() >= 0
+
+
+def test_dropin_loads_next_to_a_host_program_stub(host_stub):
+    """libtmlqcd_dropin.so resolves tmLQCD's globals from the host program (here: tests/host_stub)."""
+    stub, dropin = host_stub
+    for g in ("T", "LX", "VOLUME", "g_update_gauge_copy", "g_mu", "ka0", "g_gauge_field"):
+        C.c_int.in_dll(stub, g)
+    assert dropin.Hopping_Matrix and dropin.cg_her and dropin.tmlqcd_hip_set_residency
+
+
+def test_bad_geometry_is_rejected_before_touching_the_gpu():
+    """Same constraints as the reference's e/o build (mpi_init.c:784-799): even extents."""
+    import tmlqcd_amd
+    from tmlqcd_amd.hip import TmHipError
+    for dims in ((3, 4, 4, 4), (4, 4, 4, 5), (0, 4, 4, 4)):
+        with pytest.raises(TmHipError):
+            tmlqcd_amd.Lattice(*dims)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import tmlqcd_amd.hip as h
+    monkeypatch.setattr(h, "_LIB", None)
+    monkeypatch.setattr(h, "library_path", lambda: "/nonexistent/libtmlqcd_hip.so")
+    with pytest.raises(h.TmHipError):
+        h.load_library()

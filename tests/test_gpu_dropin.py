@@ -1,0 +1,120 @@
+"""GPU: the drop-in layer (reference symbol names, host AoS pointers, tmLQCD globals read at call time)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import TOL, random_gauge, random_spinor, rel_err
+
+pytestmark = pytest.mark.gpu
+VP = C.c_void_p
+
+
+def _p(a):
+    return a.ctypes.data_as(VP)
+
+
+@pytest.fixture(scope="module")
+def host(host_stub):
+    from oracle.oraclebind import Oracle
+    stub, d = host_stub
+    T, L = 8, 8
+    kappa, mu, theta = 0.129, 0.013, (1.0, 0.0, 0.0, 0.0)
+    V = T * L ** 3
+    gptr = stub.stub_init(T, L, L, L)
+    g = random_gauge(51, V)
+    C.memmove(gptr, _p(g), g.nbytes)
+    stub.stub_boundary(kappa, *theta)
+    stub.stub_set_mu(mu)
+    orc = Oracle(T, L, L, L, kappa=kappa, mu=mu, theta=theta, threads=4)
+    orc.set_gauge(g)
+    d.Hopping_Matrix.argtypes = [C.c_int, VP, VP]
+    d.tm_times_Hopping_Matrix.argtypes = [C.c_int, VP, VP, C.c_double, C.c_double]   # complex by value = (re, im) in SSE regs
+    d.tm_sub_Hopping_Matrix.argtypes = [C.c_int, VP, VP, VP, C.c_double, C.c_double]
+    for n in ("Qtm_pm_psi", "Qtm_minus_psi", "D_psi", "Q_pm_psi"):
+        getattr(d, n).argtypes = [VP, VP]
+    d.square_norm.restype = C.c_double; d.square_norm.argtypes = [VP, C.c_int, C.c_int]
+    d.scalar_prod_r.restype = C.c_double; d.scalar_prod_r.argtypes = [VP, VP, C.c_int, C.c_int]
+    d.assign_add_mul_r.argtypes = [VP, VP, C.c_double, C.c_int]
+    d.cg_her.restype = C.c_int; d.cg_her.argtypes = [VP, VP, C.c_int, C.c_double, C.c_int, C.c_int, VP]
+    d.tmlqcd_hip_set_residency.argtypes = [C.c_int]
+    d.tmlqcd_hip_sync_to_host.argtypes = [VP]
+    d.tmlqcd_hip_host_modified.argtypes = [VP]
+    d.tmlqcd_hip_benchmark_loop.restype = C.c_double
+    d.tmlqcd_hip_benchmark_loop.argtypes = [VP, VP, VP, C.c_int]
+    yield stub, d, orc, g, (T, L, V)
+    d.tmlqcd_hip_finalize()
+
+
+def test_coherent_mode_is_a_plain_drop_in(host):
+    stub, d, orc, g, (T, L, V) = host
+    N = V // 2
+    k = random_spinor(1, N); l = np.zeros_like(k); ref = orc.new_field()
+    d.Hopping_Matrix(0, _p(l), _p(k)); orc.Hopping_Matrix(0, ref, k)
+    assert rel_err(l, ref[:N]) < TOL
+    assert stub.stub_gauge_flag() == 0                     # consumed like update_backward_gauge.c:240
+    c = 0.6 + 0.2j
+    p = random_spinor(2, N)
+    d.tm_times_Hopping_Matrix(1, _p(l), _p(k), c.real, c.imag); orc.tm_times_Hopping_Matrix(1, ref, k, c)
+    assert rel_err(l, ref[:N]) < TOL
+    d.tm_sub_Hopping_Matrix(1, _p(l), _p(p), _p(k), c.real, c.imag); orc.tm_sub_Hopping_Matrix(1, ref, p, k, c)
+    assert rel_err(l, ref[:N]) < TOL
+    d.Qtm_pm_psi(_p(l), _p(k)); orc.op("Qtm_pm_psi", ref, k.copy())
+    assert rel_err(l, ref[:N]) < TOL
+    assert abs(d.square_norm(_p(k), N, 0) - orc.square_norm(k, N)) <= TOL * orc.square_norm(k, N)
+    a = k.copy(); d.assign_add_mul_r(_p(a), _p(p), 0.5, N)
+    assert rel_err(a, k + 0.5 * p) < TOL
+    kk = k.copy(); ref2 = orc.new_field(); ref2[:N] = k
+    d.Qtm_minus_psi(_p(kk), _p(kk)); orc.op("Qtm_minus_psi", ref2, ref2)   # in place (invert_eo.c:270)
+    assert rel_err(kk, ref2[:N]) < TOL
+
+
+def test_globals_are_reread_at_call_time(host):
+    stub, d, orc, g, (T, L, V) = host
+    N = V // 2
+    k = random_spinor(3, N); l = np.zeros_like(k); ref = orc.new_field()
+    stub.stub_set_mu(-0.05); orc.set_mu(-0.05)             # callers flip g_mu around calls (tm_operators.c:382-385)
+    stub.stub_boundary(0.11, 0.5, 0.0, 0.0, 0.25); orc.set_kappa_theta(0.11, (0.5, 0.0, 0.0, 0.25))
+    d.Qtm_pm_psi(_p(l), _p(k)); orc.op("Qtm_pm_psi", ref, k.copy())
+    assert rel_err(l, ref[:N]) < TOL
+    g2 = random_gauge(52, V)
+    C.memmove(stub.stub_init(T, L, L, L), _p(g2), g2.nbytes)   # new configuration + g_update_gauge_copy = 1
+    orc.set_gauge(g2)
+    d.Hopping_Matrix(1, _p(l), _p(k)); orc.Hopping_Matrix(1, ref, k)
+    assert rel_err(l, ref[:N]) < TOL
+    stub.stub_set_mu(0.013); orc.set_mu(0.013)
+    stub.stub_boundary(0.129, 1.0, 0.0, 0.0, 0.0); orc.set_kappa_theta(0.129, (1.0, 0.0, 0.0, 0.0))
+
+
+def test_full_lattice_operators(host):
+    stub, d, orc, g, (T, L, V) = host
+    lex = random_spinor(4, V); out = np.zeros_like(lex); ref = np.zeros_like(lex)
+    d.D_psi(_p(out), _p(lex)); orc.D_psi(ref, lex)
+    assert rel_err(out, ref) < TOL
+    # Q_pm_psi = g5 D(+mu) g5 D(-mu)   (tm_operators.c:380-388)
+    d.Q_pm_psi(_p(out), _p(lex))
+    mu = orc.mu
+    t1 = np.zeros_like(lex); t2 = np.zeros_like(lex)
+    orc.set_mu(-mu); orc.D_psi(t1, lex); orc.gamma5(t2, t1, V); orc.set_mu(mu); orc.D_psi(t1, t2); orc.gamma5(ref, t1, V)
+    assert rel_err(out, ref) < TOL
+    assert abs(d.square_norm(_p(lex), V, 0) - (lex ** 2).sum()) <= 1e-12 * (lex ** 2).sum()
+
+
+def test_cg_her_drop_in_and_resident_benchmark(host):
+    stub, d, orc, g, (T, L, V) = host
+    N = V // 2
+    q = random_spinor(5, N); P = np.zeros_like(q)
+    f = C.cast(d.Qtm_pm_psi, VP)
+    it = d.cg_her(_p(P), _p(q), 500, 1e-18, 1, N, f)
+    Pref = orc.new_field(); it_ref, _ = orc.cg_her(Pref, q.copy(), 500, 1e-18, 1, N)
+    assert abs(it - it_ref) <= 1 and rel_err(P, Pref[:N]) < 1e-8
+    # resident mode: outputs stay in HBM until asked for
+    f0 = random_spinor(6, N); f1 = np.zeros_like(f0); f2 = np.zeros_like(f0)
+    d.tmlqcd_hip_set_residency(1)
+    secs = d.tmlqcd_hip_benchmark_loop(_p(f0), _p(f1), _p(f2), 5)
+    assert secs > 0 and not f2.any()                      # host copy untouched so far
+    d.tmlqcd_hip_sync_to_host(_p(f2))
+    r1, r2 = orc.new_field(), orc.new_field()
+    orc.Hopping_Matrix(0, r1, f0); orc.Hopping_Matrix(1, r2, r1)
+    assert rel_err(f2, r2[:N]) < TOL
+    d.tmlqcd_hip_set_residency(0)

@@ -1,0 +1,269 @@
+"""GPU parity through the C-ABI: linalg, site-diagonal ops, e/o compositions, D_psi and cg_her
+against the CPU oracle on the same seeded inputs, plus the reference-generated golden fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import TOL, random_gauge, random_spinor, rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T, LX, LY, LZ = 8, 6, 4, 12          # ragged extents: no power of two, LZ/2 odd
+    kappa, mu, theta = 0.131, 0.017, (1.0, 0.5, -0.25, 0.125)
+    orc = Oracle(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta, threads=8)
+    lat = Lattice(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta)
+    g = random_gauge(41, orc.VPR)
+    orc.set_gauge(g)
+    lat.set_gauge(g)
+    yield orc, lat
+    lat.close()
+
+
+def test_reductions(setup):
+    orc, lat = setup
+    N = orc.Vh
+    a, b = random_spinor(1, N), random_spinor(2, N)
+    da, db = lat.field(a), lat.field(b)
+    for got, ref in ((lat.square_norm(da, N), orc.square_norm(a, N)),
+                     (lat.scalar_prod_r(da, db, N), orc.scalar_prod_r(a, b, N))):
+        assert abs(got - ref) <= TOL * abs(orc.square_norm(a, N))
+    ra = a.copy()
+    nref = orc.assign_mul_add_r_and_square(ra, -0.7, b, N)
+    ngot = lat.assign_mul_add_r_and_square(da, -0.7, db, N)
+    assert abs(ngot - nref) <= TOL * nref and rel_err(da.download(), ra) < TOL
+    da.free(); db.free()
+
+
+def test_reduction_is_reproducible_and_accurate(setup):
+    """Fixed-order tree: bitwise identical run to run; vs an exactly rounded sum (math.fsum) < 1e-14."""
+    import math
+    orc, lat = setup
+    N = orc.Vh
+    a = random_spinor(7, N) * np.logspace(-3, 3, N)[:, None, None, None]
+    da = lat.field(a)
+    v = [lat.square_norm(da, N) for _ in range(3)]
+    assert v[0] == v[1] == v[2]
+    exact = math.fsum((a.astype(np.float64) ** 2).ravel().tolist())
+    assert abs(v[0] - exact) <= 1e-14 * exact
+    da.free()
+
+
+def test_streaming_updates(setup):
+    orc, lat = setup
+    N = orc.Vh
+    a, b = random_spinor(3, N), random_spinor(4, N)
+    da, db, dc = lat.field(a), lat.field(b), lat.field()
+    ra = a.copy(); orc.assign_add_mul_r(ra, b, 0.756, N); lat.assign_add_mul_r(da, db, 0.756, N)
+    assert rel_err(da.download(), ra) < TOL
+    orc.assign_mul_add_r(ra, -1.3, b, N); lat.assign_mul_add_r(da, -1.3, db, N)
+    assert rel_err(da.download(), ra) < TOL
+    rc = np.zeros_like(a); orc.diff(rc, ra, b, N); lat.diff(dc, da, db, N)
+    assert rel_err(dc.download(), rc) < TOL
+    lat.assign(dc, db, N)
+    assert np.array_equal(dc.download(), b)
+    for f in (da, db, dc):
+        f.free()
+
+
+@pytest.mark.parametrize("sign", [+1.0, -1.0])
+def test_site_diagonal_ops_and_aliasing(setup, sign):
+    orc, lat = setup
+    N = orc.Vh
+    k, j = random_spinor(5, N), random_spinor(6, N)
+    dk, dj, dl = lat.field(k), lat.field(j), lat.field()
+    ref = np.zeros_like(k)
+    orc.assign_mul_one_pm_imu_inv(ref, k, sign, N); lat.assign_mul_one_pm_imu_inv(dl, dk, sign, N)
+    assert rel_err(dl.download(), ref) < TOL
+    orc.assign_mul_one_pm_imu(ref, k, sign, N); lat.assign_mul_one_pm_imu(dl, dk, sign, N)
+    assert rel_err(dl.download(), ref) < TOL
+    orc.mul_one_pm_imu_sub_mul(ref, k, j, sign, N); lat.mul_one_pm_imu_sub_mul(dl, dk, dj, sign, N)
+    assert rel_err(dl.download(), ref) < TOL
+    orc.mul_one_pm_imu_sub_mul_gamma5(ref, k, j, sign); lat.mul_one_pm_imu_sub_mul_gamma5(dl, dk, dj, sign)
+    assert rel_err(dl.download(), ref) < TOL
+    # in place, as tm_operators.c:371 (l == j) and mul_one_pm_imu_inv (l == k) use them
+    rj = j.copy(); orc.mul_one_pm_imu_sub_mul_gamma5(rj, k, rj, sign); lat.mul_one_pm_imu_sub_mul_gamma5(dj, dk, dj, sign)
+    assert rel_err(dj.download(), rj) < TOL
+    rk = k.copy(); orc.mul_one_pm_imu_inv(rk, sign, N); lat.mul_one_pm_imu_inv(dk, sign, N)
+    assert rel_err(dk.download(), rk) < TOL
+    dk.upload(rk)
+    orc.gamma5(ref, rk, N); lat.gamma5(dl, dk, N)
+    assert np.array_equal(dl.download(), ref)              # sign flips only: exact
+    for f in (dk, dj, dl):
+        f.free()
+
+
+@pytest.mark.parametrize("name", ["Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi"])
+def test_eo_operators(setup, name):
+    orc, lat = setup
+    N = orc.Vh
+    k = random_spinor(8, N)
+    ref = orc.new_field()
+    orc.op(name, ref, k.copy())
+    dk, dl = lat.field(k), lat.field()
+    lat.op(name, dl, dk)
+    assert rel_err(dl.download(), ref[:N]) < TOL
+    assert np.array_equal(dk.download(), k)          # input untouched
+    dk.free(); dl.free()
+
+
+def test_qtm_minus_in_place_like_invert_eo(setup):
+    """invert_eo.c:270 calls Qtm_minus_psi(Odd_new, Odd_new)."""
+    orc, lat = setup
+    N = orc.Vh
+    k = random_spinor(9, N)
+    ref = orc.new_field(); ref[:N] = k
+    orc.op("Qtm_minus_psi", ref, ref)
+    dk = lat.field(k)
+    lat.op("Qtm_minus_psi", dk, dk)
+    assert rel_err(dk.download(), ref[:N]) < TOL
+    dk.free()
+
+
+def test_M_full_and_D_psi(setup):
+    orc, lat = setup
+    N, V = orc.Vh, orc.V
+    e, o = random_spinor(10, N), random_spinor(11, N)
+    ren, ron = orc.new_field(), orc.new_field()
+    orc.M_full(ren, ron, e, o)
+    de, do, den, don = lat.field(e), lat.field(o), lat.field(), lat.field()
+    lat.M_full(den, don, de, do)
+    assert rel_err(den.download(), ren[:N]) < TOL and rel_err(don.download(), ron[:N]) < TOL
+    lex = random_spinor(12, V)
+    P = np.zeros_like(lex)
+    orc.D_psi(P, lex)
+    dQ = lat.full_field(lex)
+    dP = lat.full_field()
+    lat.D_psi(dP, dQ)
+    assert rel_err(dP.download(), P) < TOL
+    assert np.array_equal(dQ.download(), lex)        # lexicographic <-> e/o round trip is exact
+    from tmlqcd_amd.hip import TmHipError
+    with pytest.raises(TmHipError):                  # D_psi_body.c:267-272: P == Q is an error
+        lat.D_psi(dQ, dQ)
+    with pytest.raises(TmHipError):                  # stencil: l != k
+        lat.Hopping_Matrix(0, de, de)
+    for f in (de, do, den, don, dQ, dP):
+        f.free()
+
+
+def test_linearity_and_hermiticity_at_scale():
+    """Size-independent properties at a BASELINE size (16^4): H(a x + y) = a H x + H y;
+    <y, Q+Q- x> = <Q+Q- y, x> (Qtm_pm_psi is hermitian, which is what cg_her relies on)."""
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T = L = 16
+    lat = Lattice(T, L, L, L, kappa=0.137, mu=0.02)
+    lat.set_gauge(syn.gauge_field(5, T, L, L, L))
+    N = lat.Vh
+    x, y = lat.field(syn.spinor_field_eo(6, 1, T, L, L, L)), lat.field(syn.spinor_field_eo(7, 1, T, L, L, L))
+    hx, hy, z, hz = lat.field(), lat.field(), lat.field(), lat.field()
+    lat.Hopping_Matrix(0, hx, x); lat.Hopping_Matrix(0, hy, y)
+    lat.assign(z, y, N); lat.assign_add_mul_r(z, x, 0.37, N)          # z = 0.37 x + y
+    lat.Hopping_Matrix(0, hz, z)
+    lat.assign_add_mul_r(hy, hx, 0.37, N)                              # hy = 0.37 Hx + Hy
+    lat.diff(hz, hz, hy, N)
+    assert lat.square_norm(hz, N) <= (1e-13) ** 2 * lat.square_norm(hy, N)
+    qx, qy = lat.field(), lat.field()
+    lat.Qtm_pm_psi(qx, x); lat.Qtm_pm_psi(qy, y)
+    a, b = lat.scalar_prod_r(y, qx, N), lat.scalar_prod_r(qy, x, N)
+    assert abs(a - b) <= 1e-12 * abs(a)
+    assert lat.scalar_prod_r(x, qx, N) > 0                             # positive
+    lat.close()
+
+
+def test_cg_her_matches_oracle(setup):
+    orc, lat = setup
+    N = orc.Vh
+    q = random_spinor(13, N)
+    P = orc.new_field()
+    it_ref, hist_ref = orc.cg_her(P, q.copy(), 500, 1e-20, 1, N)
+    dq, dp = lat.field(q), lat.field()
+    it, hist = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
+    assert it > 0 and abs(it - it_ref) <= 1                    # within +-1 iteration
+    m = min(len(hist), len(hist_ref)) - 1
+    assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6)      # residual histories track each other
+    sol = dp.download()
+    assert rel_err(sol, P[:N]) < 1e-9
+    # true residual in fp64 on the CPU (operator.c:358,379-384 "reached_prec")
+    chk = orc.new_field(); full = orc.new_field(); full[:N] = sol
+    orc.op("Qtm_pm_psi", chk, full)
+    res = ((chk[:N] - q) ** 2).sum() / (q ** 2).sum()
+    assert res <= 4e-20
+    dq.free(); dp.free()
+
+
+def test_cg_not_converged_returns_minus_one(setup):
+    orc, lat = setup
+    N = orc.Vh
+    dq, dp = lat.field(random_spinor(14, N)), lat.field()
+    it, _ = lat.cg_her(dp, dq, 3, 1e-30, 1, N)
+    assert it == -1                                            # cg_her.c:140-141
+    dq.free(); dp.free()
+
+
+def test_golden_fixture_from_reference_on_gpu():
+    """tests/golden/ref_fields_4x4.npz: inputs and outputs produced by the reference object code."""
+    from tmlqcd_amd import Lattice
+    f = np.load(os.path.join(GOLD, "ref_fields_4x4.npz"))
+    s = json.load(open(os.path.join(GOLD, "ref_scalars_4x4.json")))
+    lat = Lattice(4, 4, 4, 4, kappa=s["kappa"], mu=s["mu"])
+    lat.set_gauge(np.ascontiguousarray(f["gauge"]))
+    N = lat.Vh
+    d0, d1, d2 = lat.field(np.ascontiguousarray(f["in"])), lat.field(), lat.field()
+    lat.Hopping_Matrix(0, d1, d0); lat.Hopping_Matrix(1, d2, d1)
+    assert rel_err(d1.download(), f["Heo"]) < TOL and rel_err(d2.download(), f["HoeHeo"]) < TOL
+    assert abs(lat.square_norm(d2, N) - s["norm_HoeHeo"]) <= TOL * s["norm_HoeHeo"]
+    for name in ("Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi"):
+        lat.op(name, d2, d0)
+        assert rel_err(d2.download(), f[name]) < TOL, name
+    c = complex(*s["cfactor"])
+    lat.tm_times_Hopping_Matrix(1, d2, d1, c)
+    assert rel_err(d2.download(), f["tm_times_OE_of_Heo"]) < TOL
+    lat.tm_sub_Hopping_Matrix(1, d2, d0, d1, c)
+    assert rel_err(d2.download(), f["tm_sub_OE_p_in_k_Heo"]) < TOL
+    dQ, dP = lat.full_field(np.ascontiguousarray(f["D_psi_in_lexic"])), lat.full_field()
+    lat.D_psi(dP, dQ)
+    assert rel_err(dP.download(), f["D_psi_out_lexic"]) < TOL
+    dp = lat.field()
+    it, _ = lat.cg_her(dp, d0, 1000, 1e-20, 1, N)
+    assert abs(it - s["cg_iters"]) <= 1
+    assert rel_err(dp.download(), f["cg_solution"]) < 1e-9
+    lat.close()
+
+
+@pytest.mark.parametrize("T", [2, 4])
+def test_t_split_two_contexts_on_one_gpu(T):
+    """nproc_t = 2 geometry on real hardware: two contexts of this process hold the two slabs (halo gauge
+    links, global parity offset, face pack -> peer copy -> boundary kernels) == the unsplit lattice."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    from tmlqcd_amd.hip import multi_Hopping_Matrix
+    L, world = 6, 2
+    Tg = T * world
+    kappa, theta = 0.13, (1.0, 0.0, 0.0, 0.5)
+    g = Oracle(Tg, L, L, L, kappa=kappa, theta=theta, threads=4)
+    g.set_gauge(syn.gauge_field(3, Tg, L, L, L))
+    lats = [Lattice(T, L, L, L, kappa=kappa, theta=theta, nproc_t=world, proc_t=r) for r in range(world)]
+    for r, lat in enumerate(lats):
+        lat.set_gauge(syn.gauge_field(3, T, L, L, L, world, r))
+    Vh = lats[0].Vh
+    for ieo in (0, 1):
+        kg = g.new_field(); kg[:g.Vh] = syn.spinor_field_eo(4, 1 - ieo, Tg, L, L, L)
+        ref = g.new_field()
+        g.Hopping_Matrix(ieo, ref, kg)
+        ks = [lat.field(syn.spinor_field_eo(4, 1 - ieo, T, L, L, L, world, r)) for r, lat in enumerate(lats)]
+        ls = [lat.field() for lat in lats]
+        for _ in range(2):   # twice: the second call exercises the buffer re-use ordering
+            multi_Hopping_Matrix(lats, ieo, ls, ks)
+        for r in range(world):
+            assert rel_err(ls[r].download(), ref[r * Vh:(r + 1) * Vh]) < TOL, (ieo, r)
+    for lat in lats:
+        lat.close()

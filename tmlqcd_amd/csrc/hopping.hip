@@ -285,11 +285,7 @@ static void launch_epi(const HopArgs &a, int epi, hipStream_t st, const HopLaunc
   }
 }
 
-int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
-                         double cre, double cim, bool comm) {
-  if (!ctx->gauge_set) TMHIP_FAIL("Hopping_Matrix called before tmhip_set_gauge");
-  if (out == in) TMHIP_FAIL("Hopping_Matrix: l and k must differ (operator/D_psi_body.c:267-272 convention)");
-  HopArgs a;
+static void fill_args(HopArgs &a, tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, double cre, double cim) {
   a.out = out; a.in = in; a.p = p;
   a.gauge = ctx->gauge + (size_t)(ieo ? 1 : 0) * 72 * ctx->gs;
   a.halo_up = ctx->recv_up; a.halo_dn = ctx->recv_dn;
@@ -300,6 +296,31 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
   a.nxcd_chunk = 0; a.map_tc = 0; a.map_bpt = 0;
   for (int m = 0; m < 4; m++) { a.ka[m][0] = ctx->ka[m][0]; a.ka[m][1] = ctx->ka[m][1]; }
   a.cre = cre; a.cim = cim;
+}
+
+static void launch_pack(tmhip_ctx *ctx, const v2d *in) {
+  hipLaunchKernelGGL(pack_faces_kernel, dim3((ctx->face + 255) / 256, 2), dim3(256), 0, ctx->stream,
+                     in, ctx->ns, ctx->Vh, ctx->face, ctx->send_dn, ctx->send_up);
+}
+
+static void launch_interior(tmhip_ctx *ctx, HopArgs &a, int epi, const HopLaunch &o) {
+  a.i_begin = ctx->face; a.i_end = ctx->Vh - ctx->face;
+  launch_epi<0>(a, epi, ctx->stream, o, true);
+}
+
+static void launch_boundary(tmhip_ctx *ctx, HopArgs &a, int epi, const HopLaunch &o) {
+  a.i_begin = 0; a.i_end = ctx->face;
+  launch_epi<1>(a, epi, ctx->stream, o, false);
+  a.i_begin = ctx->Vh - ctx->face; a.i_end = ctx->Vh;
+  launch_epi<2>(a, epi, ctx->stream, o, false);
+}
+
+int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
+                         double cre, double cim, bool comm) {
+  if (!ctx->gauge_set) TMHIP_FAIL("Hopping_Matrix called before tmhip_set_gauge");
+  if (out == in) TMHIP_FAIL("Hopping_Matrix: l and k must differ (operator/D_psi_body.c:267-272 convention)");
+  HopArgs a;
+  fill_args(a, ctx, ieo, out, in, p, cre, cim);
   const HopLaunch o = {ctx->opt_block, ctx->opt_nt != 0, ctx->opt_minw, ctx->opt_xcd, ctx->opt_occ};
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
   if (!split) {
@@ -308,21 +329,65 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
   } else {
     if (comm) {
       // split-phase: pack faces -> exchange on comm stream || interior kernel -> boundary kernels
-      hipLaunchKernelGGL(pack_faces_kernel, dim3((ctx->face + 255) / 256, 2), dim3(256), 0, ctx->stream,
-                         in, ctx->ns, ctx->Vh, ctx->face, ctx->send_dn, ctx->send_up);
+      launch_pack(ctx, in);
       TMHIP_CHECK(hipEventRecord(ctx->ev_pack, ctx->stream));
       TMHIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_pack, 0));
       if (tmhip_halo_exchange(ctx)) return 1;
       TMHIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
     }
-    a.i_begin = ctx->face; a.i_end = ctx->Vh - ctx->face;
-    launch_epi<0>(a, epi, ctx->stream, o, true);
+    launch_interior(ctx, a, epi, o);
     if (comm) TMHIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_comm, 0));
-    a.i_begin = 0; a.i_end = ctx->face;
-    launch_epi<1>(a, epi, ctx->stream, o, false);
-    a.i_begin = ctx->Vh - ctx->face; a.i_end = ctx->Vh;
-    launch_epi<2>(a, epi, ctx->stream, o, false);
+    launch_boundary(ctx, a, epi, o);
   }
   TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// Single-process ring: n contexts (one per GPU, or several on one GPU for the self-test) that
+// together hold a T-split lattice; faces move by peer copies instead of RCCL.  Collective over
+// all contexts because the host enqueues for every rank:
+//   1. every rank packs its two faces            (after its neighbours finished reading the previous ones)
+//   2. every rank pulls the neighbours' faces on its comm stream || runs its interior kernel
+//   3. every rank runs its boundary kernels once its pulls have landed
+extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhip_field **l, tmhip_field **k) {
+  if (n < 2) TMHIP_FAIL("tmhip_multi_hopping_matrix needs >= 2 contexts");
+  for (int r = 0; r < n; r++) {
+    tmhip_ctx *c = ctxs[r];
+    if (c->g.nproc_t != n || c->g.proc_t != r) TMHIP_FAIL("context %d is not rank %d of a %d-way T split", r, r, n);
+    if (!c->gauge_set) TMHIP_FAIL("Hopping_Matrix called before tmhip_set_gauge");
+    if (l[r]->kind != TMHIP_FIELD_EO || k[r]->kind != TMHIP_FIELD_EO || l[r]->d == k[r]->d) TMHIP_FAIL("bad fields for rank %d", r);
+  }
+  const size_t fb = (size_t)6 * ctxs[0]->face * sizeof(v2d);
+  for (int r = 0; r < n; r++) {
+    tmhip_ctx *c = ctxs[r], *up = ctxs[(r + 1) % n], *dn = ctxs[(r + n - 1) % n];
+    TMHIP_CHECK(hipSetDevice(c->device));
+    TMHIP_CHECK(hipStreamWaitEvent(c->stream, up->ev_comm, 0));  // neighbours still pulling the previous faces
+    TMHIP_CHECK(hipStreamWaitEvent(c->stream, dn->ev_comm, 0));
+    launch_pack(c, k[r]->d);
+    TMHIP_CHECK(hipEventRecord(c->ev_pack, c->stream));
+  }
+  for (int r = 0; r < n; r++) {
+    tmhip_ctx *c = ctxs[r], *up = ctxs[(r + 1) % n], *dn = ctxs[(r + n - 1) % n];
+    TMHIP_CHECK(hipSetDevice(c->device));
+    TMHIP_CHECK(hipStreamWaitEvent(c->comm_stream, up->ev_pack, 0));
+    TMHIP_CHECK(hipStreamWaitEvent(c->comm_stream, dn->ev_pack, 0));
+    TMHIP_CHECK(hipMemcpyPeerAsync(c->recv_up, c->device, up->send_dn, up->device, fb, c->comm_stream));
+    TMHIP_CHECK(hipMemcpyPeerAsync(c->recv_dn, c->device, dn->send_up, dn->device, fb, c->comm_stream));
+    TMHIP_CHECK(hipEventRecord(c->ev_comm, c->comm_stream));
+    HopArgs a;
+    fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
+    const HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ};
+    launch_interior(c, a, EPI_STORE, o);
+  }
+  for (int r = 0; r < n; r++) {
+    tmhip_ctx *c = ctxs[r];
+    TMHIP_CHECK(hipSetDevice(c->device));
+    TMHIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    HopArgs a;
+    fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
+    const HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ};
+    launch_boundary(c, a, EPI_STORE, o);
+    TMHIP_CHECK(hipGetLastError());
+  }
   return 0;
 }

@@ -79,6 +79,7 @@ def load_library():
         "tmhip_comm_init": [vp, C.c_char_p],
         "tmhip_comm_set_loopback": [vp, i],
         "tmhip_bench_hopping": [vp, vp, vp, vp, i, pd],
+        "tmhip_multi_hopping_matrix": [i, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp)],
         "tmhip_event_record": [vp, i],
         "tmhip_event_elapsed_ms": [vp, i, i, pd],
         "tmhip_set_option": [vp, C.c_char_p, i],
@@ -323,3 +324,11 @@ class Lattice:
         ms = C.c_double()
         _ck(self.lib.tmhip_event_elapsed_ms(self.h, a, b, C.byref(ms)), "tmhip_event_elapsed_ms")
         return ms.value
+
+
+def multi_Hopping_Matrix(lats, ieo, ls, ks):
+    """Hopping_Matrix on a T-split lattice held by several contexts of THIS process (peer-copy ring)."""
+    n = len(lats)
+    arr = C.c_void_p * n
+    _ck(lats[0].lib.tmhip_multi_hopping_matrix(n, arr(*[l.h for l in lats]), ieo, arr(*[f.h for f in ls]),
+                                               arr(*[f.h for f in ks])), "tmhip_multi_hopping_matrix")
