@@ -31,6 +31,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU-baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(available cores, 16)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B runs)")
+    ap.add_argument("--loopback", type=int, default=0,
+                    help="1-GPU rehearsal of the multi-GPU path: 1 = faces exchanged with self by D2D copies, 2 = through a one-rank RCCL communicator")
     return ap.parse_args()
 
 
@@ -93,6 +96,11 @@ def cpu_baseline(args, T, L, gauge, src, gpu_out):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: RCCL prints a version banner to fd 1 when a communicator is
+    # created, so everything before the final print goes to stderr.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -115,13 +123,18 @@ def main():
     nproc_t = world
     V = T * L ** 3
     lat = Lattice(T, L, L, L, kappa=0.125, mu=0.01, nproc_t=nproc_t, proc_t=rank, device=local_rank)
-    if nproc_t > 1:
+    if use_dist:
         # RCCL ring along T for the half-spinor faces: unique id from rank 0, broadcast by the host program
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid.copy_(torch.tensor(list(lat.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
-        lat.comm_init(bytes(uid.cpu().tolist()))
+        lat.comm_init(bytes(uid.cpu().tolist()))       # no-op for a single rank
+    if args.loopback and world == 1:
+        lat.set_loopback(args.loopback)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        lat.set_option(k, int(v))
     gauge = syn.gauge_field(7, T, L, L, L, nproc_t, rank)
     lat.set_gauge(gauge)
     src = syn.spinor_field_eo(8, 0, T, L, L, L, nproc_t, rank)
@@ -182,7 +195,9 @@ def main():
                                    "global %dx%d^3, fp64, kappa=0.125, periodic, random SU(3) gauge + Gaussian spinor"
                                    % (T, L, T * world, L),
                        "local_lattice": [T, L, L, L], "global_lattice": [T * world, L, L, L],
-                       "parallelism": "T-split ring of %d, half-spinor faces over RCCL" % world if world > 1 else "single GPU"},
+                       "parallelism": ("T-split ring of %d, half-spinor faces over RCCL" % world if world > 1 else
+                                       ("single GPU, split-phase path rehearsed with self-exchange (loopback %d)" % args.loopback
+                                        if args.loopback else "single GPU"))},
             "lattice_updates_per_s": args.steps / dt, "us_per_site": sdt,
             "cg": {"iters_per_s": args.cg_iters / cg_dt, "iters": args.cg_iters, "operator": "Qtm_pm_psi", "N": "VOLUME/2",
                    "ms_per_iter": 1e3 * cg_dt / args.cg_iters},
@@ -198,7 +213,10 @@ def main():
                 out["gpu_over_cpu"] = mflops / cb["value"]
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "Mflop/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     lat.close()
     if use_dist:
         dist.destroy_process_group()

@@ -72,8 +72,8 @@ def test_fused_epilogues(setup16, ieo):
         f.free()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_loopback_split_path_matches(setup16, mode):
+@pytest.mark.parametrize("mode,flagsync", [(1, 1), (2, 1), (1, 0)])
+def test_loopback_split_path_matches(setup16, mode, flagsync):
     """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self,
     consumed by the boundary kernels -- must equal the plain periodic stencil."""
     orc, lat = setup16
@@ -81,12 +81,15 @@ def test_loopback_split_path_matches(setup16, mode):
     k = random_spinor(31, N)
     ref = orc.new_field()
     dk, dl = lat.field(k), lat.field()
+    lat.set_option("flagsync", flagsync)  # cross-stream ordering by device flags (default) or HIP events
     lat.set_loopback(mode)  # 1: D2D copies, 2: one-rank RCCL communicator (ncclSend/Recv to self)
     try:
         for ieo in (0, 1):
             orc.Hopping_Matrix(ieo, ref, k)
             lat.Hopping_Matrix(ieo, dl, dk)
             assert rel_err(dl.download(), ref[:N]) < TOL
+        lat.sync()  # also checks the bounded-spin error word
     finally:
         lat.set_loopback(0)
+        lat.set_option("flagsync", 1)
     dk.free(); dl.free()

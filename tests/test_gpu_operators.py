@@ -178,8 +178,12 @@ def test_linearity_and_hermiticity_at_scale():
     lat.close()
 
 
-def test_cg_her_matches_oracle(setup):
+@pytest.mark.parametrize("cg_sync,batch", [(0, 4), (0, 1), (0, 7), (1, 1)])
+def test_cg_her_matches_oracle(setup, cg_sync, batch):
+    """cg_sync=1: reference loop with host round trips; cg_sync=0: scalars and stopping test on the device,
+    host polls the done flag every `batch` iterations -- iteration count and solution must not depend on it."""
     orc, lat = setup
+    lat.set_option("cg_sync", cg_sync); lat.set_option("cg_batch", batch)
     N = orc.Vh
     q = random_spinor(13, N)
     P = orc.new_field()
@@ -196,6 +200,8 @@ def test_cg_her_matches_oracle(setup):
     orc.op("Qtm_pm_psi", chk, full)
     res = ((chk[:N] - q) ** 2).sum() / (q ** 2).sum()
     assert res <= 4e-20
+    assert len(hist) == it
+    lat.set_option("cg_sync", 0); lat.set_option("cg_batch", 4)
     dq.free(); dp.free()
 
 

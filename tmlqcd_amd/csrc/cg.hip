@@ -1,0 +1,232 @@
+// cg_her (solver/cg_her.c:62-141) kept entirely in HBM.
+//
+// The reference's loop needs three scalars per iteration on the host (pro, err, and the stopping
+// test).  Here alpha, beta, normsq and the stopping test live in a small device-side state block that
+// the reduction epilogues update, and every field update reads its coefficient from there, so the
+// host only enqueues kernels.  Exactness is preserved by a device-side `done` flag: once the test of
+// cg_her.c:108 fires, all later updates of P / sf0 / sf2 are skipped, so P and the iteration count
+// are those of the sequential algorithm even though the host polls `done` only every few iterations.
+#include "tmhip_internal.h"
+
+struct CgState {
+  double normsq, pro, err, alpha, beta, squarenorm, eps_sq;
+  int rel_prec, done, iters, it;
+};
+
+__device__ __forceinline__ double cg_wave_reduce(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ void cg_block_reduce_store(double v, double *partials) {
+  __shared__ double wsum[LA_BS / 64];
+  v = cg_wave_reduce(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wsum[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < LA_BS / 64; k++) s += wsum[k];
+    partials[blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// pro = <sf2, sf0>   (cg_her.c:93)
+__global__ __launch_bounds__(LA_BS) void cg_dot_kernel(const v2d *__restrict__ S, const v2d *__restrict__ R, int ns, int N,
+                                                       double *partials, const CgState *st) {
+  if (st->done) return;
+  const v2d *s = S + (size_t)blockIdx.y * ns, *r = R + (size_t)blockIdx.y * ns;
+  double acc = 0.0;
+  const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < LA_UNROLL; u++) {
+    const int i = base + u * LA_BS;
+    if (i < N) { const v2d a = s[i], b = r[i]; acc += a.x * b.x + a.y * b.y; }
+  }
+  cg_block_reduce_store(acc, partials);
+}
+
+// P += alpha sf2 ; sf0 = -alpha sf0 + sf1 ; partial |sf0|^2   (cg_her.c:95,101 fused: same bytes, one launch)
+__global__ __launch_bounds__(LA_BS) void cg_update_kernel(v2d *__restrict__ P, const v2d *__restrict__ SF2, v2d *__restrict__ SF0,
+                                                          const v2d *__restrict__ SF1, int ns, int N, double *partials,
+                                                          const CgState *st) {
+  if (st->done) return;
+  const double alpha = st->alpha;
+  const size_t off = (size_t)blockIdx.y * ns;
+  v2d *p = P + off, *r0 = SF0 + off;
+  const v2d *s2 = SF2 + off, *r1 = SF1 + off;
+  double acc = 0.0;
+  const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < LA_UNROLL; u++) {
+    const int i = base + u * LA_BS;
+    if (i < N) {
+      const v2d a = p[i], b = s2[i];
+      p[i] = v2d{a.x + alpha * b.x, a.y + alpha * b.y};
+      v2d c = r0[i];
+      const v2d d = r1[i];
+      c = v2d{-alpha * c.x + d.x, -alpha * c.y + d.y};
+      r0[i] = c;
+      acc += c.x * c.x + c.y * c.y;
+    }
+  }
+  cg_block_reduce_store(acc, partials);
+}
+
+// sf2 = beta sf2 + sf0   (cg_her.c:122)
+__global__ __launch_bounds__(LA_BS) void cg_xpay_kernel(v2d *__restrict__ SF2, const v2d *__restrict__ SF0, int ns, int N,
+                                                        const CgState *st) {
+  if (st->done) return;
+  const double beta = st->beta;
+  v2d *x = SF2 + (size_t)blockIdx.y * ns;
+  const v2d *y = SF0 + (size_t)blockIdx.y * ns;
+  const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < LA_UNROLL; u++) {
+    const int i = base + u * LA_BS;
+    if (i < N) { const v2d a = x[i], b = y[i]; x[i] = v2d{beta * a.x + b.x, beta * a.y + b.y}; }
+  }
+}
+
+// fixed-order sum of the per-block partials into *out (same scheme as linalg.hip)
+__global__ __launch_bounds__(256) void cg_sum_kernel(const double *__restrict__ partials, int n, double *out, const CgState *st) {
+  if (st->done) return;
+  __shared__ double sm[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sm[0];
+}
+
+// WHICH 0: after the dot  -> alpha = normsq / pro            (cg_her.c:93-94)
+// WHICH 1: after |sf0|^2  -> stopping test, beta, normsq      (cg_her.c:101-126)
+template <int WHICH>
+__global__ void cg_scalar_kernel(CgState *st, const double *sum, double *hist, int hist_len) {
+  if (st->done) return;
+  if (WHICH == 0) {
+    st->pro = *sum;
+    st->alpha = st->normsq / st->pro;
+  } else {
+    const double err = *sum;
+    st->err = err;
+    st->it += 1;
+    if (hist && st->it - 1 < hist_len) hist[st->it - 1] = err;
+    const bool conv = ((err <= st->eps_sq) && (st->rel_prec == 0)) || ((err <= st->eps_sq * st->squarenorm) && (st->rel_prec == 1));
+    if (conv) { st->done = 1; st->iters = st->it; }
+    else { st->beta = err / st->normsq; st->normsq = err; }
+  }
+}
+
+int tmhip_apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k) {
+  switch (op) {
+    case TMHIP_OP_QTM_PM: return tmhip_Qtm_pm_psi(ctx, l, k);
+    case TMHIP_OP_QTM_PLUS: return tmhip_Qtm_plus_psi(ctx, l, k);
+    case TMHIP_OP_QTM_MINUS: return tmhip_Qtm_minus_psi(ctx, l, k);
+    case TMHIP_OP_MTM_PLUS: return tmhip_Mtm_plus_psi(ctx, l, k);
+    case TMHIP_OP_MTM_MINUS: return tmhip_Mtm_minus_psi(ctx, l, k);
+  }
+  fprintf(stderr, "[tmlqcd_hip] cg_her: unknown operator id %d\n", op);
+  return 1;
+}
+
+// straightforward port of the reference loop: three host round trips per iteration (kept for A/B: option cg_sync=1)
+static int cg_her_sync(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N, int op,
+                       int *iters, double *res_hist, int hist_len) {
+  tmhip_field *sf0 = ctx->sf[0], *sf1 = ctx->sf[1], *sf2 = ctx->sf[2], *stmp;
+  double normsq, pro, err = 0, alpha_cg, beta_cg, squarenorm;
+  int iteration;
+  if (tmhip_square_norm(ctx, Q, N, 1, &squarenorm)) return 1;
+  if (tmhip_apply_op(ctx, op, sf0, P)) return 1;
+  if (tmhip_diff(ctx, sf1, Q, sf0, N)) return 1;
+  if (tmhip_assign(ctx, sf2, sf1, N)) return 1;
+  if (tmhip_square_norm(ctx, sf1, N, 1, &normsq)) return 1;
+  for (iteration = 1; iteration <= max_iter; iteration++) {
+    if (tmhip_apply_op(ctx, op, sf0, sf2)) return 1;
+    if (tmhip_scalar_prod_r(ctx, sf2, sf0, N, 1, &pro)) return 1;
+    alpha_cg = normsq / pro;
+    if (tmhip_assign_add_mul_r(ctx, P, sf2, alpha_cg, N)) return 1;
+    if (tmhip_assign_mul_add_r_and_square(ctx, sf0, -alpha_cg, sf1, N, 1, &err)) return 1;
+    if (res_hist && iteration - 1 < hist_len) res_hist[iteration - 1] = err;
+    if (((err <= eps_sq) && (rel_prec == 0)) || ((err <= eps_sq * squarenorm) && (rel_prec == 1))) break;
+    beta_cg = err / normsq;
+    if (tmhip_assign_mul_add_r(ctx, sf2, beta_cg, sf0, N)) return 1;
+    stmp = sf0; sf0 = sf1; sf1 = stmp;
+    normsq = err;
+  }
+  *iters = iteration > max_iter ? -1 : iteration;
+  return 0;
+}
+
+static int cg_allreduce(tmhip_ctx *ctx, double *x) {
+  if (ctx->comm_ready && ctx->g.nproc_t > 1)
+    TMHIP_NCCL_CHECK(ncclAllReduce(x, x, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+  return 0;
+}
+
+extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N,
+                            int op, int *iters, double *res_hist, int hist_len) {
+  if (!P || !Q || P->kind != TMHIP_FIELD_EO || Q->kind != TMHIP_FIELD_EO) TMHIP_FAIL("cg_her needs one-parity (EO) fields");
+  if (N != ctx->Vh) TMHIP_FAIL("cg_her: N must be VOLUME/2");
+  if (ctx->opt_cg_sync) return cg_her_sync(ctx, P, Q, max_iter, eps_sq, rel_prec, N, op, iters, res_hist, hist_len);
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  if (!ctx->cg_state) TMHIP_CHECK(hipMalloc(&ctx->cg_state, sizeof(CgState)));
+  if (max_iter > ctx->cg_hist_len) {
+    if (ctx->cg_hist) TMHIP_CHECK(hipFree(ctx->cg_hist));
+    TMHIP_CHECK(hipMalloc((void **)&ctx->cg_hist, sizeof(double) * (size_t)max_iter));
+    ctx->cg_hist_len = max_iter;
+  }
+  CgState *st = (CgState *)ctx->cg_state;
+  tmhip_field *sf0 = ctx->sf[0], *sf1 = ctx->sf[1], *sf2 = ctx->sf[2], *stmp;
+  // initial residual (cg_her.c:82-88): once per solve, host-visible scalars are fine here
+  CgState h;
+  memset(&h, 0, sizeof(h));
+  if (tmhip_square_norm(ctx, Q, N, 1, &h.squarenorm)) return 1;
+  if (tmhip_apply_op(ctx, op, sf0, P)) return 1;
+  if (tmhip_diff(ctx, sf1, Q, sf0, N)) return 1;
+  if (tmhip_assign(ctx, sf2, sf1, N)) return 1;
+  if (tmhip_square_norm(ctx, sf1, N, 1, &h.normsq)) return 1;
+  h.eps_sq = eps_sq; h.rel_prec = rel_prec;
+  TMHIP_CHECK(hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+  const dim3 g = la_grid(N);
+  const int nblk = g.x * g.y;
+  double *sum = ctx->result_dev + 1;
+  const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
+  int enq = 0, done = 0;
+  int *flag = (int *)(ctx->result_host + 2);
+  while (enq < max_iter && !done) {
+    const int nb = (max_iter - enq) < batch ? (max_iter - enq) : batch;
+    for (int b = 0; b < nb; b++) {
+      if (tmhip_apply_op(ctx, op, sf0, sf2)) return 1;
+      hipLaunchKernelGGL(cg_dot_kernel, g, dim3(LA_BS), 0, ctx->stream, sf2->d, sf0->d, sf2->ns, N, ctx->partials, st);
+      hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblk, sum, st);
+      if (cg_allreduce(ctx, sum)) return 1;
+      hipLaunchKernelGGL(cg_scalar_kernel<0>, dim3(1), dim3(1), 0, ctx->stream, st, sum, ctx->cg_hist, max_iter);
+      hipLaunchKernelGGL(cg_update_kernel, g, dim3(LA_BS), 0, ctx->stream, P->d, sf2->d, sf0->d, sf1->d, P->ns, N, ctx->partials, st);
+      hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblk, sum, st);
+      if (cg_allreduce(ctx, sum)) return 1;
+      hipLaunchKernelGGL(cg_scalar_kernel<1>, dim3(1), dim3(1), 0, ctx->stream, st, sum, ctx->cg_hist, max_iter);
+      hipLaunchKernelGGL(cg_xpay_kernel, g, dim3(LA_BS), 0, ctx->stream, sf2->d, sf0->d, sf2->ns, N, st);
+      stmp = sf0; sf0 = sf1; sf1 = stmp;
+    }
+    enq += nb;
+    TMHIP_CHECK(hipGetLastError());
+    TMHIP_CHECK(hipMemcpyAsync(flag, &st->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    done = *flag;
+  }
+  TMHIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *iters = h.done ? h.iters : -1;
+  if (res_hist && hist_len > 0) {
+    const int n = h.it < hist_len ? h.it : hist_len;
+    if (n > 0) TMHIP_CHECK(hipMemcpy(res_hist, ctx->cg_hist, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}

@@ -128,9 +128,13 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->V = g.T * g.LX * g.LY * g.LZ; ctx->Vh = ctx->V / 2; ctx->face = g.LX * g.LY * g.LZ / 2;
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
-  ctx->opt_block = 256; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_variant = 0;
+  ctx->opt_block = 256; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_variant = 0; ctx->opt_cg_sync = 0; ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
+    int lo = 0, hi = 0;
+    TMHIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    TMHIP_CHECK(hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, hi));
+  }
   TMHIP_CHECK(hipEventCreateWithFlags(&ctx->ev_pack, hipEventDisableTiming));
   TMHIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
   for (int i = 0; i < 16; i++) TMHIP_CHECK(hipEventCreate(&ctx->ev_slots[i]));
@@ -144,6 +148,8 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   TMHIP_CHECK(hipMalloc((void **)&ctx->send_dn, fb));
   TMHIP_CHECK(hipMalloc((void **)&ctx->recv_up, fb));
   TMHIP_CHECK(hipMalloc((void **)&ctx->recv_dn, fb));
+  TMHIP_CHECK(hipMalloc((void **)&ctx->sync_flags, 64));
+  TMHIP_CHECK(hipMemsetAsync(ctx->sync_flags, 0, 64, ctx->stream));
   TMHIP_CHECK(hipMemsetAsync(ctx->recv_up, 0, fb, ctx->stream));
   TMHIP_CHECK(hipMemsetAsync(ctx->recv_dn, 0, fb, ctx->stream));
   for (int i = 0; i < 3; i++) {
@@ -166,8 +172,11 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->comm_ready) ncclCommDestroy(ctx->comm);
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
+  (void)hipFree(ctx->sync_flags);
   (void)hipFree(ctx->send_up); (void)hipFree(ctx->send_dn); (void)hipFree(ctx->recv_up); (void)hipFree(ctx->recv_dn);
   if (ctx->stage) (void)hipFree(ctx->stage);
+  if (ctx->cg_state) (void)hipFree(ctx->cg_state);
+  if (ctx->cg_hist) (void)hipFree(ctx->cg_hist);
   (void)hipEventDestroy(ctx->ev_pack); (void)hipEventDestroy(ctx->ev_comm);
   for (int i = 0; i < 16; i++) (void)hipEventDestroy(ctx->ev_slots[i]);
   (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->comm_stream);
@@ -177,6 +186,11 @@ void tmhip_destroy(tmhip_ctx *ctx) {
 int tmhip_sync(tmhip_ctx *ctx) {
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->comm_stream));
+  if (ctx->hop_seq) {  // a bounded cross-stream spin gave up (hopping.hip flag_wait_kernel)
+    unsigned int err = 0;
+    TMHIP_CHECK(hipMemcpy(&err, ctx->sync_flags + 2, sizeof(err), hipMemcpyDeviceToHost));
+    if (err) TMHIP_FAIL("cross-stream flag wait timed out: halo exchange did not complete");
+  }
   return 0;
 }
 
@@ -208,6 +222,11 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "xcd")) ctx->opt_xcd = value;
   else if (!strcmp(name, "nt")) ctx->opt_nt = value;
   else if (!strcmp(name, "variant")) ctx->opt_variant = value;
+  else if (!strcmp(name, "tgrp")) ctx->opt_tgrp = value;
+  else if (!strcmp(name, "flagsync")) ctx->opt_flagsync = value;
+  else if (!strcmp(name, "shape")) ctx->opt_shape = value;
+  else if (!strcmp(name, "cg_sync")) ctx->opt_cg_sync = value;
+  else if (!strcmp(name, "cg_batch")) ctx->opt_cg_batch = value > 0 ? value : 1;
   else TMHIP_FAIL("unknown option %s", name);
   return 0;
 }
@@ -375,48 +394,6 @@ int tmhip_M_full(tmhip_ctx *ctx, tmhip_field *En, tmhip_field *On, tmhip_field *
   if (need_eo(En, "M_full") || need_eo(On, "M_full") || need_eo(E, "M_full") || need_eo(O, "M_full")) return 1;
   return tmhip_launch_hopping(ctx, TMHIP_EO, En->d, O->d, E->d, EPI_TM_SUB, 1., ctx->mu, true) ||
          tmhip_launch_hopping(ctx, TMHIP_OE, On->d, E->d, O->d, EPI_TM_SUB, 1., ctx->mu, true);
-}
-
-// ------------------------------------------------------------------ solver
-static int apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k) {
-  switch (op) {
-    case TMHIP_OP_QTM_PM: return tmhip_Qtm_pm_psi(ctx, l, k);
-    case TMHIP_OP_QTM_PLUS: return tmhip_Qtm_plus_psi(ctx, l, k);
-    case TMHIP_OP_QTM_MINUS: return tmhip_Qtm_minus_psi(ctx, l, k);
-    case TMHIP_OP_MTM_PLUS: return tmhip_Mtm_plus_psi(ctx, l, k);
-    case TMHIP_OP_MTM_MINUS: return tmhip_Mtm_minus_psi(ctx, l, k);
-  }
-  fprintf(stderr, "[tmlqcd_hip] cg_her: unknown operator id %d\n", op);
-  return 1;
-}
-
-/* solver/cg_her.c:62-141, same recurrences and stopping rule; all fields stay in HBM */
-int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N, int op,
-                 int *iters, double *res_hist, int hist_len) {
-  if (need_eo(P, "cg_her") || need_eo(Q, "cg_her")) return 1;
-  tmhip_field *sf0 = ctx->sf[0], *sf1 = ctx->sf[1], *sf2 = ctx->sf[2], *stmp;
-  double normsq, pro, err = 0, alpha_cg, beta_cg, squarenorm;
-  int iteration;
-  if (tmhip_square_norm(ctx, Q, N, 1, &squarenorm)) return 1;
-  if (apply_op(ctx, op, sf0, P)) return 1;
-  if (tmhip_diff(ctx, sf1, Q, sf0, N)) return 1;
-  if (tmhip_assign(ctx, sf2, sf1, N)) return 1;
-  if (tmhip_square_norm(ctx, sf1, N, 1, &normsq)) return 1;
-  for (iteration = 1; iteration <= max_iter; iteration++) {
-    if (apply_op(ctx, op, sf0, sf2)) return 1;
-    if (tmhip_scalar_prod_r(ctx, sf2, sf0, N, 1, &pro)) return 1;
-    alpha_cg = normsq / pro;
-    if (tmhip_assign_add_mul_r(ctx, P, sf2, alpha_cg, N)) return 1;
-    if (tmhip_assign_mul_add_r_and_square(ctx, sf0, -alpha_cg, sf1, N, 1, &err)) return 1;
-    if (res_hist && iteration - 1 < hist_len) res_hist[iteration - 1] = err;
-    if (((err <= eps_sq) && (rel_prec == 0)) || ((err <= eps_sq * squarenorm) && (rel_prec == 1))) break;
-    beta_cg = err / normsq;
-    if (tmhip_assign_mul_add_r(ctx, sf2, beta_cg, sf0, N)) return 1;
-    stmp = sf0; sf0 = sf1; sf1 = stmp;
-    normsq = err;
-  }
-  *iters = iteration > max_iter ? -1 : iteration;
-  return 0;
 }
 
 // ------------------------------------------------------------------ halo exchange

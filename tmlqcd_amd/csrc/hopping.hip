@@ -33,6 +33,8 @@ struct HopArgs {
   int nxcd_chunk;  // >0: XCD-aware block remap, blocks per XCD chunk
   int map_tc;      // >0: within an XCD chunk walk t fastest over map_tc time-slices (tile order)
   int map_bpt;     // blocks per time-slice (face / BS) for the tile order
+  int map_nb;      // real number of blocks of this launch (the grid is padded to a multiple of 8)
+  int shape_bx, shape_by;  // >1: a block covers shape_bx x-planes x shape_by y-rows x all k (instead of BS consecutive sites)
   double ka[4][2];
   double cre, cim;
 };
@@ -129,6 +131,7 @@ __device__ __forceinline__ void hop_dir(v2d (&acc)[12], const v2d *__restrict__ 
 // TFACE: 0 = t-neighbours are local (interior, or unsplit lattice with periodic wrap)
 //        1 = sites of the t=0 slab:   -t half-spinors come from halo_dn
 //        2 = sites of the t=T-1 slab: +t half-spinors come from halo_up
+//        3 = both slabs in one launch (block-uniform choice between 1 and 2)
 template <int EPI, int TFACE, bool NTIO, int BS, int MINW>
 __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
   constexpr bool NT = true;  // gauge links: used once per call -> non-temporal (measured 0.19 -> 0.16 ms at 32^4)
@@ -138,16 +141,39 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
     // contiguous chunk of the lattice so neighbouring tiles hit the same L2.
     const int xcd = bid & 7;
     int q = bid >> 3;
-    if (a.map_tc > 0) {
-      // tile order inside the chunk: the same spatial tile at t, t+1, .. is dispatched
-      // back to back, so the +-t (and +-x) users of an input line run close in time.
-      const int tl = q % a.map_tc, sp = q / a.map_tc;
-      q = tl * a.map_bpt + sp;
-    }
     bid = xcd * a.nxcd_chunk + q;
+    if (bid >= a.map_nb) return;
+    if (a.map_tc > 0) {
+      // tile order: time-slices are taken in groups of map_tc; inside a group the same spatial
+      // tile at t, t+1, .. is dispatched back to back, so the +-t (and +-x) users of an input
+      // line run close in time on the same XCD.
+      const int per_group = a.map_tc * a.map_bpt;
+      const int g = bid / per_group, rem = bid - g * per_group;
+      const int sp = rem / a.map_tc, tl = rem - sp * a.map_tc;
+      bid = (g * a.map_tc + tl) * a.map_bpt + sp;
+    }
   }
-  const int i = a.i_begin + bid * BS + threadIdx.x;
-  if (i >= a.i_end) return;
+  int i = a.i_begin + bid * BS + threadIdx.x;
+  if (TFACE == 0 && a.shape_bx > 1) {
+    // compact block shape: fewer neighbour rows fall outside the block's own footprint
+    const int tt = bid / a.map_bpt, sp = bid - tt * a.map_bpt;
+    const int nyb = a.LY / a.shape_by;
+    const int xb = sp / nyb, yb = sp - xb * nyb;
+    const int rr = threadIdx.x / a.LZh, kk = threadIdx.x - rr * a.LZh;
+    const int dx = rr / a.shape_by, dy = rr - dx * a.shape_by;
+    i = ((tt * a.LX + xb * a.shape_bx + dx) * a.LY + yb * a.shape_by + dy) * a.LZh + kk;
+  }
+  int tf = TFACE;
+  if (TFACE == 3) {
+    // both t-faces in one launch: blocks [0, map_bpt) walk the t=0 slab, [map_bpt, 2 map_bpt) the t=T-1 slab
+    const int second = bid >= a.map_bpt;
+    const int jl = (bid - (second ? a.map_bpt : 0)) * BS + threadIdx.x;
+    if (jl >= a.face) return;
+    tf = second ? 2 : 1;
+    i = second ? a.Vh - a.face + jl : jl;
+  } else if (i >= a.i_end) {
+    return;
+  }
 
   const int LZh = a.LZh;
   const int k = i % LZh;
@@ -178,10 +204,10 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
   const v2d *__restrict__ in = a.in;
   const v2d *__restrict__ g = a.gauge;
 
-  if (TFACE == 2) hop_dir<0, true, NT>(acc, in, a.ns, jf, a.halo_up, a.face, g, a.gs, i, ka0);
-  else            hop_dir<0, false, NT>(acc, in, a.ns, jtp, nullptr, 0, g, a.gs, i, ka0);
-  if (TFACE == 1) hop_dir<1, true, NT>(acc, in, a.ns, jf, a.halo_dn, a.face, g, a.gs, i, ka0);
-  else            hop_dir<1, false, NT>(acc, in, a.ns, jtm, nullptr, 0, g, a.gs, i, ka0);
+  if (TFACE != 0 && tf == 2) hop_dir<0, true, NT>(acc, in, a.ns, jf, a.halo_up, a.face, g, a.gs, i, ka0);
+  else                       hop_dir<0, false, NT>(acc, in, a.ns, jtp, nullptr, 0, g, a.gs, i, ka0);
+  if (TFACE != 0 && tf == 1) hop_dir<1, true, NT>(acc, in, a.ns, jf, a.halo_dn, a.face, g, a.gs, i, ka0);
+  else                       hop_dir<1, false, NT>(acc, in, a.ns, jtm, nullptr, 0, g, a.gs, i, ka0);
   hop_dir<2, false, NT>(acc, in, a.ns, jxp, nullptr, 0, g, a.gs, i, ka1);
   hop_dir<3, false, NT>(acc, in, a.ns, jxm, nullptr, 0, g, a.gs, i, ka1);
   hop_dir<4, false, NT>(acc, in, a.ns, jyp, nullptr, 0, g, a.gs, i, ka2);
@@ -212,6 +238,26 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
   }
 }
 
+// Cross-stream ordering without HIP events: a one-thread kernel publishes a sequence number, a
+// one-thread kernel on the other stream waits for it.  Data hand-off itself still happens at kernel
+// boundaries (producer kernel complete before the flag kernel runs; consumer kernel starts after the
+// wait kernel), so only the flag word needs agent-scope atomics.  The spin is bounded: on timeout an
+// error word is set (checked by tmhip_sync) and the wave exits.
+__global__ void flag_set_kernel(unsigned int *flag, unsigned int seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void flag_wait_kernel(const unsigned int *flag, unsigned int seq, unsigned int *err) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {  // 3 s
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // Project the two t-faces of the input field to half-spinors for the neighbours
 // (what xchange_halffield ships, xchange/xchange_halffield.c:199-255; projections of
 // operator/halfspinor_hopping.h:1279-1293):
@@ -233,7 +279,7 @@ __global__ __launch_bounds__(256) void pack_faces_kernel(const v2d *__restrict__
   }
 }
 
-struct HopLaunch { int block; bool ntio; int minw; int xcd; int occ; };
+struct HopLaunch { int block; bool ntio; int minw; int xcd; int occ; int tgrp; int shape; };
 
 template <int EPI, int TFACE, bool NTIO, int BS, int MINW>
 static void launch_one(const HopArgs &a, hipStream_t st, const HopLaunch &o, bool allow_map) {
@@ -241,14 +287,22 @@ static void launch_one(const HopArgs &a, hipStream_t st, const HopLaunch &o, boo
   if (n <= 0) return;
   int nb = (n + BS - 1) / BS;
   HopArgs b = a;
-  b.nxcd_chunk = 0; b.map_tc = 0; b.map_bpt = 0;
+  b.nxcd_chunk = 0; b.map_tc = 0; b.map_bpt = 0; b.map_nb = nb; b.shape_bx = 0; b.shape_by = 0;
   if (allow_map && o.xcd && nb >= 64) {
     const int chunk = (nb + 7) / 8;
     b.nxcd_chunk = chunk;
-    // tile order needs whole time-slices per block row: T % 8 == 0 and face % BS == 0
-    if (o.xcd >= 2 && a.i_begin == 0 && n == a.Vh && a.T % 8 == 0 && a.face % BS == 0) {
-      b.map_tc = a.T / 8;
-      b.map_bpt = a.face / BS;
+    // tile order needs whole time-slices in whole blocks: range = k time-slices, face % BS == 0
+    if (o.xcd >= 2 && a.face % BS == 0 && a.i_begin % a.face == 0 && n % a.face == 0) {
+      const int nt = n / a.face;  // time-slices in this launch (T, or T-2 for the interior of a split lattice)
+      int grp = 0;
+      for (int cand : {4, 5, 6, 3, 2}) if (nt % cand == 0) { grp = cand; break; }
+      if (o.tgrp > 0 && nt % o.tgrp == 0) grp = o.tgrp;
+      if (grp) { b.map_tc = grp; b.map_bpt = a.face / BS; }
+      // optional compact block shape (bx x-planes x by y-rows x LZ/2): needs the full lattice and exact tiling
+      if (grp && o.shape > 1 && a.i_begin == 0 && n == a.Vh && BS % (a.LZh * o.shape) == 0) {
+        const int by = BS / (a.LZh * o.shape);
+        if (by >= 1 && a.LX % o.shape == 0 && a.LY % by == 0) { b.shape_bx = o.shape; b.shape_by = by; }
+      }
     }
     nb = chunk * 8;  // blocks past i_end exit immediately
   }
@@ -293,7 +347,7 @@ static void fill_args(HopArgs &a, tmhip_ctx *ctx, int ieo, v2d *out, const v2d *
   a.T = ctx->g.T; a.LX = ctx->g.LX; a.LY = ctx->g.LY; a.LZh = ctx->g.LZ / 2;
   a.Vh = ctx->Vh; a.face = ctx->face; a.YZh = ctx->g.LY * ctx->g.LZ / 2;
   a.par_off = (ctx->g.proc_t * ctx->g.T + ieo) & 1;
-  a.nxcd_chunk = 0; a.map_tc = 0; a.map_bpt = 0;
+  a.nxcd_chunk = 0; a.map_tc = 0; a.map_bpt = 0; a.map_nb = 0; a.shape_bx = 0; a.shape_by = 0;
   for (int m = 0; m < 4; m++) { a.ka[m][0] = ctx->ka[m][0]; a.ka[m][1] = ctx->ka[m][1]; }
   a.cre = cre; a.cim = cim;
 }
@@ -308,11 +362,24 @@ static void launch_interior(tmhip_ctx *ctx, HopArgs &a, int epi, const HopLaunch
   launch_epi<0>(a, epi, ctx->stream, o, true);
 }
 
-static void launch_boundary(tmhip_ctx *ctx, HopArgs &a, int epi, const HopLaunch &o) {
-  a.i_begin = 0; a.i_end = ctx->face;
-  launch_epi<1>(a, epi, ctx->stream, o, false);
-  a.i_begin = ctx->Vh - ctx->face; a.i_end = ctx->Vh;
-  launch_epi<2>(a, epi, ctx->stream, o, false);
+static void launch_boundary(tmhip_ctx *ctx, HopArgs &a, int epi, const HopLaunch &o, hipStream_t st) {
+  // one launch for both faces, 64-thread blocks: 2*face/64 small blocks spread over the whole chip and
+  // interleave with the interior kernel's blocks instead of forming two serial latency-bound launches
+  HopArgs b = a;
+  b.i_begin = 0; b.i_end = ctx->Vh;
+  b.nxcd_chunk = 0; b.map_tc = 0; b.shape_bx = 0;
+  b.map_bpt = (ctx->face + 63) / 64;
+  b.map_nb = 2 * b.map_bpt;
+  const dim3 grid(b.map_nb), blk(64);
+#define TMHIP_B(EPI) if (o.ntio) hipLaunchKernelGGL((hop_kernel<EPI, 3, true, 64, 1>), grid, blk, 0, st, b); \
+                     else hipLaunchKernelGGL((hop_kernel<EPI, 3, false, 64, 1>), grid, blk, 0, st, b)
+  switch (epi) {
+    case EPI_STORE: TMHIP_B(EPI_STORE); break;
+    case EPI_TM_TIMES: TMHIP_B(EPI_TM_TIMES); break;
+    case EPI_TM_SUB_G5: TMHIP_B(EPI_TM_SUB_G5); break;
+    default: TMHIP_B(EPI_TM_SUB); break;
+  }
+#undef TMHIP_B
 }
 
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
@@ -321,23 +388,40 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
   if (out == in) TMHIP_FAIL("Hopping_Matrix: l and k must differ (operator/D_psi_body.c:267-272 convention)");
   HopArgs a;
   fill_args(a, ctx, ieo, out, in, p, cre, cim);
-  const HopLaunch o = {ctx->opt_block, ctx->opt_nt != 0, ctx->opt_minw, ctx->opt_xcd, ctx->opt_occ};
+  const HopLaunch o = {ctx->opt_block, ctx->opt_nt != 0, ctx->opt_minw, ctx->opt_xcd, ctx->opt_occ, ctx->opt_tgrp, ctx->opt_shape};
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
   if (!split) {
     a.i_begin = 0; a.i_end = ctx->Vh;
     launch_epi<0>(a, epi, ctx->stream, o, true);
+  } else if (!comm) {
+    launch_interior(ctx, a, epi, o);
+    launch_boundary(ctx, a, epi, o, ctx->stream);
   } else {
-    if (comm) {
-      // split-phase: pack faces -> exchange on comm stream || interior kernel -> boundary kernels
-      launch_pack(ctx, in);
+    // Split-phase with the whole boundary pipeline on the second stream:
+    //   comm stream : pack faces -> exchange (RCCL / copies) -> the two boundary kernels
+    //   main stream : interior kernel (t in [1, T-2]), which needs no remote data
+    // The GPU co-schedules the 2 x face/BS boundary blocks with the interior blocks, so pack,
+    // exchange and boundary work hide behind the interior kernel (the reference's analogue is the
+    // tsplit variant, operator/hopping_sse_dbl.c:79-161).
+    const bool flags = ctx->opt_flagsync != 0;
+    const unsigned int seq = ++ctx->hop_seq;
+    if (flags) {  // `in` (and `p`) are ready, `out` is free
+      hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->sync_flags + 0, seq);
+      hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(1), 0, ctx->comm_stream, ctx->sync_flags + 0, seq, ctx->sync_flags + 2);
+    } else {
       TMHIP_CHECK(hipEventRecord(ctx->ev_pack, ctx->stream));
       TMHIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_pack, 0));
-      if (tmhip_halo_exchange(ctx)) return 1;
-      TMHIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
     }
+    hipLaunchKernelGGL(pack_faces_kernel, dim3((ctx->face + 255) / 256, 2), dim3(256), 0, ctx->comm_stream,
+                       in, ctx->ns, ctx->Vh, ctx->face, ctx->send_dn, ctx->send_up);
+    if (tmhip_halo_exchange(ctx)) return 1;
+    HopArgs b = a;
+    launch_boundary(ctx, b, epi, o, ctx->comm_stream);
+    if (flags) hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, ctx->comm_stream, ctx->sync_flags + 1, seq);
+    else TMHIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
     launch_interior(ctx, a, epi, o);
-    if (comm) TMHIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_comm, 0));
-    launch_boundary(ctx, a, epi, o);
+    if (flags) hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->sync_flags + 1, seq, ctx->sync_flags + 2);
+    else TMHIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_comm, 0));
   }
   TMHIP_CHECK(hipGetLastError());
   return 0;
@@ -376,7 +460,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipEventRecord(c->ev_comm, c->comm_stream));
     HopArgs a;
     fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ};
+    const HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape};
     launch_interior(c, a, EPI_STORE, o);
   }
   for (int r = 0; r < n; r++) {
@@ -385,8 +469,8 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     HopArgs a;
     fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ};
-    launch_boundary(c, a, EPI_STORE, o);
+    const HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape};
+    launch_boundary(c, a, EPI_STORE, o, c->stream);
     TMHIP_CHECK(hipGetLastError());
   }
   return 0;

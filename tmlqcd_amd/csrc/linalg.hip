@@ -13,8 +13,6 @@
 // sequential one, so no compensation is needed to stay within 1e-13 relative.
 #include "tmhip_internal.h"
 
-#define LA_BS 256
-#define LA_UNROLL 4
 
 __device__ __forceinline__ double wave_reduce(double v) {
 #pragma unroll
@@ -141,7 +139,6 @@ __global__ __launch_bounds__(LA_BS) void diag_kernel(v2d *L, const v2d *K, const
   }
 }
 
-static inline dim3 la_grid(int N) { return dim3((N + LA_BS * LA_UNROLL - 1) / (LA_BS * LA_UNROLL), 12); }
 
 static int check_eo(const tmhip_field *f, const char *who) {
   if (!f || f->kind != TMHIP_FIELD_EO) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity (EO) field\n", who); return 1; }

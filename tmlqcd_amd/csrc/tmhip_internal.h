@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include "../../include/tmlqcd_hip.h"
 
 typedef double v2d __attribute__((ext_vector_type(2)));  // one complex double: .x = re, .y = im
@@ -72,8 +73,11 @@ struct tmhip_ctx {
   // halo exchange
   ncclComm_t comm; bool comm_ready; bool loopback; bool loopback_rccl;
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
+  unsigned int *sync_flags; unsigned int hop_seq;  // [0] in-ready, [1] boundary-done, [2] timeout error
+  // device-resident CG state (cg.hip)
+  void *cg_state; double *cg_hist; int cg_hist_len;
   // options
-  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_variant;
+  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_variant; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync;
 };
 
 // ---- launch helpers implemented across the .hip files ----
@@ -83,3 +87,8 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
 int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out);
 int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes);
 int tmhip_halo_exchange(tmhip_ctx *ctx);
+int tmhip_apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k);
+// launch geometry shared by linalg.hip and cg.hip
+#define LA_BS 256
+#define LA_UNROLL 4
+static inline dim3 la_grid(int N) { return dim3((N + LA_BS * LA_UNROLL - 1) / (LA_BS * LA_UNROLL), 12); }
