@@ -198,14 +198,26 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
   const int nblk = g.x * g.y;
   double *sum = ctx->result_dev + 1;
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
+  const bool fused = ctx->opt_cg_fused_dot && op == TMHIP_OP_QTM_PM && ctx->g.nproc_t == 1 && !ctx->loopback && ctx->opt_block == 256;
   int enq = 0, done = 0;
   int *flag = (int *)(ctx->result_host + 2);
   while (enq < max_iter && !done) {
     const int nb = (max_iter - enq) < batch ? (max_iter - enq) : batch;
     for (int b = 0; b < nb; b++) {
-      if (tmhip_apply_op(ctx, op, sf0, sf2)) return 1;
-      hipLaunchKernelGGL(cg_dot_kernel, g, dim3(LA_BS), 0, ctx->stream, sf2->d, sf0->d, sf2->ns, N, ctx->partials, st);
-      hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblk, sum, st);
+      int ndot = nblk;
+      if (fused) {
+        // Qtm_pm_psi (tm_operators.c:338-345) with pro = <sf2, Q sf2> accumulated by the last stencil's epilogue
+        const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
+        tmhip_field *s0 = ctx->scratch[0], *s1 = ctx->scratch[1];
+        if (tmhip_launch_hopping(ctx, TMHIP_EO, s1->d, sf2->d, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
+        if (tmhip_launch_hopping(ctx, TMHIP_OE, s0->d, s1->d, sf2->d, EPI_TM_SUB_G5, 1., -mu, true)) return 1;
+        if (tmhip_launch_hopping(ctx, TMHIP_EO, s1->d, s0->d, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true)) return 1;
+        if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, sf0->d, s1->d, s0->d, sf2->d, 1., mu, &ndot)) return 1;
+      } else {
+        if (tmhip_apply_op(ctx, op, sf0, sf2)) return 1;
+        hipLaunchKernelGGL(cg_dot_kernel, g, dim3(LA_BS), 0, ctx->stream, sf2->d, sf0->d, sf2->ns, N, ctx->partials, st);
+      }
+      hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ndot, sum, st);
       if (cg_allreduce(ctx, sum)) return 1;
       hipLaunchKernelGGL(cg_scalar_kernel<0>, dim3(1), dim3(1), 0, ctx->stream, st, sum, ctx->cg_hist, max_iter);
       hipLaunchKernelGGL(cg_update_kernel, g, dim3(LA_BS), 0, ctx->stream, P->d, sf2->d, sf0->d, sf1->d, P->ns, N, ctx->partials, st);

@@ -25,6 +25,8 @@ struct HopArgs {
   const v2d *p;
   const v2d *gauge;  // already offset to the parity of the output sites
   const v2d *halo_up, *halo_dn;
+  const v2d *dotv;   // EPI_TM_SUB_G5_DOT: field whose real scalar product with the output is accumulated
+  double *partials;  // EPI_TM_SUB_G5_DOT: one partial per block
   int ns, gs;
   int T, LX, LY, LZh;
   int Vh, face, YZh;
@@ -142,7 +144,10 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
     const int xcd = bid & 7;
     int q = bid >> 3;
     bid = xcd * a.nxcd_chunk + q;
-    if (bid >= a.map_nb) return;
+    if (bid >= a.map_nb) {
+      if (EPI == EPI_TM_SUB_G5_DOT && threadIdx.x == 0) a.partials[blockIdx.x] = 0.0;
+      return;
+    }
     if (a.map_tc > 0) {
       // tile order: time-slices are taken in groups of map_tc; inside a group the same spatial
       // tile at t, t+1, .. is dispatched back to back, so the +-t (and +-x) users of an input
@@ -172,8 +177,11 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
     tf = second ? 2 : 1;
     i = second ? a.Vh - a.face + jl : jl;
   } else if (i >= a.i_end) {
-    return;
+    if (EPI != EPI_TM_SUB_G5_DOT) return;
+    i = a.i_end - 1;  // fused reduction: every wave of the block must reach the barrier; results of this lane are discarded
+    tf = -1;
   }
+  const bool lane_active = tf >= 0;
 
   const int LZh = a.LZh;
   const int k = i % LZh;
@@ -226,14 +234,39 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
 #pragma unroll
     for (int c = 6; c < 12; c++) stg<NTIO>(out + (size_t)c * a.ns + i, cmulc(cf, acc[c]));
   } else {
-    // EPI_TM_SUB_G5: hopping.h:680-688  l = g5[(cf,cf*) p - H k];  EPI_TM_SUB: same without g5
+    // EPI_TM_SUB_G5[_DOT]: hopping.h:680-688  l = g5[(cf,cf*) p - H k];  EPI_TM_SUB: same without g5
     const v2d *__restrict__ p = a.p;
 #pragma unroll
-    for (int c = 0; c < 6; c++) stg<NTIO>(out + (size_t)c * a.ns + i, cmul(cf, ldg<NTIO>(p + (size_t)c * a.ns + i)) - acc[c]);
+    for (int c = 0; c < 6; c++) {
+      acc[c] = cmul(cf, ldg<NTIO>(p + (size_t)c * a.ns + i)) - acc[c];
+      if (EPI != EPI_TM_SUB_G5_DOT || lane_active) stg<NTIO>(out + (size_t)c * a.ns + i, acc[c]);
+    }
 #pragma unroll
     for (int c = 6; c < 12; c++) {
       const v2d zp = cmulc(cf, ldg<NTIO>(p + (size_t)c * a.ns + i));
-      stg<NTIO>(out + (size_t)c * a.ns + i, (EPI == EPI_TM_SUB_G5) ? acc[c] - zp : zp - acc[c]);
+      acc[c] = (EPI == EPI_TM_SUB) ? zp - acc[c] : acc[c] - zp;
+      if (EPI != EPI_TM_SUB_G5_DOT || lane_active) stg<NTIO>(out + (size_t)c * a.ns + i, acc[c]);
+    }
+    if (EPI == EPI_TM_SUB_G5_DOT) {
+      // fused scalar_prod_r(dotv, out) of cg_her.c:93: saves re-reading `out` (and a launch) per CG iteration
+      double d = 0.0;
+#pragma unroll
+      for (int c = 0; c < 12; c++) {
+        const v2d w = ldg<NTIO>(a.dotv + (size_t)c * a.ns + i);
+        d += w.x * acc[c].x + w.y * acc[c].y;
+      }
+      if (!lane_active) d = 0.0;
+      __shared__ double wsum[BS / 64];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+      if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = d;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < BS / 64; w++) t += wsum[w];
+        a.partials[blockIdx.x] = t;
+      }
     }
   }
 }
@@ -335,12 +368,13 @@ static void launch_epi(const HopArgs &a, int epi, hipStream_t st, const HopLaunc
     case EPI_STORE: launch_variant<EPI_STORE, TFACE>(a, st, o, allow_map); break;
     case EPI_TM_TIMES: launch_variant<EPI_TM_TIMES, TFACE>(a, st, o, allow_map); break;
     case EPI_TM_SUB_G5: launch_variant<EPI_TM_SUB_G5, TFACE>(a, st, o, allow_map); break;
+    case EPI_TM_SUB_G5_DOT: launch_variant<EPI_TM_SUB_G5_DOT, TFACE>(a, st, o, allow_map); break;
     default: launch_variant<EPI_TM_SUB, TFACE>(a, st, o, allow_map); break;
   }
 }
 
 static void fill_args(HopArgs &a, tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, double cre, double cim) {
-  a.out = out; a.in = in; a.p = p;
+  a.out = out; a.in = in; a.p = p; a.dotv = nullptr; a.partials = nullptr;
   a.gauge = ctx->gauge + (size_t)(ieo ? 1 : 0) * 72 * ctx->gs;
   a.halo_up = ctx->recv_up; a.halo_dn = ctx->recv_dn;
   a.ns = ctx->ns; a.gs = ctx->gs;
@@ -423,6 +457,26 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
     if (flags) hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->sync_flags + 1, seq, ctx->sync_flags + 2);
     else TMHIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_comm, 0));
   }
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// tm_sub_Hopping_Matrix with the real scalar product <dotv, l> accumulated in the epilogue (one partial
+// per block in ctx->partials).  Unsplit lattices only; *npartials receives the number of blocks.
+int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
+                             double cre, double cim, int *npartials) {
+  if (!ctx->gauge_set) TMHIP_FAIL("Hopping_Matrix called before tmhip_set_gauge");
+  if (ctx->g.nproc_t > 1 || ctx->loopback) TMHIP_FAIL("fused scalar product is only available on an unsplit lattice");
+  if (out == in) TMHIP_FAIL("Hopping_Matrix: l and k must differ");
+  HopArgs a;
+  fill_args(a, ctx, ieo, out, in, p, cre, cim);
+  a.dotv = dotv; a.partials = ctx->partials;
+  HopLaunch o = {256, ctx->opt_nt != 0, 0, ctx->opt_xcd, ctx->opt_occ, ctx->opt_tgrp, ctx->opt_shape};
+  a.i_begin = 0; a.i_end = ctx->Vh;
+  const int nb = (ctx->Vh + 255) / 256;
+  *npartials = (o.xcd && nb >= 64) ? ((nb + 7) / 8) * 8 : nb;  // grid size chosen by launch_one
+  if (*npartials > ctx->max_partials) TMHIP_FAIL("partials buffer too small");
+  launch_epi<0>(a, EPI_TM_SUB_G5_DOT, ctx->stream, o, true);
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }
