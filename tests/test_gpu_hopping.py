@@ -72,8 +72,8 @@ def test_fused_epilogues(setup16, ieo):
         f.free()
 
 
-@pytest.mark.parametrize("mode,flagsync", [(1, 1), (2, 1), (1, 0)])
-def test_loopback_split_path_matches(setup16, mode, flagsync):
+@pytest.mark.parametrize("mode,flagsync,fusedface", [(1, 1, 0), (2, 1, 0), (1, 0, 0), (1, 1, 1), (2, 1, 1)])
+def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface):
     """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self,
     consumed by the boundary kernels -- must equal the plain periodic stencil."""
     orc, lat = setup16
@@ -81,15 +81,27 @@ def test_loopback_split_path_matches(setup16, mode, flagsync):
     k = random_spinor(31, N)
     ref = orc.new_field()
     dk, dl = lat.field(k), lat.field()
+    lat.set_option("fusedface", fusedface)  # 1: one kernel, face blocks wait in-kernel for the exchanged faces
     lat.set_option("flagsync", flagsync)  # cross-stream ordering by device flags (default) or HIP events
     lat.set_loopback(mode)  # 1: D2D copies, 2: one-rank RCCL communicator (ncclSend/Recv to self)
     try:
-        for ieo in (0, 1):
-            orc.Hopping_Matrix(ieo, ref, k)
-            lat.Hopping_Matrix(ieo, dl, dk)
-            assert rel_err(dl.download(), ref[:N]) < TOL
+        for rep in range(3):       # repeated calls re-use the face buffers: a stale-cache bug would show here
+            for ieo in (0, 1):
+                kk = k * (1.0 + rep)
+                dk.upload(kk)
+                orc.Hopping_Matrix(ieo, ref, kk)
+                lat.Hopping_Matrix(ieo, dl, dk)
+                assert rel_err(dl.download(), ref[:N]) < TOL
+        # a dependent chain without host round trips in between (what Qtm_pm_psi does)
+        dk.upload(k)
+        q = lat.field()
+        lat.Qtm_pm_psi(q, dk)
+        qref = orc.new_field(); orc.op("Qtm_pm_psi", qref, k.copy())
+        assert rel_err(q.download(), qref[:N]) < TOL
+        q.free()
         lat.sync()  # also checks the bounded-spin error word
     finally:
         lat.set_loopback(0)
         lat.set_option("flagsync", 1)
+        lat.set_option("fusedface", 0)
     dk.free(); dl.free()

@@ -205,6 +205,32 @@ def test_cg_her_matches_oracle(setup, cg_sync, batch):
     dq.free(); dp.free()
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+def test_cg_fused_scalar_product_path(fused):
+    """V/2 % 256 == 0 (8^4): cg_her fuses scalar_prod_r into the last stencil of Qtm_pm_psi; same iterations,
+    same solution as the unfused path and as the oracle."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T = L = 8
+    orc = Oracle(T, L, L, L, kappa=0.13, mu=0.015, threads=8)
+    lat = Lattice(T, L, L, L, kappa=0.13, mu=0.015)
+    g = syn.gauge_field(21, T, L, L, L)
+    orc.set_gauge(g); lat.set_gauge(g)
+    N = orc.Vh
+    q = syn.spinor_field_eo(22, 1, T, L, L, L)
+    P = orc.new_field()
+    it_ref, hist_ref = orc.cg_her(P, q.copy(), 500, 1e-20, 1, N)
+    lat.set_option("cg_fused_dot", fused)
+    dq, dp = lat.field(q), lat.field()
+    it, hist = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
+    assert abs(it - it_ref) <= 1
+    m = min(len(hist), len(hist_ref)) - 1
+    assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6)
+    assert rel_err(dp.download(), P[:N]) < 1e-9
+    lat.close()
+
+
 def test_cg_not_converged_returns_minus_one(setup):
     orc, lat = setup
     N = orc.Vh

@@ -198,7 +198,7 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
   const int nblk = g.x * g.y;
   double *sum = ctx->result_dev + 1;
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
-  const bool fused = ctx->opt_cg_fused_dot && op == TMHIP_OP_QTM_PM && ctx->g.nproc_t == 1 && !ctx->loopback && ctx->opt_block == 256;
+  const bool fused = ctx->opt_cg_fused_dot && op == TMHIP_OP_QTM_PM && ctx->g.nproc_t == 1 && !ctx->loopback && ctx->opt_block == 256 && ctx->Vh % 256 == 0;
   int enq = 0, done = 0;
   int *flag = (int *)(ctx->result_host + 2);
   while (enq < max_iter && !done) {

@@ -226,6 +226,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "tgrp")) ctx->opt_tgrp = value;
   else if (!strcmp(name, "flagsync")) ctx->opt_flagsync = value;
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
+  else if (!strcmp(name, "fusedface")) ctx->opt_fusedface = value;
   else if (!strcmp(name, "shape")) ctx->opt_shape = value;
   else if (!strcmp(name, "cg_sync")) ctx->opt_cg_sync = value;
   else if (!strcmp(name, "cg_batch")) ctx->opt_cg_batch = value > 0 ? value : 1;

@@ -36,6 +36,9 @@ struct HopArgs {
   int map_tc;      // >0: within an XCD chunk walk t fastest over map_tc time-slices (tile order)
   int map_bpt;     // blocks per time-slice (face / BS) for the tile order
   int map_nb;      // real number of blocks of this launch (the grid is padded to a multiple of 8)
+  int nb_int_grid;           // TFACE 4: grid blocks [0, nb_int_grid) are interior, the rest walk the two t-faces
+  int face_bpb;              // TFACE 4: blocks per face
+  const unsigned int *halo_flag; unsigned int halo_seq; unsigned int *err_flag;  // TFACE 4: faces are valid once *halo_flag >= halo_seq
   int shape_bx, shape_by;  // >1: a block covers shape_bx x-planes x shape_by y-rows x all k (instead of BS consecutive sites)
   double ka[4][2];
   double cre, cim;
@@ -134,10 +137,41 @@ __device__ __forceinline__ void hop_dir(v2d (&acc)[12], const v2d *__restrict__ 
 //        1 = sites of the t=0 slab:   -t half-spinors come from halo_dn
 //        2 = sites of the t=T-1 slab: +t half-spinors come from halo_up
 //        3 = both slabs in one launch (block-uniform choice between 1 and 2)
+//        4 = interior AND both slabs in one launch; the face blocks wait in-kernel for the exchanged faces
 template <int EPI, int TFACE, bool NTIO, int BS, int MINW>
 __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
   constexpr bool NT = true;  // gauge links: used once per call -> non-temporal (measured 0.19 -> 0.16 ms at 32^4)
   int bid = blockIdx.x;
+  int tf = (TFACE == 4) ? 0 : TFACE;
+  int i = 0;
+  bool face_block = false;
+  if (TFACE == 4 && bid >= a.nb_int_grid) {
+    // Face blocks of the single-launch split-phase kernel.  They carry the highest block ids, so they are
+    // dispatched after the interior blocks; the exchanged half-spinors are published by the comm stream
+    // through *halo_flag (flag_set_kernel after the exchange).  Consumer side of the hand-off
+    // (cdna guide G16): one lane polls relaxed, then ONE agent-scope acquire, vmcnt(0), barrier, plain loads.
+    // The face buffers are read nowhere else in this kernel, so no stale copy can sit in this XCD's L2.
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+      while ((int)(__hip_atomic_load(a.halo_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.halo_seq) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {  // 3 s: give up, flag the error, never hang the GPU
+          __hip_atomic_store(a.err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const int bb = bid - a.nb_int_grid;
+    const int second = bb >= a.face_bpb;
+    const int jl = (bb - (second ? a.face_bpb : 0)) * BS + threadIdx.x;
+    if (jl >= a.face) return;
+    tf = second ? 2 : 1;
+    i = second ? a.Vh - a.face + jl : jl;
+    face_block = true;
+  } else {
   if (a.nxcd_chunk > 0) {
     // XCD-aware remap: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD a
     // contiguous chunk of the lattice so neighbouring tiles hit the same L2.
@@ -158,7 +192,7 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
       bid = (g * a.map_tc + tl) * a.map_bpt + sp;
     }
   }
-  int i = a.i_begin + bid * BS + threadIdx.x;
+  i = a.i_begin + bid * BS + threadIdx.x;
   if (TFACE == 0 && a.shape_bx > 1) {
     // compact block shape: fewer neighbour rows fall outside the block's own footprint
     const int tt = bid / a.map_bpt, sp = bid - tt * a.map_bpt;
@@ -168,8 +202,10 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
     const int dx = rr / a.shape_by, dy = rr - dx * a.shape_by;
     i = ((tt * a.LX + xb * a.shape_bx + dx) * a.LY + yb * a.shape_by + dy) * a.LZh + kk;
   }
-  int tf = TFACE;
-  if (TFACE == 3) {
+  }  // !face block
+  if (face_block) {
+    // index already set
+  } else if (TFACE == 3) {
     // both t-faces in one launch: blocks [0, map_bpt) walk the t=0 slab, [map_bpt, 2 map_bpt) the t=T-1 slab
     const int second = bid >= a.map_bpt;
     const int jl = (bid - (second ? a.map_bpt : 0)) * BS + threadIdx.x;
@@ -177,11 +213,8 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
     tf = second ? 2 : 1;
     i = second ? a.Vh - a.face + jl : jl;
   } else if (i >= a.i_end) {
-    if (EPI != EPI_TM_SUB_G5_DOT) return;
-    i = a.i_end - 1;  // fused reduction: every wave of the block must reach the barrier; results of this lane are discarded
-    tf = -1;
+    return;  // (the fused-reduction variant is only launched on lattices with V/2 % BS == 0: no partial blocks)
   }
-  const bool lane_active = tf >= 0;
 
   const int LZh = a.LZh;
   const int k = i % LZh;
@@ -236,26 +269,21 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
   } else {
     // EPI_TM_SUB_G5[_DOT]: hopping.h:680-688  l = g5[(cf,cf*) p - H k];  EPI_TM_SUB: same without g5
     const v2d *__restrict__ p = a.p;
+    double d = 0.0;
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
-      acc[c] = cmul(cf, ldg<NTIO>(p + (size_t)c * a.ns + i)) - acc[c];
-      if (EPI != EPI_TM_SUB_G5_DOT || lane_active) stg<NTIO>(out + (size_t)c * a.ns + i, acc[c]);
-    }
-#pragma unroll
-    for (int c = 6; c < 12; c++) {
-      const v2d zp = cmulc(cf, ldg<NTIO>(p + (size_t)c * a.ns + i));
-      acc[c] = (EPI == EPI_TM_SUB) ? zp - acc[c] : acc[c] - zp;
-      if (EPI != EPI_TM_SUB_G5_DOT || lane_active) stg<NTIO>(out + (size_t)c * a.ns + i, acc[c]);
+    for (int c = 0; c < 12; c++) {
+      const v2d pv = ldg<NTIO>(p + (size_t)c * a.ns + i);
+      v2d r;
+      if (c < 6) r = cmul(cf, pv) - acc[c];
+      else { const v2d zp = cmulc(cf, pv); r = (EPI == EPI_TM_SUB) ? zp - acc[c] : acc[c] - zp; }
+      stg<NTIO>(out + (size_t)c * a.ns + i, r);
+      if (EPI == EPI_TM_SUB_G5_DOT) {
+        // fused scalar_prod_r(dotv, out) of cg_her.c:93: saves re-reading `out` (and a launch) per CG iteration
+        const v2d w = ldg<NTIO>(a.dotv + (size_t)c * a.ns + i);
+        d += w.x * r.x + w.y * r.y;
+      }
     }
     if (EPI == EPI_TM_SUB_G5_DOT) {
-      // fused scalar_prod_r(dotv, out) of cg_her.c:93: saves re-reading `out` (and a launch) per CG iteration
-      double d = 0.0;
-#pragma unroll
-      for (int c = 0; c < 12; c++) {
-        const v2d w = ldg<NTIO>(a.dotv + (size_t)c * a.ns + i);
-        d += w.x * acc[c].x + w.y * acc[c].y;
-      }
-      if (!lane_active) d = 0.0;
       __shared__ double wsum[BS / 64];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
@@ -317,8 +345,8 @@ struct HopLaunch { int block; bool ntio; int minw; int xcd; int occ; int tgrp; i
 template <int EPI, int TFACE, bool NTIO, int BS, int MINW>
 static void launch_one(const HopArgs &a, hipStream_t st, const HopLaunch &o, bool allow_map) {
   const int n = a.i_end - a.i_begin;
-  if (n <= 0) return;
-  int nb = (n + BS - 1) / BS;
+  if (n <= 0 && TFACE != 4) return;
+  int nb = n > 0 ? (n + BS - 1) / BS : 0;
   HopArgs b = a;
   b.nxcd_chunk = 0; b.map_tc = 0; b.map_bpt = 0; b.map_nb = nb; b.shape_bx = 0; b.shape_by = 0;
   if (allow_map && o.xcd && nb >= 64) {
@@ -338,6 +366,11 @@ static void launch_one(const HopArgs &a, hipStream_t st, const HopLaunch &o, boo
       }
     }
     nb = chunk * 8;  // blocks past i_end exit immediately
+  }
+  if (TFACE == 4) {  // face blocks ride behind the interior blocks of the same launch
+    b.nb_int_grid = nb;
+    b.face_bpb = (a.face + BS - 1) / BS;
+    nb += 2 * b.face_bpb;
   }
   // occupancy cap for A/B runs: dynamic LDS sized so that only `occ` waves per SIMD fit on a CU
   size_t lds = 0;
@@ -375,6 +408,7 @@ static void launch_epi(const HopArgs &a, int epi, hipStream_t st, const HopLaunc
 
 static void fill_args(HopArgs &a, tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, double cre, double cim) {
   a.out = out; a.in = in; a.p = p; a.dotv = nullptr; a.partials = nullptr;
+  a.nb_int_grid = 0; a.face_bpb = 0; a.halo_flag = nullptr; a.halo_seq = 0; a.err_flag = nullptr;
   a.gauge = ctx->gauge + (size_t)(ieo ? 1 : 0) * 72 * ctx->gs;
   a.halo_up = ctx->recv_up; a.halo_dn = ctx->recv_dn;
   a.ns = ctx->ns; a.gs = ctx->gs;
@@ -416,6 +450,19 @@ static void launch_boundary(tmhip_ctx *ctx, HopArgs &a, int epi, const HopLaunch
 #undef TMHIP_B
 }
 
+static void launch_fused_faces(tmhip_ctx *ctx, HopArgs &a, int epi, const HopLaunch &o) {
+  a.i_begin = ctx->face; a.i_end = ctx->Vh - ctx->face;
+#define TMHIP_F(EPI) if (o.ntio) launch_one<EPI, 4, true, 256, 1>(a, ctx->stream, o, true); \
+                     else launch_one<EPI, 4, false, 256, 1>(a, ctx->stream, o, true)
+  switch (epi) {
+    case EPI_STORE: TMHIP_F(EPI_STORE); break;
+    case EPI_TM_TIMES: TMHIP_F(EPI_TM_TIMES); break;
+    case EPI_TM_SUB_G5: TMHIP_F(EPI_TM_SUB_G5); break;
+    default: TMHIP_F(EPI_TM_SUB); break;
+  }
+#undef TMHIP_F
+}
+
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
                          double cre, double cim, bool comm) {
   if (!ctx->gauge_set) TMHIP_FAIL("Hopping_Matrix called before tmhip_set_gauge");
@@ -439,6 +486,21 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
     // tsplit variant, operator/hopping_sse_dbl.c:79-161).
     const bool flags = ctx->opt_flagsync != 0;
     const unsigned int seq = ++ctx->hop_seq;
+    if (ctx->opt_fusedface) {
+      // ONE kernel on the main stream (interior blocks first, face blocks last, the latter wait in-kernel for
+      // the faces); the comm stream packs, exchanges and publishes.  The main stream never waits on the host
+      // side, so consecutive stencils run back to back as on an unsplit lattice.
+      hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->sync_flags + 0, seq);
+      hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(1), 0, ctx->comm_stream, ctx->sync_flags + 0, seq, ctx->sync_flags + 2);
+      hipLaunchKernelGGL(pack_faces_kernel, dim3((ctx->face + 255) / 256, 2), dim3(256), 0, ctx->comm_stream,
+                         in, ctx->ns, ctx->Vh, ctx->face, ctx->send_dn, ctx->send_up);
+      if (tmhip_halo_exchange(ctx)) return 1;
+      hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, ctx->comm_stream, ctx->sync_flags + 1, seq);
+      a.halo_flag = ctx->sync_flags + 1; a.halo_seq = seq; a.err_flag = ctx->sync_flags + 2;
+      launch_fused_faces(ctx, a, epi, o);
+      TMHIP_CHECK(hipGetLastError());
+      return 0;
+    }
     if (flags) {  // `in` (and `p`) are ready, `out` is free
       hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->sync_flags + 0, seq);
       hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(1), 0, ctx->comm_stream, ctx->sync_flags + 0, seq, ctx->sync_flags + 2);
@@ -466,7 +528,7 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
                              double cre, double cim, int *npartials) {
   if (!ctx->gauge_set) TMHIP_FAIL("Hopping_Matrix called before tmhip_set_gauge");
-  if (ctx->g.nproc_t > 1 || ctx->loopback) TMHIP_FAIL("fused scalar product is only available on an unsplit lattice");
+  if (ctx->g.nproc_t > 1 || ctx->loopback || ctx->Vh % 256 != 0) TMHIP_FAIL("fused scalar product needs an unsplit lattice with V/2 %% 256 == 0");
   if (out == in) TMHIP_FAIL("Hopping_Matrix: l and k must differ");
   HopArgs a;
   fill_args(a, ctx, ieo, out, in, p, cre, cim);
