@@ -105,3 +105,36 @@ def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface):
         lat.set_option("flagsync", 1)
         lat.set_option("fusedface", 0)
     dk.free(); dl.free()
+
+
+@pytest.mark.parametrize("dims", [(2, 2, 2, 2), (4, 2, 2, 2), (2, 4, 6, 2), (24, 4, 4, 4), (4, 4, 4, 16), (6, 10, 2, 4)])
+def test_small_and_ragged_lattices(dims):
+    """The shapes of the reference's own operator regression (hopping_test: L in 4..16, T in 4..24,
+    test/hopping_test_generate_script:17-31) plus the smallest legal lattice; every direction wraps."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T, LX, LY, LZ = dims
+    theta = (1.0, 0.3, -0.2, 0.5)
+    orc = Oracle(T, LX, LY, LZ, kappa=0.14, mu=0.03, theta=theta)
+    lat = Lattice(T, LX, LY, LZ, kappa=0.14, mu=0.03, theta=theta)
+    g = random_gauge(sum(dims), orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    N = orc.Vh
+    for ieo in (0, 1):
+        k = random_spinor(3 + ieo, N)
+        ref = orc.new_field()
+        orc.Hopping_Matrix(ieo, ref, k)
+        dk, dl = lat.field(k), lat.field()
+        lat.Hopping_Matrix(ieo, dl, dk)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+        lat.set_loopback(1)
+        lat.Hopping_Matrix(ieo, dl, dk)
+        lat.set_loopback(0)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+    q = random_spinor(9, N)
+    ref = orc.new_field(); orc.op("Qtm_pm_psi", ref, q.copy())
+    dq, dl = lat.field(q), lat.field()
+    lat.Qtm_pm_psi(dl, dq)
+    assert rel_err(dl.download(), ref[:N]) < TOL
+    assert abs(lat.square_norm(dl, N) - orc.square_norm(ref, N)) <= TOL * orc.square_norm(ref, N)
+    lat.close()

@@ -39,6 +39,7 @@ struct HopArgs {
   int nb_int_grid;           // TFACE 4: grid blocks [0, nb_int_grid) are interior, the rest walk the two t-faces
   int face_bpb;              // TFACE 4: blocks per face
   const unsigned int *halo_flag; unsigned int halo_seq; unsigned int *err_flag;  // TFACE 4: faces are valid once *halo_flag >= halo_seq
+  unsigned gauge_bytes;      // experiment (GAUX >= 0): size of the gauge buffer descriptor; 0 drops every gauge load
   int shape_bx, shape_by;  // >1: a block covers shape_bx x-planes x shape_by y-rows x all k (instead of BS consecutive sites)
   double ka[4][2];
   double cre, cim;
@@ -69,10 +70,13 @@ __device__ __forceinline__ void stg(v2d *p, v2d v) {
 
 // One of the 8 hops.  D = 2*mu + (0: +mu, 1: -mu), mu = t,x,y,z.
 // HALO: the projected half-spinor comes from an exchanged face buffer [6][face] instead of `in`.
-template <int D, bool HALO, bool NT>
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int D, bool HALO, bool NT, int GAUX = -1>
 __device__ __forceinline__ void hop_dir(v2d (&acc)[12], const v2d *__restrict__ in, int ns, int j,
                                         const v2d *__restrict__ halo, int face,
-                                        const v2d *__restrict__ g, size_t gs, int i, v2d ka) {
+                                        const v2d *__restrict__ g, size_t gs, int i, v2d ka,
+                                        __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t()) {
   v2d pa[3], pb[3];
   if (HALO) {
 #pragma unroll
@@ -97,8 +101,18 @@ __device__ __forceinline__ void hop_dir(v2d (&acc)[12], const v2d *__restrict__ 
   }
   const v2d *gd = g + (size_t)D * 9 * gs + i;
   v2d u[9];
+  if (GAUX < 0) {
 #pragma unroll
-  for (int e = 0; e < 9; e++) u[e] = ldg<NT>(gd + (size_t)e * gs);
+    for (int e = 0; e < 9; e++) u[e] = ldg<NT>(gd + (size_t)e * gs);
+  } else {
+    // experiment: gauge links through a buffer descriptor with an explicit cache policy (aux: 1 sc0, 2 nt, 16 sc1)
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+      const unsigned off = (unsigned)((((size_t)(D * 9 + e)) * gs + i) * sizeof(v2d));
+      const v4i raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, GAUX);
+      u[e] = __builtin_bit_cast(v2d, raw);
+    }
+  }
   v2d ca[3], cb[3];
   if ((D & 1) == 0) {  // chi = U psi           (su3.h:308-311)
 #pragma unroll
@@ -138,7 +152,7 @@ __device__ __forceinline__ void hop_dir(v2d (&acc)[12], const v2d *__restrict__ 
 //        2 = sites of the t=T-1 slab: +t half-spinors come from halo_up
 //        3 = both slabs in one launch (block-uniform choice between 1 and 2)
 //        4 = interior AND both slabs in one launch; the face blocks wait in-kernel for the exchanged faces
-template <int EPI, int TFACE, bool NTIO, int BS, int MINW>
+template <int EPI, int TFACE, bool NTIO, int BS, int MINW, int GAUX = -1>
 __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
   constexpr bool NT = true;  // gauge links: used once per call -> non-temporal (measured 0.19 -> 0.16 ms at 32^4)
   int bid = blockIdx.x;
@@ -245,16 +259,18 @@ __global__ __launch_bounds__(BS, MINW) void hop_kernel(const HopArgs a) {
   const v2d *__restrict__ in = a.in;
   const v2d *__restrict__ g = a.gauge;
 
-  if (TFACE != 0 && tf == 2) hop_dir<0, true, NT>(acc, in, a.ns, jf, a.halo_up, a.face, g, a.gs, i, ka0);
-  else                       hop_dir<0, false, NT>(acc, in, a.ns, jtp, nullptr, 0, g, a.gs, i, ka0);
-  if (TFACE != 0 && tf == 1) hop_dir<1, true, NT>(acc, in, a.ns, jf, a.halo_dn, a.face, g, a.gs, i, ka0);
-  else                       hop_dir<1, false, NT>(acc, in, a.ns, jtm, nullptr, 0, g, a.gs, i, ka0);
-  hop_dir<2, false, NT>(acc, in, a.ns, jxp, nullptr, 0, g, a.gs, i, ka1);
-  hop_dir<3, false, NT>(acc, in, a.ns, jxm, nullptr, 0, g, a.gs, i, ka1);
-  hop_dir<4, false, NT>(acc, in, a.ns, jyp, nullptr, 0, g, a.gs, i, ka2);
-  hop_dir<5, false, NT>(acc, in, a.ns, jym, nullptr, 0, g, a.gs, i, ka2);
-  hop_dir<6, false, NT>(acc, in, a.ns, jzp, nullptr, 0, g, a.gs, i, ka3);
-  hop_dir<7, false, NT>(acc, in, a.ns, jzm, nullptr, 0, g, a.gs, i, ka3);
+  __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t();
+  if (GAUX >= 0) rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2d *>(g), 0, a.gauge_bytes, 0x00020000);
+  if (TFACE != 0 && tf == 2) hop_dir<0, true, NT, GAUX>(acc, in, a.ns, jf, a.halo_up, a.face, g, a.gs, i, ka0, rsrc);
+  else                       hop_dir<0, false, NT, GAUX>(acc, in, a.ns, jtp, nullptr, 0, g, a.gs, i, ka0, rsrc);
+  if (TFACE != 0 && tf == 1) hop_dir<1, true, NT, GAUX>(acc, in, a.ns, jf, a.halo_dn, a.face, g, a.gs, i, ka0, rsrc);
+  else                       hop_dir<1, false, NT, GAUX>(acc, in, a.ns, jtm, nullptr, 0, g, a.gs, i, ka0, rsrc);
+  hop_dir<2, false, NT, GAUX>(acc, in, a.ns, jxp, nullptr, 0, g, a.gs, i, ka1, rsrc);
+  hop_dir<3, false, NT, GAUX>(acc, in, a.ns, jxm, nullptr, 0, g, a.gs, i, ka1, rsrc);
+  hop_dir<4, false, NT, GAUX>(acc, in, a.ns, jyp, nullptr, 0, g, a.gs, i, ka2, rsrc);
+  hop_dir<5, false, NT, GAUX>(acc, in, a.ns, jym, nullptr, 0, g, a.gs, i, ka2, rsrc);
+  hop_dir<6, false, NT, GAUX>(acc, in, a.ns, jzp, nullptr, 0, g, a.gs, i, ka3, rsrc);
+  hop_dir<7, false, NT, GAUX>(acc, in, a.ns, jzm, nullptr, 0, g, a.gs, i, ka3, rsrc);
 
   v2d *__restrict__ out = a.out;
   const v2d cf = v2d{a.cre, a.cim};
@@ -340,9 +356,9 @@ __global__ __launch_bounds__(256) void pack_faces_kernel(const v2d *__restrict__
   }
 }
 
-struct HopLaunch { int block; bool ntio; int minw; int xcd; int occ; int tgrp; int shape; };
+struct HopLaunch { int block; bool ntio; int minw; int xcd; int occ; int tgrp; int shape; int gaux; int gdrop; };
 
-template <int EPI, int TFACE, bool NTIO, int BS, int MINW>
+template <int EPI, int TFACE, bool NTIO, int BS, int MINW, int GAUX = -1>
 static void launch_one(const HopArgs &a, hipStream_t st, const HopLaunch &o, bool allow_map) {
   const int n = a.i_end - a.i_begin;
   if (n <= 0 && TFACE != 4) return;
@@ -379,11 +395,25 @@ static void launch_one(const HopArgs &a, hipStream_t st, const HopLaunch &o, boo
     lds = (size_t)(163840 / (blocks_per_cu > 0 ? blocks_per_cu : 1)) / 256 * 256;
     if (lds > 65536) lds = 65536;  // default dynamic-LDS limit without an attribute opt-in
   }
-  hipLaunchKernelGGL((hop_kernel<EPI, TFACE, NTIO, BS, MINW>), dim3(nb), dim3(BS), lds, st, b);
+  if (o.gdrop) b.gauge_bytes = 0;
+  hipLaunchKernelGGL((hop_kernel<EPI, TFACE, NTIO, BS, MINW, GAUX>), dim3(nb), dim3(BS), lds, st, b);
 }
 
 template <int EPI, int TFACE>
 static void launch_variant(const HopArgs &a, hipStream_t st, const HopLaunch &o, bool allow_map) {
+  if (EPI == EPI_STORE && TFACE == 0 && o.gaux >= 0 && o.block == 256) {  // cache-policy experiment on the plain stencil only
+    switch (o.gaux) {
+      case 0: launch_one<EPI_STORE, 0, true, 256, 1, 0>(a, st, o, allow_map); return;
+      case 1: launch_one<EPI_STORE, 0, true, 256, 1, 1>(a, st, o, allow_map); return;
+      case 2: launch_one<EPI_STORE, 0, true, 256, 1, 2>(a, st, o, allow_map); return;
+      case 3: launch_one<EPI_STORE, 0, true, 256, 1, 3>(a, st, o, allow_map); return;
+      case 16: launch_one<EPI_STORE, 0, true, 256, 1, 16>(a, st, o, allow_map); return;
+      case 17: launch_one<EPI_STORE, 0, true, 256, 1, 17>(a, st, o, allow_map); return;
+      case 18: launch_one<EPI_STORE, 0, true, 256, 1, 18>(a, st, o, allow_map); return;
+      case 19: launch_one<EPI_STORE, 0, true, 256, 1, 19>(a, st, o, allow_map); return;
+      default: break;
+    }
+  }
 #define TMHIP_L(NTIO, BS, MINW) launch_one<EPI, TFACE, NTIO, BS, MINW>(a, st, o, allow_map)
   if (o.block == 64) {
     if (o.ntio) { if (o.minw >= 4) TMHIP_L(true, 64, 4); else TMHIP_L(true, 64, 1); }
@@ -408,6 +438,7 @@ static void launch_epi(const HopArgs &a, int epi, hipStream_t st, const HopLaunc
 
 static void fill_args(HopArgs &a, tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, double cre, double cim) {
   a.out = out; a.in = in; a.p = p; a.dotv = nullptr; a.partials = nullptr;
+  a.gauge_bytes = (unsigned)((size_t)72 * ctx->gs * sizeof(v2d));
   a.nb_int_grid = 0; a.face_bpb = 0; a.halo_flag = nullptr; a.halo_seq = 0; a.err_flag = nullptr;
   a.gauge = ctx->gauge + (size_t)(ieo ? 1 : 0) * 72 * ctx->gs;
   a.halo_up = ctx->recv_up; a.halo_dn = ctx->recv_dn;
@@ -469,7 +500,7 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
   if (out == in) TMHIP_FAIL("Hopping_Matrix: l and k must differ (operator/D_psi_body.c:267-272 convention)");
   HopArgs a;
   fill_args(a, ctx, ieo, out, in, p, cre, cim);
-  const HopLaunch o = {ctx->opt_block, ctx->opt_nt != 0, ctx->opt_minw, ctx->opt_xcd, ctx->opt_occ, ctx->opt_tgrp, ctx->opt_shape};
+  const HopLaunch o = {ctx->opt_block, ctx->opt_nt != 0, ctx->opt_minw, ctx->opt_xcd, ctx->opt_occ, ctx->opt_tgrp, ctx->opt_shape, ctx->opt_gaux, ctx->opt_gdrop};
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
   if (!split) {
     a.i_begin = 0; a.i_end = ctx->Vh;
@@ -533,7 +564,7 @@ int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, c
   HopArgs a;
   fill_args(a, ctx, ieo, out, in, p, cre, cim);
   a.dotv = dotv; a.partials = ctx->partials;
-  HopLaunch o = {256, ctx->opt_nt != 0, 0, ctx->opt_xcd, ctx->opt_occ, ctx->opt_tgrp, ctx->opt_shape};
+  HopLaunch o = {256, ctx->opt_nt != 0, 0, ctx->opt_xcd, ctx->opt_occ, ctx->opt_tgrp, ctx->opt_shape, ctx->opt_gaux, ctx->opt_gdrop};
   a.i_begin = 0; a.i_end = ctx->Vh;
   const int nb = (ctx->Vh + 255) / 256;
   *npartials = (o.xcd && nb >= 64) ? ((nb + 7) / 8) * 8 : nb;  // grid size chosen by launch_one
@@ -576,7 +607,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipEventRecord(c->ev_comm, c->comm_stream));
     HopArgs a;
     fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape};
+    const HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop};
     launch_interior(c, a, EPI_STORE, o);
   }
   for (int r = 0; r < n; r++) {
@@ -585,7 +616,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     HopArgs a;
     fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape};
+    const HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop};
     launch_boundary(c, a, EPI_STORE, o, c->stream);
     TMHIP_CHECK(hipGetLastError());
   }

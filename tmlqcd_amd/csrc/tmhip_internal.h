@@ -77,7 +77,7 @@ struct tmhip_ctx {
   // device-resident CG state (cg.hip)
   void *cg_state; double *cg_hist; int cg_hist_len;
   // options
-  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_variant; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface;
+  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_variant; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface; int opt_gaux; int opt_gdrop;
 };
 
 // ---- launch helpers implemented across the .hip files ----
