@@ -75,3 +75,20 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(h, "library_path", lambda: "/nonexistent/libtmlqcd_hip.so")
     with pytest.raises(h.TmHipError):
         h.load_library()
+
+
+def test_reference_caller_host_program_links_against_the_drop_in():
+    """Link-level check on the CPU: reference object code (cg_her, geometry, start, ...) with the hot-path objects
+    left out resolves every hot-path symbol from libtmlqcd_dropin.so; the drop-in resolves tmLQCD's globals and
+    update_backward_gauge from the reference objects (oracle/Makefile target libtmhostprog.so)."""
+    import subprocess, sys
+    so = os.path.join(ROOT, "oracle", "_ref", "libtmhostprog.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libtmhostprog.so not built (needs /root/reference)")
+    code = ("import ctypes as C; h = C.CDLL(%r, mode=C.RTLD_GLOBAL); "
+            "assert h.cg_her and h.geometry and h.update_backward_gauge; print('linked')" % so)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "linked" in r.stdout, r.stderr
+    und = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+    for sym in ("square_norm", "scalar_prod_r", "assign_add_mul_r", "assign_mul_add_r_and_square", "diff", "assign"):
+        assert (" U " + sym) in und, sym                       # really taken from the drop-in, not from reference objects

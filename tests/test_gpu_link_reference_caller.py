@@ -1,0 +1,70 @@
+"""GPU, link-level integration: the REFERENCE's own caller code drives the drop-in library.
+
+oracle/_ref/libtmhostprog.so is a stand-in executable made of reference objects only (solver/cg_her.c,
+solver/solver_field.c, geometry_eo.c, boundary.c, start.c + RANLUX, init_gauge_field.c,
+update_backward_gauge.c, globals) with every hot-path object left out and libtmlqcd_dropin.so on its link
+line.  So the reference's cg_her -- unmodified object code -- calls OUR square_norm,
+diff, assign, scalar_prod_r, assign_add_mul_r, assign_mul_add_r_and_square, assign_mul_add_r and, through
+the matrix_mult pointer, OUR Qtm_pm_psi, all with host AoS pointers in the default coherent mode, and our
+Hopping_Matrix calls THEIR update_backward_gauge when g_update_gauge_copy is set."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOSTPROG = os.path.join(ROOT, "oracle", "_ref", "libtmhostprog.so")
+
+CHILD = r'''
+import ctypes as C, json, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+host = C.CDLL(%(hostprog)r, mode=C.RTLD_GLOBAL)          # pulls in libtmlqcd_dropin.so + libtmlqcd_hip.so
+dropin = C.CDLL(%(root)r + "/tmlqcd_amd/lib/libtmlqcd_dropin.so", mode=C.RTLD_GLOBAL)
+host.tmref_init.argtypes = [C.c_int] * 4 + [C.c_double] * 2 + [C.c_int] * 2
+host.tmref_spinor.restype = C.c_void_p; host.tmref_spinor.argtypes = [C.c_int]
+host.tmref_gauge.restype = C.c_void_p
+L = 8
+assert host.tmref_init(L, L, L, L, 0.125, 0.01, 14, 1) == 0
+host.tmref_random_fields(123456)                          # benchmark.c:247-259
+V, N = L ** 4, L ** 4 // 2
+sp = host.tmref_spinor
+def view(i, n=N):
+    return np.frombuffer((C.c_double * (n * 24)).from_address(sp(i)), dtype=np.float64).reshape(n, 4, 3, 2)
+gauge = np.frombuffer((C.c_double * (V * 72)).from_address(host.tmref_gauge()), dtype=np.float64).reshape(V, 4, 3, 3, 2).copy()
+src = view(0).copy()
+view(1)[:] = 0
+host.cg_her.restype = C.c_int
+host.cg_her.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p]
+f = C.cast(dropin.Qtm_pm_psi, C.c_void_p)
+assert C.c_int.in_dll(host, "g_update_gauge_copy").value == 1
+it = host.cg_her(sp(1), sp(0), 1000, 1e-20, 1, N, f)     # the reference's cg_her object code
+assert C.c_int.in_dll(host, "g_update_gauge_copy").value == 0   # their update_backward_gauge ran and cleared it
+sol = view(1).copy()
+# independent fp64 check on the CPU oracle
+from oracle.oraclebind import Oracle
+o = Oracle(L, L, L, L, kappa=0.125, mu=0.01)
+o.set_gauge(gauge)
+full = o.new_field(); full[:N] = sol
+chk = o.new_field(); o.op("Qtm_pm_psi", chk, full)
+res = float(((chk[:N] - src) ** 2).sum() / (src ** 2).sum())
+Pref = o.new_field(); it_ref, _ = o.cg_her(Pref, src.copy(), 1000, 1e-20, 1, N)
+err = float(np.abs(sol - Pref[:N]).max() / np.abs(Pref[:N]).max())
+dropin.tmlqcd_hip_finalize()
+print(json.dumps({"iters": it, "iters_oracle": it_ref, "true_res_rel": res, "sol_err": err}))
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(HOSTPROG), reason="oracle/_ref/libtmhostprog.so not built (needs /root/reference)")
+def test_reference_cg_her_object_code_drives_the_drop_in():
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "hostprog": HOSTPROG}],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_scalars_8x8.json")))
+    assert abs(d["iters"] - gold["cg_iters"]) <= 1           # 36 iterations in the all-reference run
+    assert abs(d["iters"] - d["iters_oracle"]) <= 1
+    assert d["true_res_rel"] <= 4e-20 and d["sol_err"] < 1e-8
