@@ -85,6 +85,17 @@ void assign(spinor *const R, spinor *const S, const int N);
 int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, const int rel_prec,
            const int N, matrix_mult f);
 
+/* ---- solver/mixed_cg_her.h ------------------------------ */
+/* `solver_params_t` (solver/solver_params.h:46) is passed BY VALUE but not used by the reference's mixed_cg_her
+ * (solver/mixed_cg_her.c:65-202 reads the globals mixcg_innereps / mixcg_maxinnersolverit, read_input.h:112-113).
+ * Any struct larger than 16 bytes is passed in memory under the SysV ABI and leaves the register arguments
+ * (P, Q, max_iter, eps_sq, rel_prec, N, f) where the caller put them, so it is declared opaque here; the
+ * stack-passed `f32` is not read (the fp32 operator is always Qtm_pm_psi_32). */
+typedef struct { double opaque[64]; } tmlqcd_solver_params_opaque;
+typedef void (*matrix_mult32)(void *const, void *const);   /* solver/matrix_mult_typedef.h:32 */
+int mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params_opaque solver_params, const int max_iter,
+                 double eps_sq, const int rel_prec, const int N, matrix_mult f, matrix_mult32 f32);
+
 /* ---- residency control (additions; not in the reference) ------------------- */
 enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1 };
 void tmlqcd_hip_set_residency(int mode);

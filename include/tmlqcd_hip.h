@@ -124,6 +124,27 @@ enum { TMHIP_OP_QTM_PM = 0, TMHIP_OP_QTM_PLUS = 1, TMHIP_OP_QTM_MINUS = 2, TMHIP
 int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec,
                  int N, int op, int *iters, double *res_hist, int hist_len);
 
+/* ---- mixed precision -------------------------------------
+ * fp32 one-parity fields hold the reference's `spinor32` (su3.h:65-68); the fp32 gauge copy is built
+ * on first use from the links given to tmhip_set_gauge. */
+int tmhip_field_alloc32(tmhip_ctx *ctx, tmhip_field **out);
+int tmhip_field_upload32(tmhip_ctx *ctx, tmhip_field *f, const void *host_spinor32, int nsites);
+int tmhip_field_download32(tmhip_ctx *ctx, tmhip_field *f, void *host_spinor32, int nsites);
+int tmhip_assign_to_32(tmhip_ctx *ctx, tmhip_field *R32, tmhip_field *S64, int N);          /* linalg/assign_to_32.c */
+int tmhip_assign_to_64(tmhip_ctx *ctx, tmhip_field *R64, tmhip_field *S32, int N);          /* linalg/assign_to_64.c */
+int tmhip_add_from_32(tmhip_ctx *ctx, tmhip_field *P64, tmhip_field *X32, int N);           /* assign_to_64 + add, mixed_cg_her.c:158-159 */
+int tmhip_hopping_matrix_32(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k);       /* operator/Hopping_Matrix_32.c:97-127 */
+int tmhip_Qtm_pm_psi_32(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);                    /* operator/tm_operators_32.c Qtm_pm_psi_32 */
+int tmhip_square_norm_32(tmhip_ctx *ctx, tmhip_field *P, int N, int parallel, double *out);
+int tmhip_scalar_prod_r_32(tmhip_ctx *ctx, tmhip_field *S, tmhip_field *R, int N, int parallel, double *out);
+int tmhip_assign_add_mul_r_32(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, float c, int N);
+int tmhip_assign_mul_add_r_32(tmhip_ctx *ctx, tmhip_field *R, float c, tmhip_field *S, int N);
+/* mixed_cg_her(P,Q,params,max_iter,eps_sq,rel_prec,N,f,f32)  solver/mixed_cg_her.c:65-202 with f = Qtm_pm_psi,
+ * f32 = Qtm_pm_psi_32; innereps / max_inner_it are the reference's mixcg_innereps / mixcg_maxinnersolverit
+ * (default_input_values.h:193-194: 5.0e-5, 5000).  *iters = the reference's return value (-1: not converged). */
+int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N,
+                       int op, double innereps, int max_inner_it, int *iters, int *outer_iters);
+
 /* ---- multi-GPU halo exchange (replaces xchange_field / xchange_halffield,
  *      xchange/xchange_field.c:269-470, xchange/xchange_halffield.c:176-263) -- */
 #define TMHIP_UNIQUE_ID_BYTES 128

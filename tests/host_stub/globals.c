@@ -15,6 +15,8 @@ su3 **g_gauge_field = NULL;
 int g_update_gauge_copy = 1;
 double g_mu = 0.0, g_kappa = 0.125;
 double _Complex ka0, ka1, ka2, ka3;
+double mixcg_innereps = 5.0e-5;   /* read_input.l:2912, default_input_values.h:193 */
+int mixcg_maxinnersolverit = 5000;
 static su3 *gauge_block = NULL;
 
 su3 *stub_init(int T_, int LX_, int LY_, int LZ_) {

@@ -118,3 +118,20 @@ def test_cg_her_drop_in_and_resident_benchmark(host):
     orc.Hopping_Matrix(0, r1, f0); orc.Hopping_Matrix(1, r2, r1)
     assert rel_err(f2, r2[:N]) < TOL
     d.tmlqcd_hip_set_residency(0)
+
+
+def test_mixed_cg_her_drop_in(host):
+    """solver/mixed_cg_her.h signature: solver_params_t by value (opaque, >16 B => passed in memory), f32 on the stack."""
+    stub, d, orc, g, (T, L, V) = host
+    N = V // 2
+
+    class Params(C.Structure):
+        _fields_ = [("opaque", C.c_double * 64)]
+    d.mixed_cg_her.restype = C.c_int
+    d.mixed_cg_her.argtypes = [VP, VP, Params, C.c_int, C.c_double, C.c_int, C.c_int, VP, VP]
+    q = random_spinor(8, N); P = np.zeros_like(q)
+    it = d.mixed_cg_her(_p(P), _p(q), Params(), 5000, 1e-20, 1, N, C.cast(d.Qtm_pm_psi, VP), None)
+    assert it > 0
+    full = orc.new_field(); full[:N] = P
+    chk = orc.new_field(); orc.op("Qtm_pm_psi", chk, full)
+    assert ((chk[:N] - q) ** 2).sum() / (q ** 2).sum() <= 1e-20

@@ -1,0 +1,100 @@
+"""GPU: fp32 twins and the mixed-precision CG.  The fp32 reference path only exists in the
+half-spinor build with a different operation order, so these rows are checked by properties: the fp32 operators
+against the fp64 oracle at fp32 tolerance, mixed_cg_her by the true fp64 residual and against the fp64 solution."""
+import numpy as np
+import pytest
+
+from tests.util import random_gauge, random_spinor
+
+pytestmark = pytest.mark.gpu
+TOL32 = 2e-6
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T = L = 8
+    kappa, mu, theta = 0.13, 0.015, (1.0, 0.0, 0.0, 0.5)
+    orc = Oracle(T, L, L, L, kappa=kappa, mu=mu, theta=theta, threads=8)
+    lat = Lattice(T, L, L, L, kappa=kappa, mu=mu, theta=theta)
+    g = random_gauge(61, orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    yield orc, lat
+    lat.close()
+
+
+def test_fp32_stencil_and_operator(setup):
+    orc, lat = setup
+    N = orc.Vh
+    k32 = random_spinor(1, N).astype(np.float32)
+    k = k32.astype(np.float64)
+    ref = orc.new_field()
+    dk, dl = lat.field32(k32), lat.field32()
+    for ieo in (0, 1):
+        orc.Hopping_Matrix(ieo, ref, k)
+        lat.Hopping_Matrix_32(ieo, dl, dk)
+        assert rel(dl.download().astype(np.float64), ref[:N]) < TOL32
+    orc.op("Qtm_pm_psi", ref, k.copy())
+    lat.Qtm_pm_psi_32(dl, dk)
+    assert rel(dl.download().astype(np.float64), ref[:N]) < 4 * TOL32
+    dk.free(); dl.free()
+
+
+def test_fp32_linalg_and_conversions(setup):
+    orc, lat = setup
+    N = orc.Vh
+    a64, b64 = random_spinor(2, N), random_spinor(3, N)
+    da, d32, db32, back = lat.field(a64), lat.field32(), lat.field32(b64.astype(np.float32)), lat.field()
+    lat.assign_to_32(d32, da, N)
+    assert np.array_equal(d32.download(), a64.astype(np.float32))
+    lat.assign_to_64(back, d32, N)
+    assert np.array_equal(back.download(), a64.astype(np.float32).astype(np.float64))
+    a32, b32 = a64.astype(np.float32).astype(np.float64), b64.astype(np.float32).astype(np.float64)
+    assert abs(lat.square_norm_32(d32, N) - (a32 ** 2).sum()) <= 1e-12 * (a32 ** 2).sum()     # double accumulation
+    assert abs(lat.scalar_prod_r_32(d32, db32, N) - (a32 * b32).sum()) <= 1e-10 * (a32 ** 2).sum()
+    lat.assign_add_mul_r_32(d32, db32, 0.5, N)
+    assert rel(d32.download().astype(np.float64), a32 + 0.5 * b32) < TOL32
+    lat.assign_mul_add_r_32(d32, -0.25, db32, N)
+    assert rel(d32.download().astype(np.float64), -0.25 * (a32 + 0.5 * b32) + b32) < TOL32
+    for f in (da, d32, db32, back):
+        f.free()
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_mixed_cg_her_reaches_fp64_residual(setup, fused):
+    orc, lat = setup
+    lat.set_option("cg_fused_dot", fused)
+    N = orc.Vh
+    q = random_spinor(4, N)
+    eps_sq = 1e-20
+    dq, dp = lat.field(q), lat.field()
+    it, outer = lat.mixed_cg_her(dp, dq, 5000, eps_sq, 1, N)
+    assert it > 0 and outer >= 2                  # fp32 alone cannot reach 1e-10: at least one fp64 restart
+    sol = dp.download()
+    full = orc.new_field(); full[:N] = sol
+    chk = orc.new_field(); orc.op("Qtm_pm_psi", chk, full)
+    res = ((chk[:N] - q) ** 2).sum() / (q ** 2).sum()
+    assert res <= eps_sq                          # true residual, fp64 on the CPU (operator.c:379-384)
+    P = orc.new_field(); it64, _ = orc.cg_her(P, q.copy(), 5000, eps_sq, 1, N)
+    assert rel(sol, P[:N]) < 1e-8
+    assert it < 2.0 * it64 + 20                   # same order of work as the fp64 CG
+    # same right-hand side through the fp64 solver on the GPU for reference
+    dp2 = lat.field(); it_gpu, _ = lat.cg_her(dp2, dq, 5000, eps_sq, 1, N)
+    assert rel(sol, dp2.download()) < 1e-8
+    lat.set_option("cg_fused_dot", 1)
+    for f in (dq, dp, dp2):
+        f.free()
+
+
+def test_mixed_cg_loose_tolerance_single_outer(setup):
+    orc, lat = setup
+    N = orc.Vh
+    dq, dp = lat.field(random_spinor(5, N)), lat.field()
+    it, outer = lat.mixed_cg_her(dp, dq, 5000, 1e-6, 1, N, innereps=1e-7)
+    assert it > 0 and outer == 1
+    dq.free(); dp.free()

@@ -11,6 +11,9 @@
 struct CgState {
   double normsq, pro, err, alpha, beta, squarenorm, eps_sq;
   int rel_prec, done, iters, it;
+  // inner loop of mixed_cg_her (mixed_cg_her.c:141): stop when err <= innereps * sqnrm_outer, after max_inner
+  // iterations, or when 1.3 err already meets the outer target
+  int inner; int max_inner; double innereps, sqnrm_outer;
 };
 
 __device__ __forceinline__ double cg_wave_reduce(double v) {
@@ -34,59 +37,64 @@ __device__ __forceinline__ void cg_block_reduce_store(double v, double *partials
 }
 
 // pro = <sf2, sf0>   (cg_her.c:93)
-__global__ __launch_bounds__(LA_BS) void cg_dot_kernel(const v2d *__restrict__ S, const v2d *__restrict__ R, int ns, int N,
+template <class V2>
+__global__ __launch_bounds__(LA_BS) void cg_dot_kernel(const V2 *__restrict__ S, const V2 *__restrict__ R, int ns, int N,
                                                        double *partials, const CgState *st) {
   if (st->done) return;
-  const v2d *s = S + (size_t)blockIdx.y * ns, *r = R + (size_t)blockIdx.y * ns;
+  const V2 *s = S + (size_t)blockIdx.y * ns, *r = R + (size_t)blockIdx.y * ns;
   double acc = 0.0;
   const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
 #pragma unroll
   for (int u = 0; u < LA_UNROLL; u++) {
     const int i = base + u * LA_BS;
-    if (i < N) { const v2d a = s[i], b = r[i]; acc += a.x * b.x + a.y * b.y; }
+    if (i < N) { const V2 a = s[i], b = r[i]; acc += (double)a.x * (double)b.x + (double)a.y * (double)b.y; }
   }
   cg_block_reduce_store(acc, partials);
 }
 
 // P += alpha sf2 ; sf0 = -alpha sf0 + sf1 ; partial |sf0|^2   (cg_her.c:95,101 fused: same bytes, one launch)
-__global__ __launch_bounds__(LA_BS) void cg_update_kernel(v2d *__restrict__ P, const v2d *__restrict__ SF2, v2d *__restrict__ SF0,
-                                                          const v2d *__restrict__ SF1, int ns, int N, double *partials,
+template <class V2>
+__global__ __launch_bounds__(LA_BS) void cg_update_kernel(V2 *__restrict__ P, const V2 *__restrict__ SF2, V2 *__restrict__ SF0,
+                                                          const V2 *__restrict__ SF1, int ns, int N, double *partials,
                                                           const CgState *st) {
   if (st->done) return;
-  const double alpha = st->alpha;
+  typedef decltype(V2{}.x) R;
+  const R alpha = (R)st->alpha;
   const size_t off = (size_t)blockIdx.y * ns;
-  v2d *p = P + off, *r0 = SF0 + off;
-  const v2d *s2 = SF2 + off, *r1 = SF1 + off;
+  V2 *p = P + off, *r0 = SF0 + off;
+  const V2 *s2 = SF2 + off, *r1 = SF1 + off;
   double acc = 0.0;
   const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
 #pragma unroll
   for (int u = 0; u < LA_UNROLL; u++) {
     const int i = base + u * LA_BS;
     if (i < N) {
-      const v2d a = p[i], b = s2[i];
-      p[i] = v2d{a.x + alpha * b.x, a.y + alpha * b.y};
-      v2d c = r0[i];
-      const v2d d = r1[i];
-      c = v2d{-alpha * c.x + d.x, -alpha * c.y + d.y};
+      const V2 a = p[i], b = s2[i];
+      p[i] = V2{a.x + alpha * b.x, a.y + alpha * b.y};
+      V2 c = r0[i];
+      const V2 d = r1[i];
+      c = V2{-alpha * c.x + d.x, -alpha * c.y + d.y};
       r0[i] = c;
-      acc += c.x * c.x + c.y * c.y;
+      acc += (double)c.x * (double)c.x + (double)c.y * (double)c.y;
     }
   }
   cg_block_reduce_store(acc, partials);
 }
 
 // sf2 = beta sf2 + sf0   (cg_her.c:122)
-__global__ __launch_bounds__(LA_BS) void cg_xpay_kernel(v2d *__restrict__ SF2, const v2d *__restrict__ SF0, int ns, int N,
+template <class V2>
+__global__ __launch_bounds__(LA_BS) void cg_xpay_kernel(V2 *__restrict__ SF2, const V2 *__restrict__ SF0, int ns, int N,
                                                         const CgState *st) {
   if (st->done) return;
-  const double beta = st->beta;
-  v2d *x = SF2 + (size_t)blockIdx.y * ns;
-  const v2d *y = SF0 + (size_t)blockIdx.y * ns;
+  typedef decltype(V2{}.x) R;
+  const R beta = (R)st->beta;
+  V2 *x = SF2 + (size_t)blockIdx.y * ns;
+  const V2 *y = SF0 + (size_t)blockIdx.y * ns;
   const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
 #pragma unroll
   for (int u = 0; u < LA_UNROLL; u++) {
     const int i = base + u * LA_BS;
-    if (i < N) { const v2d a = x[i], b = y[i]; x[i] = v2d{beta * a.x + b.x, beta * a.y + b.y}; }
+    if (i < N) { const V2 a = x[i], b = y[i]; x[i] = V2{beta * a.x + b.x, beta * a.y + b.y}; }
   }
 }
 
@@ -118,7 +126,12 @@ __global__ void cg_scalar_kernel(CgState *st, const double *sum, double *hist, i
     st->err = err;
     st->it += 1;
     if (hist && st->it - 1 < hist_len) hist[st->it - 1] = err;
-    const bool conv = ((err <= st->eps_sq) && (st->rel_prec == 0)) || ((err <= st->eps_sq * st->squarenorm) && (st->rel_prec == 1));
+    bool conv;
+    if (st->inner)
+      conv = (err <= st->innereps * st->sqnrm_outer) || (st->it - 1 == st->max_inner) ||
+             ((1.3 * err <= st->eps_sq) && (st->rel_prec == 0)) || ((1.3 * err <= st->eps_sq * st->squarenorm) && (st->rel_prec == 1));
+    else
+      conv = ((err <= st->eps_sq) && (st->rel_prec == 0)) || ((err <= st->eps_sq * st->squarenorm) && (st->rel_prec == 1));
     if (conv) { st->done = 1; st->iters = st->it; }
     else { st->beta = err / st->normsq; st->normsq = err; }
   }
@@ -215,16 +228,16 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
         if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, sf0->d, s1->d, s0->d, sf2->d, 1., mu, &ndot)) return 1;
       } else {
         if (tmhip_apply_op(ctx, op, sf0, sf2)) return 1;
-        hipLaunchKernelGGL(cg_dot_kernel, g, dim3(LA_BS), 0, ctx->stream, sf2->d, sf0->d, sf2->ns, N, ctx->partials, st);
+        hipLaunchKernelGGL(cg_dot_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, sf2->d, sf0->d, sf2->ns, N, ctx->partials, st);
       }
       hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ndot, sum, st);
       if (cg_allreduce(ctx, sum)) return 1;
       hipLaunchKernelGGL(cg_scalar_kernel<0>, dim3(1), dim3(1), 0, ctx->stream, st, sum, ctx->cg_hist, max_iter);
-      hipLaunchKernelGGL(cg_update_kernel, g, dim3(LA_BS), 0, ctx->stream, P->d, sf2->d, sf0->d, sf1->d, P->ns, N, ctx->partials, st);
+      hipLaunchKernelGGL(cg_update_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, P->d, sf2->d, sf0->d, sf1->d, P->ns, N, ctx->partials, st);
       hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblk, sum, st);
       if (cg_allreduce(ctx, sum)) return 1;
       hipLaunchKernelGGL(cg_scalar_kernel<1>, dim3(1), dim3(1), 0, ctx->stream, st, sum, ctx->cg_hist, max_iter);
-      hipLaunchKernelGGL(cg_xpay_kernel, g, dim3(LA_BS), 0, ctx->stream, sf2->d, sf0->d, sf2->ns, N, st);
+      hipLaunchKernelGGL(cg_xpay_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, sf2->d, sf0->d, sf2->ns, N, st);
       stmp = sf0; sf0 = sf1; sf1 = stmp;
     }
     enq += nb;
@@ -240,5 +253,97 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
     const int n = h.it < hist_len ? h.it : hist_len;
     if (n > 0) TMHIP_CHECK(hipMemcpy(res_hist, ctx->cg_hist, sizeof(double) * n, hipMemcpyDeviceToHost));
   }
+  return 0;
+}
+
+// ------------------------------------------------------------------ mixed precision
+/* solver/mixed_cg_her.c:65-202: fp32 inner CG on the defect equation until err <= innereps * |delta|^2, then the
+ * solution is accumulated and the defect recomputed in fp64 (x += x32; delta = Q - A x).  The inner loop is the
+ * device-resident loop of tmhip_cg_her instantiated for float2 fields with the stopping rule of :141. */
+extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N,
+                                  int op, double innereps, int max_inner_it, int *iters, int *outer_iters) {
+  if (!P || !Q || P->kind != TMHIP_FIELD_EO || Q->kind != TMHIP_FIELD_EO || P->prec || Q->prec) TMHIP_FAIL("mixed_cg_her needs fp64 one-parity fields");
+  if (N != ctx->Vh) TMHIP_FAIL("mixed_cg_her: N must be VOLUME/2");
+  if (op != TMHIP_OP_QTM_PM) TMHIP_FAIL("mixed_cg_her: only Qtm_pm_psi / Qtm_pm_psi_32 is available in fp32");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  if (tmhip_prepare_fp32(ctx)) return 1;
+  if (!ctx->cg_state) TMHIP_CHECK(hipMalloc(&ctx->cg_state, sizeof(CgState)));
+  CgState *st = (CgState *)ctx->cg_state;
+  int N_outer = max_iter / (max_inner_it > 0 ? max_inner_it : 1);
+  if (N_outer < 10) N_outer = 10;                                   /* mixed_cg_her.c:83-85 */
+  tmhip_field *delta = ctx->sf[0], *y = ctx->sf[1];
+  tmhip_field *x = ctx->sf32[3];
+  double sourcesquarenorm, sqnrm_d;
+  if (tmhip_square_norm(ctx, Q, N, 1, &sourcesquarenorm)) return 1;
+  sqnrm_d = sourcesquarenorm;
+  if (tmhip_assign(ctx, delta, Q, N)) return 1;
+  if (tmhip_field_zero(ctx, P)) return 1;
+  const dim3 g = la_grid(N);
+  const int nblk = g.x * g.y;
+  double *sum = ctx->result_dev + 1;
+  int *flag = (int *)(ctx->result_host + 2);
+  const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
+  const bool fused = ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && ctx->Vh % 256 == 0;
+  const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
+  int iter = 0;
+  for (int i = 0; i < N_outer; i++) {
+    tmhip_field *sf0 = ctx->sf32[0], *sf1 = ctx->sf32[1], *sf2 = ctx->sf32[2], *stmp;
+    if (tmhip_field_zero(ctx, x)) return 1;
+    if (tmhip_assign_to_32(ctx, sf1, delta, N)) return 1;
+    if (tmhip_assign_to_32(ctx, sf2, delta, N)) return 1;
+    CgState h;
+    memset(&h, 0, sizeof(h));
+    h.normsq = (double)(float)sqnrm_d; h.sqnrm_outer = h.normsq; h.squarenorm = sourcesquarenorm;
+    h.eps_sq = eps_sq; h.rel_prec = rel_prec; h.inner = 1; h.max_inner = max_inner_it; h.innereps = innereps;
+    TMHIP_CHECK(hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    int done = 0, enq = 0;
+    while (!done && enq <= max_inner_it) {
+      for (int b = 0; b < batch; b++) {
+        int ndot = nblk;
+        v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
+        if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, sf2->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
+        if (tmhip_launch_hopping32(ctx, TMHIP_OE, s0, s1, sf2->d32, EPI_TM_SUB_G5, 1., -mu, true)) return 1;
+        if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true)) return 1;
+        if (fused) {
+          if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, sf0->d32, s1, s0, sf2->d32, 1., mu, &ndot)) return 1;
+        } else {
+          if (tmhip_launch_hopping32(ctx, TMHIP_OE, sf0->d32, s1, s0, EPI_TM_SUB_G5, 1., mu, true)) return 1;
+          hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, ctx->partials, st);
+        }
+        hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ndot, sum, st);
+        if (cg_allreduce(ctx, sum)) return 1;
+        hipLaunchKernelGGL(cg_scalar_kernel<0>, dim3(1), dim3(1), 0, ctx->stream, st, sum, (double *)nullptr, 0);
+        hipLaunchKernelGGL(cg_update_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, x->d32, (const v2f *)sf2->d32, sf0->d32, (const v2f *)sf1->d32,
+                           x->ns, N, ctx->partials, st);
+        hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblk, sum, st);
+        if (cg_allreduce(ctx, sum)) return 1;
+        hipLaunchKernelGGL(cg_scalar_kernel<1>, dim3(1), dim3(1), 0, ctx->stream, st, sum, (double *)nullptr, 0);
+        hipLaunchKernelGGL(cg_xpay_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, st);
+        stmp = sf0; sf0 = sf1; sf1 = stmp;
+      }
+      enq += batch;
+      TMHIP_CHECK(hipGetLastError());
+      TMHIP_CHECK(hipMemcpyAsync(flag, &st->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+      done = *flag;
+    }
+    TMHIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (!h.done) TMHIP_FAIL("mixed_cg_her: inner loop did not terminate");
+    iter += h.iters - 1;                                             /* "iter += j" with j = completed iterations - 1 */
+    /* defect in double precision (mixed_cg_her.c:157-162) */
+    if (tmhip_add_from_32(ctx, P, x, N)) return 1;
+    if (tmhip_apply_op(ctx, op, y, P)) return 1;
+    if (tmhip_diff(ctx, delta, Q, y, N)) return 1;
+    if (tmhip_square_norm(ctx, delta, N, 1, &sqnrm_d)) return 1;
+    if (((sqnrm_d <= eps_sq) && (rel_prec == 0)) || ((sqnrm_d <= eps_sq * sourcesquarenorm) && (rel_prec == 1))) {
+      *iters = iter + i;
+      if (outer_iters) *outer_iters = i + 1;
+      return 0;
+    }
+    iter++;
+  }
+  *iters = -1;
+  if (outer_iters) *outer_iters = N_outer;
   return 0;
 }

@@ -83,17 +83,24 @@ int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes) {
   return 0;
 }
 
-static int field_alloc_impl(tmhip_ctx *ctx, int kind, tmhip_field **out) {
+int tmhip_field_alloc_prec(tmhip_ctx *ctx, int kind, int prec, tmhip_field **out) {
   tmhip_field *f = new (std::nothrow) tmhip_field();
   if (!f) TMHIP_FAIL("out of host memory");
-  f->kind = kind; f->ns = ctx->ns; f->view = false; f->half[0] = f->half[1] = nullptr; f->d = nullptr;
+  f->kind = kind; f->prec = prec; f->ns = ctx->ns; f->view = false; f->half[0] = f->half[1] = nullptr; f->d = nullptr; f->d32 = nullptr;
   const size_t elems = (size_t)12 * ctx->ns * (kind == TMHIP_FIELD_FULL ? 2 : 1);
+  if (prec) {
+    if (kind != TMHIP_FIELD_EO) TMHIP_FAIL("fp32 fields are one-parity fields");
+    TMHIP_CHECK(hipMalloc((void **)&f->d32, elems * sizeof(v2f)));
+    TMHIP_CHECK(hipMemsetAsync(f->d32, 0, elems * sizeof(v2f), ctx->stream));
+    *out = f;
+    return 0;
+  }
   TMHIP_CHECK(hipMalloc((void **)&f->d, elems * sizeof(v2d)));
   TMHIP_CHECK(hipMemsetAsync(f->d, 0, elems * sizeof(v2d), ctx->stream));
   if (kind == TMHIP_FIELD_FULL) {
     for (int p = 0; p < 2; p++) {
       tmhip_field *h = new tmhip_field();
-      h->kind = TMHIP_FIELD_EO; h->ns = ctx->ns; h->view = true; h->half[0] = h->half[1] = nullptr;
+      h->kind = TMHIP_FIELD_EO; h->prec = 0; h->d32 = nullptr; h->ns = ctx->ns; h->view = true; h->half[0] = h->half[1] = nullptr;
       h->d = f->d + (size_t)p * 12 * ctx->ns;
       f->half[p] = h;
     }
@@ -101,6 +108,7 @@ static int field_alloc_impl(tmhip_ctx *ctx, int kind, tmhip_field **out) {
   *out = f;
   return 0;
 }
+static int field_alloc_impl(tmhip_ctx *ctx, int kind, tmhip_field **out) { return tmhip_field_alloc_prec(ctx, kind, 0, out); }
 
 extern "C" {
 
@@ -170,6 +178,9 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   for (int i = 0; i < 3; i++) { tmhip_field_free(ctx, ctx->scratch[i]); tmhip_field_free(ctx, ctx->sf[i]); }
+  for (int i = 0; i < 2; i++) tmhip_field_free(ctx, ctx->scratch32[i]);
+  for (int i = 0; i < 4; i++) tmhip_field_free(ctx, ctx->sf32[i]);
+  if (ctx->gauge32) (void)hipFree(ctx->gauge32);
   if (ctx->comm_ready) ncclCommDestroy(ctx->comm);
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
@@ -251,6 +262,7 @@ int tmhip_set_gauge(tmhip_ctx *ctx, const void *host) {
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   TMHIP_CHECK(hipFree(raw));
   ctx->gauge_set = true;
+  ctx->gauge32_set = false;  // the fp32 twin is rebuilt lazily from the new links
   return 0;
 }
 
@@ -264,7 +276,8 @@ int tmhip_field_alloc(tmhip_ctx *ctx, int kind, tmhip_field **out) {
 void tmhip_field_free(tmhip_ctx *ctx, tmhip_field *f) {
   if (!f || f->view) return;
   (void)ctx;
-  (void)hipFree(f->d);
+  if (f->d) (void)hipFree(f->d);
+  if (f->d32) (void)hipFree(f->d32);
   if (f->half[0]) delete f->half[0];
   if (f->half[1]) delete f->half[1];
   delete f;
@@ -275,7 +288,8 @@ tmhip_field *tmhip_field_odd(tmhip_field *full) { return (full && full->kind == 
 
 int tmhip_field_zero(tmhip_ctx *ctx, tmhip_field *f) {
   const size_t elems = (size_t)12 * f->ns * (f->kind == TMHIP_FIELD_FULL ? 2 : 1);
-  TMHIP_CHECK(hipMemsetAsync(f->d, 0, elems * sizeof(v2d), ctx->stream));
+  if (f->prec) TMHIP_CHECK(hipMemsetAsync(f->d32, 0, elems * sizeof(v2f), ctx->stream));
+  else TMHIP_CHECK(hipMemsetAsync(f->d, 0, elems * sizeof(v2d), ctx->stream));
   return 0;
 }
 
@@ -319,7 +333,7 @@ int tmhip_field_download(tmhip_ctx *ctx, tmhip_field *f, void *host, int nsites)
 
 // ------------------------------------------------------------------ stencil entry points
 static int need_eo(const tmhip_field *f, const char *who) {
-  if (!f || f->kind != TMHIP_FIELD_EO) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity (EO) field\n", who); return 1; }
+  if (!f || f->kind != TMHIP_FIELD_EO || f->prec != 0) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity (EO) field\n", who); return 1; }
   return 0;
 }
 

@@ -21,6 +21,8 @@ extern su3 **g_gauge_field;                                       /* global.h:17
 extern int g_update_gauge_copy;                                   /* global.h:73  */
 extern double g_mu;                                               /* global.h:198 */
 extern TM_COMPLEX ka0, ka1, ka2, ka3;                             /* boundary.h:25 */
+extern double mixcg_innereps __attribute__((weak));               /* read_input.h:112 (only needed by mixed_cg_her) */
+extern int mixcg_maxinnersolverit __attribute__((weak));          /* read_input.h:113 */
 // Present in a full tmLQCD link (update_backward_gauge.c, libhmc.a); refreshes the HOST gauge
 // copy that deriv_Sb.c:405-408,472 still reads, and clears g_update_gauge_copy.
 void update_backward_gauge(su3 **const gf) __attribute__((weak));
@@ -513,6 +515,22 @@ int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, 
   g_mode = saved;
   if (iteration > max_iter) return -1;
   return iteration;
+}
+
+/* solver/mixed_cg_her.c:65-202 with f = Qtm_pm_psi: fp32 inner CG + fp64 defect correction, all in HBM */
+int mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params_opaque, const int max_iter, double eps_sq,
+                 const int rel_prec, const int N, matrix_mult f, matrix_mult32) {
+  if (f != &Qtm_pm_psi || N != VOLUME / 2) die("mixed_cg_her: only f = Qtm_pm_psi on VOLUME/2 sites runs on the device");
+  const double innereps = &mixcg_innereps ? mixcg_innereps : 5.0e-5;           /* default_input_values.h:193 */
+  const int max_inner = &mixcg_maxinnersolverit ? mixcg_maxinnersolverit : 5000; /* default_input_values.h:194 */
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fq = in(c, Q, TMHIP_FIELD_EO), *fp = out(c, P, TMHIP_FIELD_EO);
+  int iters = -1, outer = 0;
+  CK(tmhip_mixed_cg_her(c, fp, fq, max_iter, eps_sq, rel_prec, N, TMHIP_OP_QTM_PM, innereps, max_inner, &iters, &outer));
+  Mirror &m = g_reg[P];
+  m.dev_valid = true; m.host_valid = false;
+  download(c, P, m);
+  return iters;
 }
 
 // ------------------------------------------------------------------ benchmark helper

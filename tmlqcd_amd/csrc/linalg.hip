@@ -141,7 +141,7 @@ __global__ __launch_bounds__(LA_BS) void diag_kernel(v2d *L, const v2d *K, const
 
 
 static int check_eo(const tmhip_field *f, const char *who) {
-  if (!f || f->kind != TMHIP_FIELD_EO) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity (EO) field\n", who); return 1; }
+  if (!f || f->kind != TMHIP_FIELD_EO || f->prec != 0) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity (EO) field\n", who); return 1; }
   return 0;
 }
 

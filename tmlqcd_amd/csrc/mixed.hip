@@ -1,0 +1,225 @@
+// fp32 twins of the hot path for the mixed-precision CG:
+//   Hopping_Matrix_32 / Qtm_pm_psi_32        operator/Hopping_Matrix_32.c:97-127, operator/tm_operators_32.c
+//   assign_to_32 / assign_to_64              linalg/assign_to_32.c, assign_to_64.c
+//   square_norm_32, scalar_prod_r_32, assign_add_mul_r_32, assign_mul_add_r_32   linalg/*_32.c
+// Same SoA layout as the fp64 fields with float2 elements (96 B/site); the stencil is the fp64 kernel
+// instantiated for float2 (hopping_impl.inc).  Reductions accumulate in double.
+#include "tmhip_internal.h"
+
+template <class VD, class VS>
+__global__ __launch_bounds__(LA_BS) void convert_kernel(VD *__restrict__ D, const VS *__restrict__ S, int ns, int N) {
+  typedef decltype(VD{}.x) RD;
+  VD *d = D + (size_t)blockIdx.y * ns;
+  const VS *s = S + (size_t)blockIdx.y * ns;
+  const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < LA_UNROLL; u++) {
+    const int i = base + u * LA_BS;
+    if (i < N) { const VS a = s[i]; d[i] = VD{(RD)a.x, (RD)a.y}; }
+  }
+}
+
+// P += (double) x      (assign_to_64 + add of mixed_cg_her.c:158-159 in one pass)
+__global__ __launch_bounds__(LA_BS) void add_from32_kernel(v2d *__restrict__ P, const v2f *__restrict__ X, int ns, int N) {
+  v2d *p = P + (size_t)blockIdx.y * ns;
+  const v2f *x = X + (size_t)blockIdx.y * ns;
+  const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < LA_UNROLL; u++) {
+    const int i = base + u * LA_BS;
+    if (i < N) { const v2f a = x[i]; v2d b = p[i]; p[i] = v2d{b.x + (double)a.x, b.y + (double)a.y}; }
+  }
+}
+
+__global__ void gauge_to32_kernel(v2f *__restrict__ d, const v2d *__restrict__ s, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const v2d a = s[i]; d[i] = v2f{(float)a.x, (float)a.y}; }
+}
+
+__device__ __forceinline__ void block_reduce_store32(double v, double *partials) {
+  __shared__ double wsum[LA_BS / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < LA_BS / 64; k++) s += wsum[k];
+    partials[blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// MODE 0: |S|^2   1: Re<S,R>
+template <int MODE>
+__global__ __launch_bounds__(LA_BS) void reduce32_kernel(const v2f *__restrict__ S, const v2f *__restrict__ R, int ns, int N,
+                                                         double *partials) {
+  const v2f *s = S + (size_t)blockIdx.y * ns;
+  const v2f *r = MODE ? R + (size_t)blockIdx.y * ns : nullptr;
+  double acc = 0.0;
+  const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < LA_UNROLL; u++) {
+    const int i = base + u * LA_BS;
+    if (i < N) {
+      const v2f a = s[i];
+      if (MODE == 0) acc += (double)a.x * a.x + (double)a.y * a.y;
+      else { const v2f b = r[i]; acc += (double)a.x * b.x + (double)a.y * b.y; }
+    }
+  }
+  block_reduce_store32(acc, partials);
+}
+
+// MODE 0: P += c Q   1: R = c R + S
+template <int MODE>
+__global__ __launch_bounds__(LA_BS) void stream32_kernel(v2f *__restrict__ X, const v2f *__restrict__ Y, float c, int ns, int N) {
+  v2f *x = X + (size_t)blockIdx.y * ns;
+  const v2f *y = Y + (size_t)blockIdx.y * ns;
+  const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < LA_UNROLL; u++) {
+    const int i = base + u * LA_BS;
+    if (i < N) {
+      const v2f a = x[i], b = y[i];
+      x[i] = MODE == 0 ? v2f{a.x + c * b.x, a.y + c * b.y} : v2f{c * a.x + b.x, c * a.y + b.y};
+    }
+  }
+}
+
+// host spinor32[n] (float AoS) <-> device SoA float2
+__global__ __launch_bounds__(256) void aos_to_soa32_kernel(const v2f *__restrict__ aos, v2f *__restrict__ soa, int ns, int n) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (tid >= 12L * n) return;
+  soa[(size_t)(tid % 12) * ns + tid / 12] = aos[tid];
+}
+__global__ __launch_bounds__(256) void soa_to_aos32_kernel(const v2f *__restrict__ soa, v2f *__restrict__ aos, int ns, int n) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (tid >= 12L * n) return;
+  aos[tid] = soa[(size_t)(tid % 12) * ns + tid / 12];
+}
+
+static int need32(const tmhip_field *f, const char *who) {
+  if (!f || f->kind != TMHIP_FIELD_EO || f->prec != 1) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity fp32 field\n", who); return 1; }
+  return 0;
+}
+static int need64(const tmhip_field *f, const char *who) {
+  if (!f || f->kind != TMHIP_FIELD_EO || f->prec != 0) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity fp64 field\n", who); return 1; }
+  return 0;
+}
+
+int tmhip_prepare_fp32(tmhip_ctx *ctx) {
+  if (!ctx->gauge_set) TMHIP_FAIL("fp32 operators called before tmhip_set_gauge");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  const size_t n = (size_t)2 * 72 * ctx->gs;
+  if (!ctx->gauge32) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge32, n * sizeof(v2f)));
+  if (!ctx->gauge32_set) {  // g_gauge_field_32 / copy_32: converted from the fp64 links (update_backward_gauge.c:244-312)
+    hipLaunchKernelGGL(gauge_to32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->gauge32, ctx->gauge, n);
+    TMHIP_CHECK(hipGetLastError());
+    ctx->gauge32_set = true;
+  }
+  for (int i = 0; i < 2; i++) if (!ctx->scratch32[i] && tmhip_field_alloc_prec(ctx, TMHIP_FIELD_EO, 1, &ctx->scratch32[i])) return 1;
+  for (int i = 0; i < 4; i++) if (!ctx->sf32[i] && tmhip_field_alloc_prec(ctx, TMHIP_FIELD_EO, 1, &ctx->sf32[i])) return 1;
+  return 0;
+}
+
+extern "C" {
+
+int tmhip_field_alloc32(tmhip_ctx *ctx, tmhip_field **out) {
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  return tmhip_field_alloc_prec(ctx, TMHIP_FIELD_EO, 1, out);
+}
+
+int tmhip_field_upload32(tmhip_ctx *ctx, tmhip_field *f, const void *host, int nsites) {
+  if (need32(f, "tmhip_field_upload32") || !host) return 1;
+  if (nsites <= 0 || nsites > ctx->Vh) TMHIP_FAIL("tmhip_field_upload32: nsites out of range");
+  const size_t bytes = (size_t)nsites * 12 * sizeof(v2f);
+  if (tmhip_stage_reserve(ctx, bytes)) return 1;
+  TMHIP_CHECK(hipMemcpyAsync(ctx->stage, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(aos_to_soa32_kernel, dim3((unsigned)((12L * nsites + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const v2f *)ctx->stage, f->d32, f->ns, nsites);
+  TMHIP_CHECK(hipGetLastError());
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int tmhip_field_download32(tmhip_ctx *ctx, tmhip_field *f, void *host, int nsites) {
+  if (need32(f, "tmhip_field_download32") || !host) return 1;
+  if (nsites <= 0 || nsites > ctx->Vh) TMHIP_FAIL("tmhip_field_download32: nsites out of range");
+  const size_t bytes = (size_t)nsites * 12 * sizeof(v2f);
+  if (tmhip_stage_reserve(ctx, bytes)) return 1;
+  hipLaunchKernelGGL(soa_to_aos32_kernel, dim3((unsigned)((12L * nsites + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const v2f *)f->d32, (v2f *)ctx->stage, f->ns, nsites);
+  TMHIP_CHECK(hipGetLastError());
+  TMHIP_CHECK(hipMemcpyAsync(host, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+/* linalg/assign_to_32.c */
+int tmhip_assign_to_32(tmhip_ctx *ctx, tmhip_field *R32, tmhip_field *S64, int N) {
+  if (need32(R32, "assign_to_32") || need64(S64, "assign_to_32")) return 1;
+  hipLaunchKernelGGL((convert_kernel<v2f, v2d>), la_grid(N), dim3(LA_BS), 0, ctx->stream, R32->d32, (const v2d *)S64->d, R32->ns, N);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+/* linalg/assign_to_64.c */
+int tmhip_assign_to_64(tmhip_ctx *ctx, tmhip_field *R64, tmhip_field *S32, int N) {
+  if (need64(R64, "assign_to_64") || need32(S32, "assign_to_64")) return 1;
+  hipLaunchKernelGGL((convert_kernel<v2d, v2f>), la_grid(N), dim3(LA_BS), 0, ctx->stream, R64->d, (const v2f *)S32->d32, R64->ns, N);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+int tmhip_add_from_32(tmhip_ctx *ctx, tmhip_field *P64, tmhip_field *X32, int N) {
+  if (need64(P64, "add_from_32") || need32(X32, "add_from_32")) return 1;
+  hipLaunchKernelGGL(add_from32_kernel, la_grid(N), dim3(LA_BS), 0, ctx->stream, P64->d, (const v2f *)X32->d32, P64->ns, N);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* linalg/square_norm_32.c, scalar_prod_r_32.c (double accumulation) */
+int tmhip_square_norm_32(tmhip_ctx *ctx, tmhip_field *P, int N, int parallel, double *out) {
+  if (need32(P, "square_norm_32")) return 1;
+  const dim3 g = la_grid(N);
+  hipLaunchKernelGGL(reduce32_kernel<0>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)P->d32, (const v2f *)nullptr, P->ns, N, ctx->partials);
+  return tmhip_reduce_finish(ctx, g.x * g.y, parallel, out);
+}
+int tmhip_scalar_prod_r_32(tmhip_ctx *ctx, tmhip_field *S, tmhip_field *R, int N, int parallel, double *out) {
+  if (need32(S, "scalar_prod_r_32") || need32(R, "scalar_prod_r_32")) return 1;
+  const dim3 g = la_grid(N);
+  hipLaunchKernelGGL(reduce32_kernel<1>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)S->d32, (const v2f *)R->d32, S->ns, N, ctx->partials);
+  return tmhip_reduce_finish(ctx, g.x * g.y, parallel, out);
+}
+/* linalg/assign_add_mul_r_32.c, assign_mul_add_r_32.c */
+int tmhip_assign_add_mul_r_32(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, float c, int N) {
+  if (need32(P, "assign_add_mul_r_32") || need32(Q, "assign_add_mul_r_32")) return 1;
+  hipLaunchKernelGGL(stream32_kernel<0>, la_grid(N), dim3(LA_BS), 0, ctx->stream, P->d32, (const v2f *)Q->d32, c, P->ns, N);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+int tmhip_assign_mul_add_r_32(tmhip_ctx *ctx, tmhip_field *R, float c, tmhip_field *S, int N) {
+  if (need32(R, "assign_mul_add_r_32") || need32(S, "assign_mul_add_r_32")) return 1;
+  hipLaunchKernelGGL(stream32_kernel<1>, la_grid(N), dim3(LA_BS), 0, ctx->stream, R->d32, (const v2f *)S->d32, c, R->ns, N);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* operator/Hopping_Matrix_32.c:97-127 */
+int tmhip_hopping_matrix_32(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k) {
+  if (need32(l, "Hopping_Matrix_32") || need32(k, "Hopping_Matrix_32")) return 1;
+  if (tmhip_prepare_fp32(ctx)) return 1;
+  return tmhip_launch_hopping32(ctx, ieo, l->d32, k->d32, nullptr, EPI_STORE, 0, 0, true);
+}
+
+/* operator/tm_operators_32.c Qtm_pm_psi_32: same algebra as Qtm_pm_psi, twists fused into the stencil epilogues */
+int tmhip_Qtm_pm_psi_32(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (need32(l, "Qtm_pm_psi_32") || need32(k, "Qtm_pm_psi_32")) return 1;
+  if (tmhip_prepare_fp32(ctx)) return 1;
+  const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
+  v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
+  return tmhip_launch_hopping32(ctx, TMHIP_EO, s1, k->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true) ||
+         tmhip_launch_hopping32(ctx, TMHIP_OE, s0, s1, k->d32, EPI_TM_SUB_G5, 1., -mu, true) ||
+         tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true) ||
+         tmhip_launch_hopping32(ctx, TMHIP_OE, l->d32, s1, s0, EPI_TM_SUB_G5, 1., mu, true);
+}
+
+}  // extern "C"

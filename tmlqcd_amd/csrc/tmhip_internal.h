@@ -13,6 +13,7 @@
 #include "../../include/tmlqcd_hip.h"
 
 typedef double v2d __attribute__((ext_vector_type(2)));  // one complex double: .x = re, .y = im
+typedef float v2f __attribute__((ext_vector_type(2)));   // one complex float (mixed-precision CG)
 
 #define TMHIP_CHECK(expr)                                                                           \
   do {                                                                                              \
@@ -43,6 +44,8 @@ typedef double v2d __attribute__((ext_vector_type(2)));  // one complex double: 
 
 struct tmhip_field {
   int kind;            // TMHIP_FIELD_EO | TMHIP_FIELD_FULL
+  int prec;            // 0: fp64 (d), 1: fp32 (d32; `spinor32` of su3.h:65-68), EO only
+  v2f *d32;
   v2d *d;              // EO: [12][ns]; FULL: even half then odd half, each [12][ns]
   int ns;              // site stride of one parity
   bool view;           // true for the even/odd views of a FULL field
@@ -62,6 +65,8 @@ struct tmhip_ctx {
   hipEvent_t ev_pack, ev_comm, ev_slots[16];
   v2d *gauge;          // [2][8][9][gs]
   bool gauge_set;
+  v2f *gauge32;        // fp32 twin of the gauge copy (g_gauge_field_copy_32), built on first use
+  bool gauge32_set;
   // staging for host<->device layout conversion
   void *stage; size_t stage_bytes;
   // reductions
@@ -70,6 +75,9 @@ struct tmhip_ctx {
   tmhip_field *scratch[3];
   // solver work fields
   tmhip_field *sf[3];
+  // fp32 twins for the mixed-precision CG (allocated on first use): scratch32 = g_spinor_field32[0..1]
+  // (tm_operators_32.c Qtm_pm_psi_32), sf32 = solver_field32[0..3] (mixed_cg_her.c:72-102)
+  tmhip_field *scratch32[2]; tmhip_field *sf32[4];
   // halo exchange
   ncclComm_t comm; bool comm_ready; bool loopback; bool loopback_rccl;
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
@@ -86,10 +94,16 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
                          double cre, double cim, bool comm);
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
                              double cre, double cim, int *npartials);
+int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
+                           double cre, double cim, bool comm);
+int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
+                               double cre, double cim, int *npartials);
 int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out);
 int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes);
+int tmhip_field_alloc_prec(tmhip_ctx *ctx, int kind, int prec, tmhip_field **out);
 int tmhip_halo_exchange(tmhip_ctx *ctx);
 int tmhip_apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k);
+int tmhip_prepare_fp32(tmhip_ctx *ctx);  // fp32 gauge copy + fp32 scratch / solver fields
 // launch geometry shared by linalg.hip and cg.hip
 #define LA_BS 256
 #define LA_UNROLL 4

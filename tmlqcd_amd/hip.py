@@ -75,6 +75,19 @@ def load_library():
         "tmhip_diff": [vp, vp, vp, vp, i],
         "tmhip_assign": [vp, vp, vp, i],
         "tmhip_cg_her": [vp, vp, vp, i, d, i, i, i, C.POINTER(i), pd, i],
+        "tmhip_field_alloc32": [vp, C.POINTER(vp)],
+        "tmhip_field_upload32": [vp, vp, vp, i],
+        "tmhip_field_download32": [vp, vp, vp, i],
+        "tmhip_assign_to_32": [vp, vp, vp, i],
+        "tmhip_assign_to_64": [vp, vp, vp, i],
+        "tmhip_add_from_32": [vp, vp, vp, i],
+        "tmhip_hopping_matrix_32": [vp, i, vp, vp],
+        "tmhip_Qtm_pm_psi_32": [vp, vp, vp],
+        "tmhip_square_norm_32": [vp, vp, i, i, pd],
+        "tmhip_scalar_prod_r_32": [vp, vp, vp, i, i, pd],
+        "tmhip_assign_add_mul_r_32": [vp, vp, vp, C.c_float, i],
+        "tmhip_assign_mul_add_r_32": [vp, vp, C.c_float, vp, i],
+        "tmhip_mixed_cg_her": [vp, vp, vp, i, d, i, i, i, d, i, C.POINTER(i), C.POINTER(i)],
         "tmhip_comm_get_unique_id": [C.c_char_p],
         "tmhip_comm_init": [vp, C.c_char_p],
         "tmhip_comm_set_loopback": [vp, i],
@@ -114,23 +127,35 @@ def _hp(a):
 
 
 class Field:
-    """A device-resident spinor field (opaque handle)."""
+    """A device-resident spinor field (opaque handle); prec 32 = the reference's spinor32."""
 
-    def __init__(self, lat, kind=FIELD_EO, handle=None, owner=True):
-        self.lat, self.kind, self.owner = lat, kind, owner
+    def __init__(self, lat, kind=FIELD_EO, handle=None, owner=True, prec=64):
+        self.lat, self.kind, self.owner, self.prec = lat, kind, owner, prec
         if handle is None:
             h = C.c_void_p()
-            _ck(lat.lib.tmhip_field_alloc(lat.h, kind, C.byref(h)), "tmhip_field_alloc")
+            if prec == 32:
+                _ck(lat.lib.tmhip_field_alloc32(lat.h, C.byref(h)), "tmhip_field_alloc32")
+            else:
+                _ck(lat.lib.tmhip_field_alloc(lat.h, kind, C.byref(h)), "tmhip_field_alloc")
             handle = h
         self.h = handle
 
     def upload(self, host, nsites=None):
         nsites = nsites if nsites is not None else (self.lat.V if self.kind == FIELD_FULL else self.lat.Vh)
+        if self.prec == 32:
+            if host.dtype != np.float32 or not host.flags["C_CONTIGUOUS"]:
+                raise TmHipError("fp32 fields take C-contiguous float32 arrays")
+            _ck(self.lat.lib.tmhip_field_upload32(self.lat.h, self.h, host.ctypes.data_as(C.c_void_p), nsites), "tmhip_field_upload32")
+            return self
         _ck(self.lat.lib.tmhip_field_upload(self.lat.h, self.h, _hp(host), nsites), "tmhip_field_upload")
         return self
 
     def download(self, nsites=None):
         nsites = nsites if nsites is not None else (self.lat.V if self.kind == FIELD_FULL else self.lat.Vh)
+        if self.prec == 32:
+            out = np.empty((nsites, 4, 3, 2), dtype=np.float32)
+            _ck(self.lat.lib.tmhip_field_download32(self.lat.h, self.h, out.ctypes.data_as(C.c_void_p), nsites), "tmhip_field_download32")
+            return out
         out = np.empty((nsites, 4, 3, 2), dtype=np.float64)
         _ck(self.lat.lib.tmhip_field_download(self.lat.h, self.h, _hp(out), nsites), "tmhip_field_download")
         return out
@@ -209,6 +234,48 @@ class Lattice:
 
     def full_field(self, host=None):
         return self.field(host, FIELD_FULL)
+
+    def field32(self, host=None):
+        f = Field(self, FIELD_EO, prec=32)
+        if host is not None:
+            f.upload(host, host.shape[0])
+        return f
+
+    # --- mixed precision (reference names with the _32 suffix) -------------
+    def assign_to_32(self, r32, s64, N):
+        _ck(self.lib.tmhip_assign_to_32(self.h, r32.h, s64.h, N), "assign_to_32")
+
+    def assign_to_64(self, r64, s32, N):
+        _ck(self.lib.tmhip_assign_to_64(self.h, r64.h, s32.h, N), "assign_to_64")
+
+    def Hopping_Matrix_32(self, ieo, l, k):
+        _ck(self.lib.tmhip_hopping_matrix_32(self.h, ieo, l.h, k.h), "Hopping_Matrix_32")
+
+    def Qtm_pm_psi_32(self, l, k):
+        _ck(self.lib.tmhip_Qtm_pm_psi_32(self.h, l.h, k.h), "Qtm_pm_psi_32")
+
+    def square_norm_32(self, P, N, parallel=0):
+        out = C.c_double()
+        _ck(self.lib.tmhip_square_norm_32(self.h, P.h, N, parallel, C.byref(out)), "square_norm_32")
+        return out.value
+
+    def scalar_prod_r_32(self, S, R, N, parallel=0):
+        out = C.c_double()
+        _ck(self.lib.tmhip_scalar_prod_r_32(self.h, S.h, R.h, N, parallel, C.byref(out)), "scalar_prod_r_32")
+        return out.value
+
+    def assign_add_mul_r_32(self, P, Q, c, N):
+        _ck(self.lib.tmhip_assign_add_mul_r_32(self.h, P.h, Q.h, c, N), "assign_add_mul_r_32")
+
+    def assign_mul_add_r_32(self, R, c, S, N):
+        _ck(self.lib.tmhip_assign_mul_add_r_32(self.h, R.h, c, S.h, N), "assign_mul_add_r_32")
+
+    def mixed_cg_her(self, P, Q, max_iter, eps_sq, rel_prec, N, innereps=5.0e-5, max_inner_it=5000):
+        """solver/mixed_cg_her.c with f = Qtm_pm_psi, f32 = Qtm_pm_psi_32; returns (iterations, outer iterations)."""
+        it, outer = C.c_int(), C.c_int()
+        _ck(self.lib.tmhip_mixed_cg_her(self.h, P.h, Q.h, max_iter, eps_sq, rel_prec, N, OPS["Qtm_pm_psi"], innereps,
+                                        max_inner_it, C.byref(it), C.byref(outer)), "mixed_cg_her")
+        return it.value, outer.value
 
     # --- stencil ----------------------------------------------------------
     def Hopping_Matrix(self, ieo, l, k):
