@@ -27,6 +27,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--L", type=int, default=32, help="spatial extent")
     ap.add_argument("--T", type=int, default=0, help="local time extent (default = L)")
+    ap.add_argument("--strong", type=int, default=0, metavar="TGLOBAL",
+                    help="strong scaling: fixed global lattice TGLOBAL x L^3 split in T over the ranks "
+                         "(BASELINE configs[3]: --strong 64); default is weak scaling with L^4 per GPU")
     ap.add_argument("--cg-iters", type=int, default=200, help="cg_her iterations timed for the CG part of the metric")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU-baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(available cores, 16)")
@@ -120,6 +123,10 @@ def main():
 
     L = args.L
     T = args.T or L
+    if args.strong:
+        if args.strong % world or (args.strong // world) % 2:
+            raise SystemExit("--strong %d cannot be split evenly (even local T) over %d ranks" % (args.strong, world))
+        T = args.strong // world
     nproc_t = world
     V = T * L ** 3
     lat = Lattice(T, L, L, L, kappa=0.125, mu=0.01, nproc_t=nproc_t, proc_t=rank, device=local_rank)
@@ -212,7 +219,7 @@ def main():
         out = {
             "metric": "Hopping_Matrix Mflop/s per site (benchmark.c) + CG iters/sec, 32^4 fp64",
             "value": mflops, "unit": "Mflop/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "benchmark.c loop {Hopping_Matrix(0);Hopping_Matrix(1)}, local lattice %dx%d^3 per GPU, "
                                    "global %dx%d^3, fp64, kappa=0.125, periodic, random SU(3) gauge + Gaussian spinor"

@@ -42,6 +42,8 @@ int g_device = -1;
 int g_mode = TMLQCD_HIP_COHERENT;
 int g_dims[6] = {0, 0, 0, 0, 0, 0};
 std::unordered_map<const void *, Mirror> g_reg;
+bool g_gauge_uploaded = false;   // the current context holds a gauge copy
+tmhip_field *g_full_tmp = nullptr; // FULL-lattice scratch of Q_pm_psi / D_dagg_psi (tm_operators.c:380-397)
 
 [[noreturn]] void die(const char *what) {
   fprintf(stderr, "[tmlqcd_dropin] fatal: %s\n", what);
@@ -73,12 +75,11 @@ tmhip_ctx *refresh(bool need_gauge) {
                         __real__ ka2, __imag__ ka2, __real__ ka3, __imag__ ka3};
   CK(tmhip_set_ka(c, ka));
   CK(tmhip_set_mu(c, g_mu));
-  static bool gauge_uploaded = false;
-  if (need_gauge && (g_update_gauge_copy || !gauge_uploaded)) {   /* Hopping_Matrix.c:135-139 */
+  if (need_gauge && (g_update_gauge_copy || !g_gauge_uploaded)) {   /* Hopping_Matrix.c:135-139 */
     if (update_backward_gauge) update_backward_gauge(g_gauge_field);  // host copy + flag, as the reference
     else g_update_gauge_copy = 0;
     CK(tmhip_set_gauge(c, &g_gauge_field[0][0]));
-    gauge_uploaded = true;
+    g_gauge_uploaded = true;
   }
   return c;
 }
@@ -168,8 +169,10 @@ void tmlqcd_hip_finalize(void) {
   tmlqcd_hip_sync_all_to_host();
   for (auto &kv : g_reg) if (kv.second.f) tmhip_field_free(g_ctx, kv.second.f);
   g_reg.clear();
+  if (g_full_tmp) { tmhip_field_free(g_ctx, g_full_tmp); g_full_tmp = nullptr; }
   tmhip_destroy(g_ctx);
   g_ctx = nullptr;
+  g_gauge_uploaded = false;
 }
 
 // ------------------------------------------------------------------ stencil
@@ -344,7 +347,6 @@ void gamma5(spinor *const l, spinor *const k, const int V) {
 
 // ------------------------------------------------------------------ full-lattice operators
 /* The reference toggles g_mu's sign around D_psi (tm_operators.c:380-492); refresh() re-reads it. */
-static tmhip_field *g_full_tmp = nullptr;
 static tmhip_field *full_tmp(tmhip_ctx *c) {
   if (!g_full_tmp) CK(tmhip_field_alloc(c, TMHIP_FIELD_FULL, &g_full_tmp));
   return g_full_tmp;
