@@ -82,9 +82,38 @@ def gen(T, L, full):
     print(tag, scal)
 
 
+def gen_hs(T, L):
+    """Default (half-spinor) build of the reference: fp64 cross-check + fp32 twins of the mixed-precision CG."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle.refbind import RefLattice
+    kappa, mu = 0.125, 0.01
+    r = RefLattice(T, L, L, L, kappa=kappa, mu=mu, nfields=14, hs=True)
+    r.random_fields(123456)
+    lib, N = r.lib, r.V // 2
+    arrs, scal = {}, {"T": T, "L": L, "kappa": kappa, "mu": mu, "seed": 123456}
+    lib.Hopping_Matrix(0, r.sp(1), r.sp(0)); lib.Hopping_Matrix(1, r.sp(2), r.sp(1))
+    arrs["hs_Heo"], arrs["hs_HoeHeo"] = r.spinor(1, N).copy(), r.spinor(2, N).copy()
+    lib.Qtm_pm_psi(r.sp(3), r.sp(0)); arrs["hs_Qtm_pm_psi"] = r.spinor(3, N).copy()
+    lib.assign_to_32(r.sp32(2), r.sp(0), N)
+    arrs["in32"] = r.spinor32(2).copy()
+    lib.Hopping_Matrix_32(0, r.sp32(3), r.sp32(2)); arrs["Heo32"] = r.spinor32(3).copy()
+    lib.Hopping_Matrix_32(1, r.sp32(4), r.sp32(3)); arrs["HoeHeo32"] = r.spinor32(4).copy()
+    lib.Qtm_pm_psi_32(r.sp32(5), r.sp32(2)); arrs["Qtm_pm_psi_32"] = r.spinor32(5).copy()
+    scal["square_norm_32_in"] = float(lib.square_norm_32(r.sp32(2), N, 0))
+    scal["scalar_prod_r_32_in_Qpm"] = float(lib.scalar_prod_r_32(r.sp32(2), r.sp32(5), N, 0))
+    tag = "%dx%d" % (T, L)
+    json.dump(scal, open(os.path.join(GOLD, "ref_hs_scalars_%s.json" % tag), "w"), indent=1)
+    np.savez_compressed(os.path.join(GOLD, "ref_hs_fields_%s.npz" % tag), **arrs)
+    print("hs", tag, scal)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) == 4:
+    if len(sys.argv) == 4 and sys.argv[3] == "hs":
+        gen_hs(int(sys.argv[1]), int(sys.argv[2]))
+    elif len(sys.argv) == 4:
         gen(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "1")
     else:
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "hs"])
         for T, L, full in ((4, 4, 1), (8, 8, 0), (6, 4, 0)):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), str(T), str(L), str(full)])

@@ -30,6 +30,9 @@ extern double X0, X1, X2, X3; /* boundary.c:37 */
 #ifdef TM_USE_OMP
 #include "init/init_omp_accumulators.h"
 #endif
+#ifdef _USE_HALFSPINOR
+#include "init/init_dirac_halfspinor.h"
+#endif
 
 static spinor *tmref_spinor_base = NULL;
 static int tmref_nfields = 0;
@@ -67,8 +70,22 @@ int tmref_init(int T_, int LX_, int LY_, int LZ_, double kappa, double mu,
   for (int i = 0; i < nfields; i++) g_spinor_field[i] = tmref_spinor_base + (size_t)i * VOLUMEPLUSRAND;
   geometry();
   boundary(g_kappa);
+#ifdef _USE_HALFSPINOR
+  /* benchmark.c:219-236 (default build) + invert.c:176-299 for the fp32 twins */
+  if (init_dirac_halfspinor() != 0) return 4;
+  if (init_gauge_field_32(VOLUMEPLUSRAND + g_dbw2rand, 1) != 0) return 5;
+  if (init_dirac_halfspinor32() != 0) return 6;
+  NO_OF_SPINORFIELDS_32 = 6;
+  g_spinor_field32 = (spinor32 **)calloc(NO_OF_SPINORFIELDS_32, sizeof(spinor32 *));
+  for (int i = 0; i < NO_OF_SPINORFIELDS_32; i++) g_spinor_field32[i] = (spinor32 *)calloc(VOLUMEPLUSRAND / 2 + 1, sizeof(spinor32));
+#endif
   return 0;
 }
+
+#ifdef _USE_HALFSPINOR
+/* invert.c:299 */
+void tmref_convert_gauge_32(void) { convert_32_gauge_field(g_gauge_field_32, g_gauge_field, VOLUMEPLUSRAND); g_update_gauge_copy_32 = 1; }
+#endif
 
 void tmref_set_theta(double x0, double x1, double x2, double x3) {
   X0 = x0; X1 = x1; X2 = x2; X3 = x3;

@@ -16,17 +16,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 MATRIX_MULT = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 
 
-def ref_path(omp=False):
-    return os.path.join(_HERE, "_ref", "libtmref_omp.so" if omp else "libtmref.so")
+def ref_path(omp=False, hs=False):
+    """omp: -O3 OpenMP build (timed CPU baseline); hs: the default half-spinor configuration with the fp32 twins."""
+    name = "libtmref_hs.so" if hs else ("libtmref_omp.so" if omp else "libtmref.so")
+    return os.path.join(_HERE, "_ref", name)
 
 
-def ref_available(omp=False):
-    return os.path.exists(ref_path(omp))
+def ref_available(omp=False, hs=False):
+    return os.path.exists(ref_path(omp, hs))
 
 
 class RefLattice:
-    def __init__(self, T, LX, LY, LZ, kappa=0.125, mu=0.0, nfields=12, omp=False, threads=1):
-        self.lib = lib = C.CDLL(ref_path(omp))
+    def __init__(self, T, LX, LY, LZ, kappa=0.125, mu=0.0, nfields=12, omp=False, threads=1, hs=False):
+        self.lib = lib = C.CDLL(ref_path(omp, hs))
+        self.hs = hs
         self.T, self.LX, self.LY, self.LZ = T, LX, LY, LZ
         self.V = T * LX * LY * LZ
         self.nfields = nfields
@@ -70,6 +73,20 @@ class RefLattice:
         lib.tm_sub_Hopping_Matrix.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
         lib.cg_her.restype = C.c_int
         lib.cg_her.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p]
+        if hs:  # fp32 twins (operator/Hopping_Matrix_32.c, operator/tm_operators_32.c, linalg/*_32.c)
+            for name in ("Hopping_Matrix_32",):
+                getattr(lib, name).argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+                getattr(lib, name).restype = None
+            lib.Qtm_pm_psi_32.argtypes = [C.c_void_p, C.c_void_p]
+            lib.Qtm_pm_psi_32.restype = None
+            lib.assign_to_32.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            lib.assign_to_64.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            lib.square_norm_32.restype = C.c_float
+            lib.square_norm_32.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            lib.scalar_prod_r_32.restype = C.c_float
+            lib.scalar_prod_r_32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            lib.assign_add_mul_r_32.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
+            lib.assign_mul_add_r_32.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int]
         rc = lib.tmref_init(T, LX, LY, LZ, kappa, mu, nfields, threads)
         if rc != 0:
             raise RuntimeError("tmref_init failed: %d" % rc)
@@ -101,6 +118,18 @@ class RefLattice:
 
     def random_fields(self, seed=123456):
         self.lib.tmref_random_fields(seed)
+        if self.hs:
+            self.lib.tmref_convert_gauge_32()
+
+    def spinor32(self, i, nsites=None):
+        """g_spinor_field32[i] as float32 [nsites][4][3][2] (su3.h:65-68); fields 0,1 are Qtm_pm_psi_32's scratch."""
+        nsites = nsites or self.V // 2
+        p = C.cast(C.c_void_p.in_dll(self.lib, "g_spinor_field32"), C.POINTER(C.c_void_p))[i]
+        buf = (C.c_float * (nsites * 24)).from_address(p)
+        return np.frombuffer(buf, dtype=np.float32).reshape(nsites, 4, 3, 2)
+
+    def sp32(self, i):
+        return C.cast(C.c_void_p.in_dll(self.lib, "g_spinor_field32"), C.POINTER(C.c_void_p))[i]
 
     def set_kappa_mu(self, kappa, mu):
         self.lib.tmref_set_kappa_mu(kappa, mu)

@@ -98,3 +98,30 @@ def test_mixed_cg_loose_tolerance_single_outer(setup):
     it, outer = lat.mixed_cg_her(dp, dq, 5000, 1e-6, 1, N, innereps=1e-7)
     assert it > 0 and outer == 1
     dq.free(); dp.free()
+
+
+def test_fp32_operators_against_reference_fp32_fixture():
+    """tests/golden/ref_hs_fields_4x4.npz: Hopping_Matrix_32 / Qtm_pm_psi_32 / linalg_32 outputs of the reference's
+    half-spinor build (the only configuration that has the fp32 twins).  Different operation order => fp32 tolerance."""
+    import json
+    import os
+    from tmlqcd_amd import Lattice
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    f = np.load(os.path.join(gold, "ref_fields_4x4.npz"))
+    h = np.load(os.path.join(gold, "ref_hs_fields_4x4.npz"))
+    s = json.load(open(os.path.join(gold, "ref_hs_scalars_4x4.json")))
+    lat = Lattice(4, 4, 4, 4, kappa=s["kappa"], mu=s["mu"])
+    lat.set_gauge(np.ascontiguousarray(f["gauge"]))
+    N = lat.Vh
+    d64, d32, a, b = lat.field(np.ascontiguousarray(f["in"])), lat.field32(), lat.field32(), lat.field32()
+    lat.assign_to_32(d32, d64, N)
+    assert np.array_equal(d32.download(), h["in32"])
+    lat.Hopping_Matrix_32(0, a, d32)
+    assert rel(a.download().astype(np.float64), h["Heo32"].astype(np.float64)) < TOL32
+    lat.Hopping_Matrix_32(1, b, a)
+    assert rel(b.download().astype(np.float64), h["HoeHeo32"].astype(np.float64)) < TOL32
+    lat.Qtm_pm_psi_32(b, d32)
+    assert rel(b.download().astype(np.float64), h["Qtm_pm_psi_32"].astype(np.float64)) < 2 * TOL32
+    assert abs(lat.square_norm_32(d32, N) - s["square_norm_32_in"]) <= 1e-6 * s["square_norm_32_in"]
+    assert abs(lat.scalar_prod_r_32(d32, b, N) - s["scalar_prod_r_32_in_Qpm"]) <= 1e-5 * abs(s["scalar_prod_r_32_in_Qpm"])
+    lat.close()

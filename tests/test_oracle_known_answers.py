@@ -131,3 +131,20 @@ def test_survey_known_scalars_are_in_the_fixtures():
     assert eq(s8["norm_in"], 2.487157888943338e+04) and eq(s8["norm_Heo"], 6.168649177022544e+03)
     assert eq(s8["norm_HoeHeo"], 1.602210010255744e+03) and s8["cg_iters"] == 36
     assert eq(s8["HoeHeo_site0_s0c0"][0], 2.112889071498668e-02) and eq(s8["HoeHeo_site0_s0c0"][1], 1.575582919029603e-01)
+
+
+def test_default_halfspinor_build_of_the_reference_agrees(gold4):
+    """tests/golden/ref_hs_fields_4x4.npz was produced by the reference's DEFAULT configuration
+    (_USE_HALFSPINOR, operator/halfspinor_body.c): an independently written implementation of the same
+    operator.  The oracle (generic body) must reproduce it; its fp32 twins agree at fp32 accuracy."""
+    o, f, s = gold4
+    h = np.load(os.path.join(GOLD, "ref_hs_fields_4x4.npz"))
+    N = o.Vh
+    l1, l2, q = o.new_field(), o.new_field(), o.new_field()
+    o.Hopping_Matrix(0, l1, f["in"]); o.Hopping_Matrix(1, l2, l1)
+    o.op("Qtm_pm_psi", q, np.ascontiguousarray(f["in"]))
+    assert rel_err(l1[:N], h["hs_Heo"]) < 1e-15 and rel_err(l2[:N], h["hs_HoeHeo"]) < 1e-15
+    assert rel_err(q[:N], h["hs_Qtm_pm_psi"]) < 1e-15
+    assert np.array_equal(h["in32"], f["in"].astype(np.float32))                    # assign_to_32 = plain rounding
+    assert rel_err(h["Heo32"].astype(np.float64), l1[:N]) < 1e-6
+    assert rel_err(h["Qtm_pm_psi_32"].astype(np.float64), q[:N]) < 1e-6
