@@ -28,8 +28,11 @@ def setup():
     lat.close()
 
 
-def test_fp32_stencil_and_operator(setup):
+@pytest.mark.parametrize("pairs", [1, 0])
+def test_fp32_stencil_and_operator(setup, pairs):
+    """pairs=1: two sites per thread (16-byte accesses, LZ % 4 == 0); pairs=0: one site per thread."""
     orc, lat = setup
+    lat.set_option("fp32_pairs", pairs)
     N = orc.Vh
     k32 = random_spinor(1, N).astype(np.float32)
     k = k32.astype(np.float64)
@@ -42,7 +45,38 @@ def test_fp32_stencil_and_operator(setup):
     orc.op("Qtm_pm_psi", ref, k.copy())
     lat.Qtm_pm_psi_32(dl, dk)
     assert rel(dl.download().astype(np.float64), ref[:N]) < 4 * TOL32
+    lat.set_loopback(1)                                   # split-phase path in fp32 (faces packed as float2)
+    for ieo in (0, 1):
+        orc.Hopping_Matrix(ieo, ref, k)
+        lat.Hopping_Matrix_32(ieo, dl, dk)
+        assert rel(dl.download().astype(np.float64), ref[:N]) < TOL32
+    lat.set_loopback(0)
+    lat.set_option("fp32_pairs", 1)
     dk.free(); dl.free()
+
+
+@pytest.mark.parametrize("dims", [(4, 4, 4, 6), (2, 2, 2, 4), (4, 6, 2, 12), (2, 2, 2, 2)])
+def test_fp32_stencil_ragged(dims):
+    """LZ/2 odd (6, 2) falls back to one site per thread; LZ/2 even (4, 12) uses site pairs with every row wrap."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T, LX, LY, LZ = dims
+    orc = Oracle(T, LX, LY, LZ, kappa=0.14, mu=0.03, theta=(1.0, 0.3, -0.2, 0.5))
+    lat = Lattice(T, LX, LY, LZ, kappa=0.14, mu=0.03, theta=(1.0, 0.3, -0.2, 0.5))
+    g = random_gauge(sum(dims), orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    N = orc.Vh
+    k32 = random_spinor(3, N).astype(np.float32)
+    ref = orc.new_field()
+    dk, dl = lat.field32(k32), lat.field32()
+    for ieo in (0, 1):
+        orc.Hopping_Matrix(ieo, ref, k32.astype(np.float64))
+        lat.Hopping_Matrix_32(ieo, dl, dk)
+        assert rel(dl.download().astype(np.float64), ref[:N]) < TOL32
+    orc.op("Qtm_pm_psi", ref, k32.astype(np.float64))
+    lat.Qtm_pm_psi_32(dl, dk)
+    assert rel(dl.download().astype(np.float64), ref[:N]) < 4 * TOL32
+    lat.close()
 
 
 def test_fp32_linalg_and_conversions(setup):

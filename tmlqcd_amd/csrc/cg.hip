@@ -283,7 +283,7 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
   double *sum = ctx->result_dev + 1;
   int *flag = (int *)(ctx->result_host + 2);
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
-  const bool fused = ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && ctx->Vh % 256 == 0;
+  const bool fused = ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   int iter = 0;
   for (int i = 0; i < N_outer; i++) {

@@ -85,7 +85,7 @@ struct tmhip_ctx {
   // device-resident CG state (cg.hip)
   void *cg_state; double *cg_hist; int cg_hist_len;
   // options
-  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_variant; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface; int opt_gaux; int opt_gdrop;
+  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_variant; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface; int opt_gaux; int opt_gdrop; int opt_fp32_pairs;
 };
 
 // ---- launch helpers implemented across the .hip files ----
@@ -98,6 +98,7 @@ int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, con
                            double cre, double cim, bool comm);
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
                                double cre, double cim, int *npartials);
+bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx);
 int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out);
 int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes);
 int tmhip_field_alloc_prec(tmhip_ctx *ctx, int kind, int prec, tmhip_field **out);
