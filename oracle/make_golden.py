@@ -82,6 +82,35 @@ def gen(T, L, full):
     print(tag, scal)
 
 
+def gen_clover(T, L):
+    """Clover twisted mass (invert_clover_eo path): sw_term / sw_invert outputs and the operators built on them."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle.refbind import RefLattice
+    kappa, mu, c_sw = 0.125, 0.01, 1.2
+    r = RefLattice(T, L, L, L, kappa=kappa, mu=mu, nfields=14)
+    r.random_fields(123456)
+    sw, swi = r.clover(c_sw, mu)
+    lib, N = r.lib, r.V // 2
+    arrs = {"sw": sw.copy(), "sw_inv": swi.copy()}
+    scal = {"T": T, "L": L, "kappa": kappa, "mu": mu, "c_sw": c_sw, "seed": 123456}
+    lib.Qsw_pm_psi(r.sp(1), r.sp(0)); arrs["Qsw_pm_psi"] = r.spinor(1, N).copy()
+    lib.Msw_plus_psi(r.sp(1), r.sp(0)); arrs["Msw_plus_psi"] = r.spinor(1, N).copy()
+    lib.assign(r.sp(2), r.sp(0), N); lib.clover_inv(r.sp(2), -1, mu); arrs["clover_inv_minus"] = r.spinor(2, N).copy()
+    lib.assign(r.sp(2), r.sp(0), N); lib.clover_inv(r.sp(2), +1, mu); arrs["clover_inv_plus"] = r.spinor(2, N).copy()
+    lib.Hopping_Matrix(1, r.sp(3), r.sp(0))
+    lib.clover_gamma5(1, r.sp(4), r.sp(0), r.sp(3), -mu); arrs["clover_gamma5_OO_in_Hoe"] = r.spinor(4, N).copy()
+    lib.assign(r.sp(8), r.sp(0), N)
+    r.spinor(9)[:] = 0
+    it = lib.cg_her(r.sp(9), r.sp(8), 1000, 1e-20, 1, N, r.fnptr("Qsw_pm_psi"))
+    scal["cg_iters"] = it
+    arrs["cg_solution"] = r.spinor(9, N).copy()
+    tag = "%dx%d" % (T, L)
+    json.dump(scal, open(os.path.join(GOLD, "ref_clover_scalars_%s.json" % tag), "w"), indent=1)
+    np.savez_compressed(os.path.join(GOLD, "ref_clover_fields_%s.npz" % tag), **arrs)
+    print("clover", tag, scal)
+
+
 def gen_hs(T, L):
     """Default (half-spinor) build of the reference: fp64 cross-check + fp32 twins of the mixed-precision CG."""
     sys.path.insert(0, ROOT)
@@ -111,9 +140,12 @@ def gen_hs(T, L):
 if __name__ == "__main__":
     if len(sys.argv) == 4 and sys.argv[3] == "hs":
         gen_hs(int(sys.argv[1]), int(sys.argv[2]))
+    elif len(sys.argv) == 4 and sys.argv[3] == "clover":
+        gen_clover(int(sys.argv[1]), int(sys.argv[2]))
     elif len(sys.argv) == 4:
         gen(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "1")
     else:
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "hs"])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "clover"])
         for T, L, full in ((4, 4, 1), (8, 8, 0), (6, 4, 0)):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), str(T), str(L), str(full)])

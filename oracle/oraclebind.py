@@ -47,6 +47,12 @@ def _lib():
         for n in ("Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi", "Qtm_pm_psi"):
             getattr(lib, "tmo_" + n).argtypes = [vp, vp, vp]
         lib.tmo_M_full.argtypes = [vp] * 5
+        lib.tmo_set_clover.argtypes = [vp, vp, vp]
+        lib.tmo_clover_inv.argtypes = [vp, vp, i, d]
+        lib.tmo_clover_gamma5.argtypes = [vp, i, vp, vp, vp, d]
+        lib.tmo_clover.argtypes = [vp, i, vp, vp, vp, d]
+        lib.tmo_Qsw_pm_psi.argtypes = [vp, vp, vp]
+        lib.tmo_Msw_plus_psi.argtypes = [vp, vp, vp]
         lib.tmo_square_norm.restype = d
         lib.tmo_square_norm.argtypes = [vp, i]
         lib.tmo_scalar_prod_r.restype = d
@@ -129,6 +135,22 @@ class Oracle:
         assert g.shape == (self.VPR, 4, 3, 3, 2)
         self._gauge = np.ascontiguousarray(g, dtype=np.float64)
         self.lib.tmo_set_gauge(self.h, _p(self._gauge))
+
+    def set_clover(self, sw, sw_inv):
+        """sw [V][3][2][3][3][2], sw_inv [V][4][2][3][3][2] as the reference's sw_term / sw_invert lay them out."""
+        assert sw.shape == (self.V, 3, 2, 3, 3, 2) and sw_inv.shape == (self.V, 4, 2, 3, 3, 2)
+        self._sw = np.ascontiguousarray(sw, dtype=np.float64)
+        self._sw_inv = np.ascontiguousarray(sw_inv, dtype=np.float64)
+        self.lib.tmo_set_clover(self.h, _p(self._sw), _p(self._sw_inv))
+
+    def clover_inv(self, l, tau3sign, mu):
+        self.lib.tmo_clover_inv(self.h, _p(l), tau3sign, mu)
+
+    def clover_gamma5(self, ieo, l, k, j, mu):
+        self.lib.tmo_clover_gamma5(self.h, ieo, _p(l), _p(k), _p(j), mu)
+
+    def clover(self, ieo, l, k, j, mu):
+        self.lib.tmo_clover(self.h, ieo, _p(l), _p(k), _p(j), mu)
 
     def new_field(self, n=None):
         return np.zeros((n or (self.VPR // 2), 4, 3, 2), dtype=np.float64)

@@ -27,6 +27,8 @@
 extern double X0, X1, X2, X3; /* boundary.c:37 */
 #include "init/init_gauge_field.h"
 #include "init/init_geometry_indices.h"
+#include "operator/clovertm_operators.h"
+#include "operator/clover_leaf.h"
 #ifdef TM_USE_OMP
 #include "init/init_omp_accumulators.h"
 #endif
@@ -105,6 +107,17 @@ void tmref_random_fields(int seed) {
 }
 
 void tmref_random_spinor_eo(int i) { random_spinor_field_eo(g_spinor_field[i], 1, RN_GAUSS); }
+
+/* clover term and its inverse on the even sites, as operator.c:329-330,364 prepare them for invert_clover_eo */
+void tmref_clover(double c_sw, double mu) {
+  g_c_sw = c_sw; g_mu = mu; g_mu3 = 0.;
+  init_sw_fields();
+  sw_term((const su3 **)g_gauge_field, g_kappa, g_c_sw);
+  sw_invert(0 /* EE, operator/Hopping_Matrix.h:26 */, g_mu);
+  g_c_sw = 0.;   /* keep D_psi on its non-clover branch (D_psi_body.c:314-316) */
+}
+su3 *tmref_sw(void) { return &sw[0][0][0]; }
+su3 *tmref_sw_inv(void) { return &sw_inv[0][0][0]; }
 
 su3 *tmref_gauge(void) { return &g_gauge_field[0][0]; }
 spinor *tmref_spinor(int i) { return g_spinor_field[i]; }

@@ -140,5 +140,22 @@ class RefLattice:
     def mark_gauge_dirty(self):
         self.lib.tmref_mark_gauge_dirty()
 
+    def clover(self, c_sw, mu):
+        """init_sw_fields + sw_term + sw_invert(EE, mu) (operator.c:329-330,364); returns views (sw, sw_inv)."""
+        lib = self.lib
+        lib.tmref_clover.argtypes = [C.c_double, C.c_double]
+        lib.tmref_sw.restype = C.c_void_p
+        lib.tmref_sw_inv.restype = C.c_void_p
+        for n in ("Qsw_pm_psi", "Msw_plus_psi"):
+            getattr(lib, n).argtypes = [C.c_void_p, C.c_void_p]
+            getattr(lib, n).restype = None
+        lib.clover_inv.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        lib.clover_gamma5.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        lib.tmref_clover(c_sw, mu)
+        V = self.V
+        sw = np.frombuffer((C.c_double * (V * 6 * 18)).from_address(lib.tmref_sw()), dtype=np.float64).reshape(V, 3, 2, 3, 3, 2)
+        swi = np.frombuffer((C.c_double * (V * 8 * 18)).from_address(lib.tmref_sw_inv()), dtype=np.float64).reshape(V, 4, 2, 3, 3, 2)
+        return sw, swi
+
     def fnptr(self, name):
         return C.cast(getattr(self.lib, name), C.c_void_p)

@@ -502,6 +502,78 @@ void tmo_M_full(tmo_lattice *lat, tmo_spinor *Even_new, tmo_spinor *Odd_new,
   tmo_assign_add_mul_r(Odd_new, lat->scratch[0], -1., N);
 }
 
+/* ---------------------------------------------------------------- clover twisted mass */
+void tmo_set_clover(tmo_lattice *lat, const tmo_su3 *sw, const tmo_su3 *sw_inv) { lat->sw = sw; lat->sw_inv = sw_inv; }
+
+/* operator/clovertm_operators.c:287-350: l = (1 + T_ee +- i mu g5)^-1 l on the V/2 sites the inverse was built for */
+void tmo_clover_inv(tmo_lattice *lat, tmo_spinor *l, int tau3sign, double mu) {
+  const int Vh = lat->V / 2;
+  const int ioff = (tau3sign < 0 && fabs(mu) > 0) ? Vh : 0;
+#pragma omp parallel for
+  for (int icx = 0; icx < Vh; icx++) {
+    const tmo_su3 *w = lat->sw_inv + 8 * (size_t)(ioff + icx);   /* [4][2]: w[2a + b] = sw_inv[icy][a][b] */
+    tmo_spinor *rn = l + icx;
+    tmo_su3_vector psi, chi, phi1 = rn->s0, phi3 = rn->s2;
+    psi = su3_mul(&w[0], phi1); chi = su3_mul(&w[2], rn->s1); rn->s0 = v_add(psi, chi);
+    psi = su3_mul(&w[6], phi1); chi = su3_mul(&w[4], rn->s1); rn->s1 = v_add(psi, chi);
+    psi = su3_mul(&w[1], phi3); chi = su3_mul(&w[3], rn->s3); rn->s2 = v_add(psi, chi);
+    psi = su3_mul(&w[7], phi3); chi = su3_mul(&w[5], rn->s3); rn->s3 = v_add(psi, chi);
+  }
+}
+
+/* su3.h _vector_add_i_mul(r, c, s): r += i c s */
+#define V_ADD_I_MUL(r, c, s) do { (r).c0 += I * (c) * (s).c0; (r).c1 += I * (c) * (s).c1; (r).c2 += I * (c) * (s).c2; } while (0)
+
+/* operator/clovertm_operators.c:448-520 (g5 = 1) and :535-600 `clover` (g5 = 0):
+ * l = [g5] ( (1 + T + i mu g5) k - j ) on the sites of parity ieo */
+static void tmo_clover_generic(tmo_lattice *lat, int ieo, tmo_spinor *l, const tmo_spinor *k, const tmo_spinor *j,
+                               double mu, int g5) {
+  const int ioff = ieo == 0 ? 0 : lat->VPR / 2, Vh = lat->V / 2;
+#pragma omp parallel for
+  for (int icx = ioff; icx < Vh + ioff; icx++) {
+    const int ix = lat->eo2lexic[icx];
+    const tmo_su3 *w = lat->sw + 6 * (size_t)ix;                 /* [3][2]: w[2a + b] = sw[ix][a][b] */
+    const tmo_spinor *s = k + (icx - ioff), *t = j + (icx - ioff);
+    tmo_spinor o;
+    tmo_su3_vector chi, psi1, psi2;
+    psi1 = su3_mul(&w[0], s->s0); chi = su3_mul(&w[2], s->s1); V_ADD_ASSIGN(psi1, chi);
+    psi2 = su3_inv_mul(&w[2], s->s0); chi = su3_mul(&w[4], s->s1); V_ADD_ASSIGN(psi2, chi);
+    V_ADD_I_MUL(psi1, mu, s->s0); V_ADD_I_MUL(psi2, mu, s->s1);
+    o.s0 = v_sub(psi1, t->s0); o.s1 = v_sub(psi2, t->s1);
+    psi1 = su3_mul(&w[1], s->s2); chi = su3_mul(&w[3], s->s3); V_ADD_ASSIGN(psi1, chi);
+    psi2 = su3_inv_mul(&w[3], s->s2); chi = su3_mul(&w[5], s->s3); V_ADD_ASSIGN(psi2, chi);
+    V_ADD_I_MUL(psi1, -mu, s->s2); V_ADD_I_MUL(psi2, -mu, s->s3);
+    if (g5) { o.s2 = v_sub(t->s2, psi1); o.s3 = v_sub(t->s3, psi2); }
+    else    { o.s2 = v_sub(psi1, t->s2); o.s3 = v_sub(psi2, t->s3); }
+    l[icx - ioff] = o;
+  }
+}
+void tmo_clover_gamma5(tmo_lattice *lat, int ieo, tmo_spinor *l, const tmo_spinor *k, const tmo_spinor *j, double mu) {
+  tmo_clover_generic(lat, ieo, l, k, j, mu, 1);
+}
+void tmo_clover(tmo_lattice *lat, int ieo, tmo_spinor *l, const tmo_spinor *k, const tmo_spinor *j, double mu) {
+  tmo_clover_generic(lat, ieo, l, k, j, mu, 0);
+}
+
+/* operator/clovertm_operators.c:233-245 (g_mu3 = 0) */
+void tmo_Qsw_pm_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
+  tmo_clover_inv(lat, lat->scratch[1], -1, lat->mu);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
+  tmo_clover_gamma5(lat, OE, lat->scratch[0], k, lat->scratch[0], -lat->mu);
+  tmo_Hopping_Matrix(lat, EO, l, lat->scratch[0]);
+  tmo_clover_inv(lat, l, +1, lat->mu);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[1], l);
+  tmo_clover_gamma5(lat, OE, l, lat->scratch[0], lat->scratch[1], +lat->mu);
+}
+/* operator/clovertm_operators.c:256-261 */
+void tmo_Msw_plus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
+  tmo_clover_inv(lat, lat->scratch[1], +1, lat->mu);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
+  tmo_clover(lat, OE, l, k, lat->scratch[0], +lat->mu);
+}
+
 /* ---------------------------------------------------------------- linalg */
 /* Per-thread Kahan partials summed in thread order, as the reference does with
    g_omp_acc_re (linalg/square_norm.c:299-304). */

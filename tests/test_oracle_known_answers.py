@@ -148,3 +148,37 @@ def test_default_halfspinor_build_of_the_reference_agrees(gold4):
     assert np.array_equal(h["in32"], f["in"].astype(np.float32))                    # assign_to_32 = plain rounding
     assert rel_err(h["Heo32"].astype(np.float64), l1[:N]) < 1e-6
     assert rel_err(h["Qtm_pm_psi_32"].astype(np.float64), q[:N]) < 1e-6
+
+
+def test_golden_4x4_clover(gold4):
+    """Clover twisted mass: sw / sw_inv from the reference's sw_term / sw_invert and the
+    reference's clover_inv, clover_gamma5, Qsw_pm_psi, Msw_plus_psi and cg_her(Qsw_pm_psi) on them."""
+    o, f, s = gold4
+    c = np.load(os.path.join(GOLD, "ref_clover_fields_4x4.npz"))
+    cs = json.load(open(os.path.join(GOLD, "ref_clover_scalars_4x4.json")))
+    N = o.Vh
+    mu = cs["mu"]
+    o.set_clover(c["sw"], c["sw_inv"])
+    # sw is hermitian block-wise and sw_inv really is the inverse of (1 + T +- i mu g5) on the even sites
+    sw, swi = c["sw"][..., 0] + 1j * c["sw"][..., 1], c["sw_inv"][..., 0] + 1j * c["sw_inv"][..., 1]
+    x = f["eo2lexic"][5]                     # an even site, e/o index 5
+    for chi, sgn in ((0, +1), (1, -1)):
+        A, B, Cc = sw[x, 0, chi], sw[x, 1, chi], sw[x, 2, chi]
+        M = np.block([[A, B], [B.conj().T, Cc]]) + 1j * sgn * mu * np.eye(6)
+        Minv = np.block([[swi[5, 0, chi], swi[5, 1, chi]], [swi[5, 3, chi], swi[5, 2, chi]]])
+        assert np.abs(M @ Minv - np.eye(6)).max() < 1e-13
+    k = np.ascontiguousarray(f["in"])
+    for sign, key in ((-1, "clover_inv_minus"), (+1, "clover_inv_plus")):
+        l = o.new_field(); l[:N] = k
+        o.clover_inv(l, sign, mu)
+        assert np.array_equal(l[:N], c[key])
+    h = o.new_field(); o.Hopping_Matrix(1, h, k)
+    l = o.new_field(); o.clover_gamma5(1, l, k, h, -mu)
+    assert np.array_equal(l[:N], c["clover_gamma5_OO_in_Hoe"])
+    q = o.new_field(); o.op("Qsw_pm_psi", q, k.copy())
+    assert np.array_equal(q[:N], c["Qsw_pm_psi"])
+    o.op("Msw_plus_psi", q, k.copy())
+    assert np.array_equal(q[:N], c["Msw_plus_psi"])
+    P = o.new_field()
+    it, _ = o.cg_her(P, k.copy(), 1000, 1e-20, 1, N, "Qsw_pm_psi")
+    assert it == cs["cg_iters"] and np.array_equal(P[:N], c["cg_solution"])
