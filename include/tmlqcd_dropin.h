@@ -85,6 +85,18 @@ void assign(spinor *const R, spinor *const S, const int N);
 int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, const int rel_prec,
            const int N, matrix_mult f);
 
+/* ---- operator/clovertm_operators.h ----------------------- */
+/* The host keeps computing `sw` / `sw_inv` with its own sw_term / sw_invert (operator.c:329-330,364); the library
+ * reads the globals `su3 ***sw, ***sw_inv` (clovertm_operators.c:58-59).  They carry no dirty flag in the reference,
+ * so call tmlqcd_hip_update_clover() after every sw_term / sw_invert (first use uploads automatically). */
+void tmlqcd_hip_update_clover(void);
+void Qsw_pm_psi(spinor *const l, spinor *const k);                                                  /* clovertm_operators.c:233 */
+void Msw_plus_psi(spinor *const l, spinor *const k);                                                /* :256 */
+void H_eo_sw_inv_psi(spinor *const l, spinor *const k, const int ieo, const int tau3sign, const double mu); /* :268 */
+void clover_inv(spinor *const l, const int tau3sign, const double mu);                              /* :287 */
+void clover_gamma5(const int ieo, spinor *const l, const spinor *const k, const spinor *const j, const double mu); /* :448 */
+void clover(const int ieo, spinor *const l, const spinor *const k, const spinor *const j, const double mu);        /* :535 */
+
 /* ---- solver/mixed_cg_her.h ------------------------------ */
 /* `solver_params_t` (solver/solver_params.h:46) is passed BY VALUE but not used by the reference's mixed_cg_her
  * (solver/mixed_cg_her.c:65-202 reads the globals mixcg_innereps / mixcg_maxinnersolverit, read_input.h:112-113).

@@ -116,13 +116,27 @@ int tmhip_diff(tmhip_ctx *ctx, tmhip_field *Q, tmhip_field *R, tmhip_field *S, i
 int tmhip_assign(tmhip_ctx *ctx, tmhip_field *R, tmhip_field *S, int N);                                       /* assign.c:42 */
 
 /* ---- solver --------------------------------------------------------------- */
-enum { TMHIP_OP_QTM_PM = 0, TMHIP_OP_QTM_PLUS = 1, TMHIP_OP_QTM_MINUS = 2, TMHIP_OP_MTM_PLUS = 3, TMHIP_OP_MTM_MINUS = 4 };
+enum { TMHIP_OP_QTM_PM = 0, TMHIP_OP_QTM_PLUS = 1, TMHIP_OP_QTM_MINUS = 2, TMHIP_OP_MTM_PLUS = 3, TMHIP_OP_MTM_MINUS = 4,
+       TMHIP_OP_QSW_PM = 5 /* clover: Qsw_pm_psi, needs tmhip_set_clover */ };
 /* cg_her(P,Q,max_iter,eps_sq,rel_prec,N,f)   solver/cg_her.c:62-141.
  * Device-resident: P, Q and the three work fields never leave HBM.  Returns the
  * iteration count in *iters (-1 if not converged); res_hist (may be NULL) gets
  * err after each iteration, up to hist_len entries. */
 int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec,
                  int N, int op, int *iters, double *res_hist, int hist_len);
+
+/* ---- clover twisted mass (invert_clover_eo.c:63-165) ------
+ * The 6x6 site blocks are inputs like the gauge field: `sw` = su3 sw[VOLUME][3][2] from sw_term
+ * (operator/clover_term.c:88), `sw_inv` = su3 sw_inv[VOLUME][4][2] from sw_invert(EE, mu)
+ * (operator/clover_invert.c:170; +mu set in [0,V/2), -mu set in [V/2,V)).  Call again whenever they change. */
+int tmhip_set_clover(tmhip_ctx *ctx, const void *sw, const void *sw_inv);
+int tmhip_clover_inv(tmhip_ctx *ctx, tmhip_field *l, int tau3sign, double mu);                                   /* clovertm_operators.c:287 */
+int tmhip_clover_gamma5(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, tmhip_field *j, double mu);     /* :448 */
+int tmhip_clover(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, tmhip_field *j, double mu);            /* :535 */
+int tmhip_H_eo_sw_inv_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int ieo, int tau3sign, double mu);     /* :268 */
+int tmhip_Qsw_pm_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);                                            /* :233 */
+int tmhip_Msw_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);                                          /* :256 */
+int tmhip_Qsw_pm_psi_32(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);                                         /* clovertm_operators_32.c */
 
 /* ---- mixed precision -------------------------------------
  * fp32 one-parity fields hold the reference's `spinor32` (su3.h:65-68); the fp32 gauge copy is built

@@ -108,6 +108,7 @@ void tmref_random_fields(int seed) {
 
 void tmref_random_spinor_eo(int i) { random_spinor_field_eo(g_spinor_field[i], 1, RN_GAUSS); }
 
+#ifndef TMREF_NO_CLOVER
 /* clover term and its inverse on the even sites, as operator.c:329-330,364 prepare them for invert_clover_eo */
 void tmref_clover(double c_sw, double mu) {
   g_c_sw = c_sw; g_mu = mu; g_mu3 = 0.;
@@ -118,6 +119,7 @@ void tmref_clover(double c_sw, double mu) {
 }
 su3 *tmref_sw(void) { return &sw[0][0][0]; }
 su3 *tmref_sw_inv(void) { return &sw_inv[0][0][0]; }
+#endif
 
 su3 *tmref_gauge(void) { return &g_gauge_field[0][0]; }
 spinor *tmref_spinor(int i) { return g_spinor_field[i]; }

@@ -38,3 +38,23 @@ void stub_boundary(double kappa, double x0, double x1, double x2, double x3) {
 void stub_set_mu(double mu) { g_mu = mu; }
 void stub_mark_gauge_dirty(void) { g_update_gauge_copy = 1; }
 int stub_gauge_flag(void) { return g_update_gauge_copy; }
+
+/* clover fields, allocated the way init_sw_fields does (operator/clovertm_operators.c:1162-1210):
+ * sw[ix][a] -> &block[(ix*3 + a)*2], sw_inv[icy][a] -> &block[(icy*4 + a)*2] */
+su3 ***sw = NULL, ***sw_inv = NULL;
+static su3 *sw_block = NULL, *swinv_block = NULL;
+static su3 **sw1 = NULL, **swinv1 = NULL;
+su3 *stub_init_clover(int which) {
+  const int V = VOLUME;
+  if (!sw) {
+    sw = (su3 ***)calloc(V, sizeof(su3 **)); sw_inv = (su3 ***)calloc(V, sizeof(su3 **));
+    sw1 = (su3 **)calloc(3 * (size_t)V, sizeof(su3 *)); swinv1 = (su3 **)calloc(4 * (size_t)V, sizeof(su3 *));
+    sw_block = (su3 *)calloc(6 * (size_t)V + 1, sizeof(su3)); swinv_block = (su3 *)calloc(8 * (size_t)V + 1, sizeof(su3));
+    for (int i = 0; i < V; i++) {
+      sw[i] = sw1 + 3 * (size_t)i; sw_inv[i] = swinv1 + 4 * (size_t)i;
+      for (int a = 0; a < 3; a++) sw[i][a] = sw_block + ((size_t)i * 3 + a) * 2;
+      for (int a = 0; a < 4; a++) sw_inv[i][a] = swinv_block + ((size_t)i * 4 + a) * 2;
+    }
+  }
+  return which ? swinv_block : sw_block;
+}

@@ -1,0 +1,114 @@
+"""GPU: clover twisted-mass operators (the invert_clover_eo path) against the reference's
+fixture (sw_term / sw_invert outputs at 4^4) and against the CPU oracle on synthetic clover blocks at 8^4."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import TOL, random_clover, random_gauge, random_spinor, rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_clover_fixture_from_reference():
+    from tmlqcd_amd import Lattice
+    f = np.load(os.path.join(GOLD, "ref_fields_4x4.npz"))
+    c = np.load(os.path.join(GOLD, "ref_clover_fields_4x4.npz"))
+    s = json.load(open(os.path.join(GOLD, "ref_clover_scalars_4x4.json")))
+    mu = s["mu"]
+    lat = Lattice(4, 4, 4, 4, kappa=s["kappa"], mu=mu)
+    lat.set_gauge(np.ascontiguousarray(f["gauge"]))
+    lat.set_clover(np.ascontiguousarray(c["sw"]), np.ascontiguousarray(c["sw_inv"]))
+    N = lat.Vh
+    k = np.ascontiguousarray(f["in"])
+    dk, dl, dh = lat.field(k), lat.field(), lat.field()
+    for sign, key in ((-1, "clover_inv_minus"), (+1, "clover_inv_plus")):
+        dl.upload(k); lat.clover_inv(dl, sign, mu)
+        assert rel_err(dl.download(), c[key]) < TOL
+    lat.Hopping_Matrix(1, dh, dk)
+    lat.clover_gamma5(1, dl, dk, dh, -mu)
+    assert rel_err(dl.download(), c["clover_gamma5_OO_in_Hoe"]) < TOL
+    lat.op("Qsw_pm_psi", dl, dk)
+    assert rel_err(dl.download(), c["Qsw_pm_psi"]) < TOL
+    lat.op("Msw_plus_psi", dl, dk)
+    assert rel_err(dl.download(), c["Msw_plus_psi"]) < TOL
+    dp = lat.field()
+    it, _ = lat.cg_her(dp, dk, 1000, 1e-20, 1, N, op="Qsw_pm_psi")
+    assert abs(it - s["cg_iters"]) <= 1 and rel_err(dp.download(), c["cg_solution"]) < 1e-9
+    lat.close()
+
+
+@pytest.fixture(scope="module")
+def setup8():
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T, LX, LY, LZ = 8, 6, 4, 12
+    kappa, mu, theta = 0.13, 0.02, (1.0, 0.0, 0.3, 0.5)
+    orc = Oracle(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta, threads=8)
+    lat = Lattice(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta)
+    g = random_gauge(71, orc.VPR)
+    sw, swi = random_clover(72, orc, mu)
+    orc.set_gauge(g); lat.set_gauge(g)
+    orc.set_clover(sw, swi); lat.set_clover(sw, swi)
+    yield orc, lat, mu
+    lat.close()
+
+
+def test_clover_site_ops_and_fused_operator(setup8):
+    orc, lat, mu = setup8
+    N = orc.Vh
+    k, j = random_spinor(1, N), random_spinor(2, N)
+    dk, dj, dl = lat.field(k), lat.field(j), lat.field()
+    for sign in (+1, -1):
+        ref = orc.new_field(); ref[:N] = k
+        orc.clover_inv(ref, sign, mu)
+        dl.upload(k); lat.clover_inv(dl, sign, mu)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+        ref2 = orc.new_field(); orc.Hopping_Matrix(0, ref2, k); orc.clover_inv(ref2, sign, mu)
+        lat.H_eo_sw_inv_psi(dl, dk, 0, sign, mu)                    # stencil with the fused clover_inv epilogue
+        assert rel_err(dl.download(), ref2[:N]) < TOL
+    for ieo in (0, 1):
+        ref = orc.new_field(); orc.clover_gamma5(ieo, ref, k, j, -mu)
+        lat.clover_gamma5(ieo, dl, dk, dj, -mu)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+        orc.clover(ieo, ref, k, j, mu); lat.clover(ieo, dl, dk, dj, mu)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+    ref = orc.new_field(); orc.op("Qsw_pm_psi", ref, k.copy())
+    lat.op("Qsw_pm_psi", dl, dk)
+    assert rel_err(dl.download(), ref[:N]) < TOL
+    lat.set_loopback(1)                                             # clover epilogues on the split-phase path
+    lat.op("Qsw_pm_psi", dl, dk)
+    lat.set_loopback(0)
+    assert rel_err(dl.download(), ref[:N]) < TOL
+    orc.op("Msw_plus_psi", ref, k.copy()); lat.op("Msw_plus_psi", dl, dk)
+    assert rel_err(dl.download(), ref[:N]) < TOL
+    for f in (dk, dj, dl):
+        f.free()
+
+
+def test_clover_cg_and_mixed_cg(setup8):
+    """BASELINE configs[4] in miniature: clover twisted mass, fp64 CG and mixed fp32/fp64 CG with fp64 residual restart."""
+    orc, lat, mu = setup8
+    N = orc.Vh
+    q = random_spinor(3, N)
+    P = orc.new_field(); it_ref, _ = orc.cg_her(P, q.copy(), 2000, 1e-20, 1, N, "Qsw_pm_psi")
+    dq, dp = lat.field(q), lat.field()
+    it, _ = lat.cg_her(dp, dq, 2000, 1e-20, 1, N, op="Qsw_pm_psi")
+    assert abs(it - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9
+    # fp32 operator vs fp64 oracle
+    k32 = q.astype(np.float32)
+    d32, l32 = lat.field32(k32), lat.field32()
+    ref = orc.new_field(); orc.op("Qsw_pm_psi", ref, k32.astype(np.float64))
+    lat.Qsw_pm_psi_32(l32, d32)
+    assert rel_err(l32.download().astype(np.float64), ref[:N]) < 1e-5
+    itm, outer = lat.mixed_cg_her(dp, dq, 5000, 1e-20, 1, N, op="Qsw_pm_psi")
+    assert itm > 0 and outer >= 2
+    sol = dp.download()
+    full = orc.new_field(); full[:N] = sol
+    chk = orc.new_field(); orc.op("Qsw_pm_psi", chk, full)
+    assert ((chk[:N] - q) ** 2).sum() / (q ** 2).sum() <= 1e-20
+    assert rel_err(sol, P[:N]) < 1e-8
+    for f in (dq, dp, d32, l32):
+        f.free()

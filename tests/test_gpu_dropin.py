@@ -111,6 +111,8 @@ def test_cg_her_drop_in_and_resident_benchmark(host):
     # resident mode: outputs stay in HBM until asked for
     f0 = random_spinor(6, N); f1 = np.zeros_like(f0); f2 = np.zeros_like(f0)
     d.tmlqcd_hip_set_residency(1)
+    for a in (f0, f1, f2):                     # resident-mode contract: tell the library about host-side writes
+        d.tmlqcd_hip_host_modified(_p(a))
     secs = d.tmlqcd_hip_benchmark_loop(_p(f0), _p(f1), _p(f2), 5)
     assert secs > 0 and not f2.any()                      # host copy untouched so far
     d.tmlqcd_hip_sync_to_host(_p(f2))
@@ -135,3 +137,34 @@ def test_mixed_cg_her_drop_in(host):
     full = orc.new_field(); full[:N] = P
     chk = orc.new_field(); orc.op("Qtm_pm_psi", chk, full)
     assert ((chk[:N] - q) ** 2).sum() / (q ** 2).sum() <= 1e-20
+
+
+def test_clover_drop_in(host):
+    """operator/clovertm_operators.h symbols: sw / sw_inv are read from the host program's globals."""
+    from tests.util import random_clover
+    stub, d, orc, g, (T, L, V) = host
+    N = V // 2
+    mu = orc.mu
+    sw, swi = random_clover(9, orc, mu)
+    stub.stub_init_clover.restype = C.c_void_p
+    stub.stub_init_clover.argtypes = [C.c_int]
+    C.memmove(stub.stub_init_clover(0), _p(sw), sw.nbytes)
+    C.memmove(stub.stub_init_clover(1), _p(swi), swi.nbytes)
+    d.tmlqcd_hip_update_clover()
+    orc.set_clover(sw, swi)
+    d.Qsw_pm_psi.argtypes = [VP, VP]
+    d.clover_inv.argtypes = [VP, C.c_int, C.c_double]
+    d.clover_gamma5.argtypes = [C.c_int, VP, VP, VP, C.c_double]
+    k, j = random_spinor(11, N), random_spinor(12, N)
+    l = np.zeros_like(k); ref = orc.new_field()
+    d.Qsw_pm_psi(_p(l), _p(k)); orc.op("Qsw_pm_psi", ref, k.copy())
+    assert rel_err(l, ref[:N]) < TOL
+    kk = k.copy(); ref[:N] = k
+    d.clover_inv(_p(kk), -1, mu); orc.clover_inv(ref, -1, mu)
+    assert rel_err(kk, ref[:N]) < TOL
+    d.clover_gamma5(1, _p(l), _p(k), _p(j), mu); orc.clover_gamma5(1, ref, k, j, mu)
+    assert rel_err(l, ref[:N]) < TOL
+    q = random_spinor(13, N); P = np.zeros_like(q)
+    it = d.cg_her(_p(P), _p(q), 2000, 1e-18, 1, N, C.cast(d.Qsw_pm_psi, VP))
+    Pref = orc.new_field(); it_ref, _ = orc.cg_her(Pref, q.copy(), 2000, 1e-18, 1, N, "Qsw_pm_psi")
+    assert abs(it - it_ref) <= 1 and rel_err(P, Pref[:N]) < 1e-8

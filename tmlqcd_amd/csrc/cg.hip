@@ -144,6 +144,7 @@ int tmhip_apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k) {
     case TMHIP_OP_QTM_MINUS: return tmhip_Qtm_minus_psi(ctx, l, k);
     case TMHIP_OP_MTM_PLUS: return tmhip_Mtm_plus_psi(ctx, l, k);
     case TMHIP_OP_MTM_MINUS: return tmhip_Mtm_minus_psi(ctx, l, k);
+    case TMHIP_OP_QSW_PM: return tmhip_Qsw_pm_psi(ctx, l, k);
   }
   fprintf(stderr, "[tmlqcd_hip] cg_her: unknown operator id %d\n", op);
   return 1;
@@ -264,9 +265,11 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
                                   int op, double innereps, int max_inner_it, int *iters, int *outer_iters) {
   if (!P || !Q || P->kind != TMHIP_FIELD_EO || Q->kind != TMHIP_FIELD_EO || P->prec || Q->prec) TMHIP_FAIL("mixed_cg_her needs fp64 one-parity fields");
   if (N != ctx->Vh) TMHIP_FAIL("mixed_cg_her: N must be VOLUME/2");
-  if (op != TMHIP_OP_QTM_PM) TMHIP_FAIL("mixed_cg_her: only Qtm_pm_psi / Qtm_pm_psi_32 is available in fp32");
+  if (op != TMHIP_OP_QTM_PM && op != TMHIP_OP_QSW_PM) TMHIP_FAIL("mixed_cg_her: fp32 operators exist for Qtm_pm_psi and Qsw_pm_psi only");
   TMHIP_CHECK(hipSetDevice(ctx->device));
   if (tmhip_prepare_fp32(ctx)) return 1;
+  const bool clover = op == TMHIP_OP_QSW_PM;
+  if (clover && tmhip_prepare_clover32(ctx)) return 1;
   if (!ctx->cg_state) TMHIP_CHECK(hipMalloc(&ctx->cg_state, sizeof(CgState)));
   CgState *st = (CgState *)ctx->cg_state;
   int N_outer = max_iter / (max_inner_it > 0 ? max_inner_it : 1);
@@ -283,7 +286,7 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
   double *sum = ctx->result_dev + 1;
   int *flag = (int *)(ctx->result_host + 2);
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
-  const bool fused = ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
+  const bool fused = !clover && ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   int iter = 0;
   for (int i = 0; i < N_outer; i++) {
@@ -301,6 +304,10 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
       for (int b = 0; b < batch; b++) {
         int ndot = nblk;
         v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
+        if (clover) {
+          if (tmhip_Qsw_pm_psi_32(ctx, sf0, sf2)) return 1;
+          hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, ctx->partials, st);
+        } else {
         if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, sf2->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
         if (tmhip_launch_hopping32(ctx, TMHIP_OE, s0, s1, sf2->d32, EPI_TM_SUB_G5, 1., -mu, true)) return 1;
         if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true)) return 1;
@@ -309,6 +316,7 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
         } else {
           if (tmhip_launch_hopping32(ctx, TMHIP_OE, sf0->d32, s1, s0, EPI_TM_SUB_G5, 1., mu, true)) return 1;
           hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, ctx->partials, st);
+        }
         }
         hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ndot, sum, st);
         if (cg_allreduce(ctx, sum)) return 1;

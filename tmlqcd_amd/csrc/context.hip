@@ -181,6 +181,10 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   for (int i = 0; i < 2; i++) tmhip_field_free(ctx, ctx->scratch32[i]);
   for (int i = 0; i < 4; i++) tmhip_field_free(ctx, ctx->sf32[i]);
   if (ctx->gauge32) (void)hipFree(ctx->gauge32);
+  if (ctx->sw) (void)hipFree(ctx->sw);
+  if (ctx->sw_inv) (void)hipFree(ctx->sw_inv);
+  if (ctx->sw32) (void)hipFree(ctx->sw32);
+  if (ctx->sw_inv32) (void)hipFree(ctx->sw_inv32);
   if (ctx->comm_ready) ncclCommDestroy(ctx->comm);
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);

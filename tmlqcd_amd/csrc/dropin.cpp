@@ -21,6 +21,8 @@ extern su3 **g_gauge_field;                                       /* global.h:17
 extern int g_update_gauge_copy;                                   /* global.h:73  */
 extern double g_mu;                                               /* global.h:198 */
 extern TM_COMPLEX ka0, ka1, ka2, ka3;                             /* boundary.h:25 */
+extern su3 ***sw __attribute__((weak));                           /* clovertm_operators.c:58 */
+extern su3 ***sw_inv __attribute__((weak));                       /* clovertm_operators.c:59 */
 extern double mixcg_innereps __attribute__((weak));               /* read_input.h:112 (only needed by mixed_cg_her) */
 extern int mixcg_maxinnersolverit __attribute__((weak));          /* read_input.h:113 */
 // Present in a full tmLQCD link (update_backward_gauge.c, libhmc.a); refreshes the HOST gauge
@@ -43,6 +45,7 @@ int g_mode = TMLQCD_HIP_COHERENT;
 int g_dims[6] = {0, 0, 0, 0, 0, 0};
 std::unordered_map<const void *, Mirror> g_reg;
 bool g_gauge_uploaded = false;   // the current context holds a gauge copy
+bool g_clover_uploaded = false;
 tmhip_field *g_full_tmp = nullptr; // FULL-lattice scratch of Q_pm_psi / D_dagg_psi (tm_operators.c:380-397)
 
 [[noreturn]] void die(const char *what) {
@@ -126,7 +129,10 @@ tmhip_field *out(tmhip_ctx *c, const void *host, int kind) { return mirror(c, ho
 void done(tmhip_ctx *c, const void *host) {
   Mirror &m = g_reg[host];
   m.dev_valid = true; m.host_valid = false;
-  if (g_mode == TMLQCD_HIP_COHERENT) download(c, host, m);
+  if (g_mode == TMLQCD_HIP_COHERENT) {
+    download(c, host, m);
+    m.dev_valid = false;   // coherent mode: the host copy is the truth (it may be rewritten or its address recycled)
+  }
 }
 
 tmhip_field *half(tmhip_field *f, int kind, int par) {
@@ -142,6 +148,9 @@ extern "C" {
 void tmlqcd_hip_set_device(int device) { g_device = device; }
 void tmlqcd_hip_set_residency(int mode) {
   if (mode == TMLQCD_HIP_COHERENT && g_mode == TMLQCD_HIP_RESIDENT) tmlqcd_hip_sync_all_to_host();
+  // whenever the host copy is current it is authoritative: a mirror left over from an earlier call may belong to a
+  // host array that has since been rewritten, or to a freed one whose address was recycled
+  for (auto &kv : g_reg) if (kv.second.host_valid) kv.second.dev_valid = false;
   g_mode = mode;
 }
 void tmlqcd_hip_sync_to_host(spinor *field) {
@@ -173,6 +182,7 @@ void tmlqcd_hip_finalize(void) {
   tmhip_destroy(g_ctx);
   g_ctx = nullptr;
   g_gauge_uploaded = false;
+  g_clover_uploaded = false;
 }
 
 // ------------------------------------------------------------------ stencil
@@ -224,6 +234,13 @@ void D_psi(spinor *const P, spinor *const Q) {
     CK(CORE(c, fl, fk));                                                                   \
     done(c, l);                                                                            \
   }
+#define EO_OP_CLOVER(NAME, CORE)                                                           \
+  void NAME(spinor *const l, spinor *const k) {                                            \
+    tmhip_ctx *c = refresh_clover();                                                       \
+    tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);           \
+    CK(CORE(c, fl, fk));                                                                   \
+    done(c, l);                                                                            \
+  }
 EO_OP(Qtm_plus_psi, tmhip_Qtm_plus_psi)        /* tm_operators.c:172-177 */
 EO_OP(Qtm_minus_psi, tmhip_Qtm_minus_psi)      /* tm_operators.c:216-221 */
 EO_OP(Mtm_plus_psi, tmhip_Mtm_plus_psi)        /* tm_operators.c:245-250 */
@@ -268,6 +285,48 @@ void M_minus_1_timesC(spinor *const En, spinor *const On, spinor *const E, spino
   CK(tmhip_H_eo_tm_inv_psi(c, fen, fo, TMHIP_EO, +1.));
   CK(tmhip_H_eo_tm_inv_psi(c, fon, fe, TMHIP_OE, +1.));
   done(c, En); done(c, On);
+}
+
+// ------------------------------------------------------------------ clover twisted mass
+static tmhip_ctx *refresh_clover() {
+  tmhip_ctx *c = refresh(true);
+  if (!g_clover_uploaded) {
+    if (!&sw || !&sw_inv || !sw || !sw_inv) die("clover operator called but the host program has no sw / sw_inv (init_sw_fields)");
+    CK(tmhip_set_clover(c, &sw[0][0][0], &sw_inv[0][0][0]));
+    g_clover_uploaded = true;
+  }
+  return c;
+}
+void tmlqcd_hip_update_clover(void) { g_clover_uploaded = false; }
+EO_OP_CLOVER(Qsw_pm_psi, tmhip_Qsw_pm_psi)      /* clovertm_operators.c:233-245 */
+EO_OP_CLOVER(Msw_plus_psi, tmhip_Msw_plus_psi)  /* clovertm_operators.c:256-261 */
+/* clovertm_operators.c:268-272 */
+void H_eo_sw_inv_psi(spinor *const l, spinor *const k, const int ieo, const int tau3sign, const double mu) {
+  tmhip_ctx *c = refresh_clover();
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_H_eo_sw_inv_psi(c, fl, fk, ieo, tau3sign, mu));
+  done(c, l);
+}
+/* clovertm_operators.c:287-350 (in place) */
+void clover_inv(spinor *const l, const int tau3sign, const double mu) {
+  tmhip_ctx *c = refresh_clover();
+  tmhip_field *fl = in(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_clover_inv(c, fl, tau3sign, mu));
+  done(c, l);
+}
+/* clovertm_operators.c:448-520 */
+void clover_gamma5(const int ieo, spinor *const l, const spinor *const k, const spinor *const j, const double mu) {
+  tmhip_ctx *c = refresh_clover();
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fj = in(c, j, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_clover_gamma5(c, ieo, fl, fk, fj, mu));
+  done(c, l);
+}
+/* clovertm_operators.c:535-600 */
+void clover(const int ieo, spinor *const l, const spinor *const k, const spinor *const j, const double mu) {
+  tmhip_ctx *c = refresh_clover();
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fj = in(c, j, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_clover(c, ieo, fl, fk, fj, mu));
+  done(c, l);
 }
 
 // ------------------------------------------------------------------ site-diagonal ops
@@ -476,14 +535,16 @@ int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, 
   else if (f == &Qtm_minus_psi) op = TMHIP_OP_QTM_MINUS;
   else if (f == &Mtm_plus_psi) op = TMHIP_OP_MTM_PLUS;
   else if (f == &Mtm_minus_psi) op = TMHIP_OP_MTM_MINUS;
+  else if (f == &Qsw_pm_psi) op = TMHIP_OP_QSW_PM;
   if (op >= 0 && N == VOLUME / 2) {
-    tmhip_ctx *c = refresh(true);
+    tmhip_ctx *c = op == TMHIP_OP_QSW_PM ? refresh_clover() : refresh(true);
     tmhip_field *fq = in(c, Q, TMHIP_FIELD_EO), *fp = in(c, P, TMHIP_FIELD_EO);
     int iters = -1;
     CK(tmhip_cg_her(c, fp, fq, max_iter, eps_sq, rel_prec, N, op, &iters, nullptr, 0));
     Mirror &m = g_reg[P];
     m.dev_valid = true; m.host_valid = false;
     download(c, P, m);   // the solution is always handed back on the host
+    if (g_mode == TMLQCD_HIP_COHERENT) m.dev_valid = false;
     return iters;
   }
   // generic path: reference algorithm verbatim on host-visible fields
@@ -522,16 +583,18 @@ int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, 
 /* solver/mixed_cg_her.c:65-202 with f = Qtm_pm_psi: fp32 inner CG + fp64 defect correction, all in HBM */
 int mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params_opaque, const int max_iter, double eps_sq,
                  const int rel_prec, const int N, matrix_mult f, matrix_mult32) {
-  if (f != &Qtm_pm_psi || N != VOLUME / 2) die("mixed_cg_her: only f = Qtm_pm_psi on VOLUME/2 sites runs on the device");
+  if ((f != &Qtm_pm_psi && f != &Qsw_pm_psi) || N != VOLUME / 2) die("mixed_cg_her: only f = Qtm_pm_psi / Qsw_pm_psi on VOLUME/2 sites runs on the device");
+  const int op = f == &Qsw_pm_psi ? TMHIP_OP_QSW_PM : TMHIP_OP_QTM_PM;
   const double innereps = &mixcg_innereps ? mixcg_innereps : 5.0e-5;           /* default_input_values.h:193 */
   const int max_inner = &mixcg_maxinnersolverit ? mixcg_maxinnersolverit : 5000; /* default_input_values.h:194 */
-  tmhip_ctx *c = refresh(true);
+  tmhip_ctx *c = op == TMHIP_OP_QSW_PM ? refresh_clover() : refresh(true);
   tmhip_field *fq = in(c, Q, TMHIP_FIELD_EO), *fp = out(c, P, TMHIP_FIELD_EO);
   int iters = -1, outer = 0;
-  CK(tmhip_mixed_cg_her(c, fp, fq, max_iter, eps_sq, rel_prec, N, TMHIP_OP_QTM_PM, innereps, max_inner, &iters, &outer));
+  CK(tmhip_mixed_cg_her(c, fp, fq, max_iter, eps_sq, rel_prec, N, op, innereps, max_inner, &iters, &outer));
   Mirror &m = g_reg[P];
   m.dev_valid = true; m.host_valid = false;
   download(c, P, m);
+  if (g_mode == TMLQCD_HIP_COHERENT) m.dev_valid = false;
   return iters;
 }
 

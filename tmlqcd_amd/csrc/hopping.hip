@@ -95,17 +95,17 @@ __device__ __forceinline__ double cdotd(V2T w, V2T r) {
 static inline bool fp32_pairs(const tmhip_ctx *ctx) { return ctx->opt_fp32_pairs && ((ctx->g.LZ / 2) % 2 == 0); }
 
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
-                         double cre, double cim, bool comm) {
-  return hop64::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm);
+                         double cre, double cim, bool comm, const v2d *cw) {
+  return hop64::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
 }
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
                              double cre, double cim, int *npartials) {
   return hop64::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials);
 }
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
-                           double cre, double cim, bool comm) {
-  if (fp32_pairs(ctx)) return hop32p::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm);
-  return hop32::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm);
+                           double cre, double cim, bool comm, const v2f *cw) {
+  if (fp32_pairs(ctx)) return hop32p::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
+  return hop32::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
 }
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
                                double cre, double cim, int *npartials) {

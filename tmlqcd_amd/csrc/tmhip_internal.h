@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include "../../include/tmlqcd_hip.h"
 
 typedef double v2d __attribute__((ext_vector_type(2)));  // one complex double: .x = re, .y = im
@@ -65,6 +66,11 @@ struct tmhip_ctx {
   hipEvent_t ev_pack, ev_comm, ev_slots[16];
   v2d *gauge;          // [2][8][9][gs]
   bool gauge_set;
+  // clover twisted mass: site-local blocks uploaded from the host's sw / sw_inv
+  v2d *sw;             // [2 parity][6][9][gs]   sw[ix][a][b] -> block 2a+b
+  v2d *sw_inv;         // [2 sign: +mu, -mu][8][9][gs]  sw_inv[icy][a][b] -> block 2a+b (even sites)
+  bool clover_set;
+  v2f *sw32, *sw_inv32; bool clover32_set;
   v2f *gauge32;        // fp32 twin of the gauge copy (g_gauge_field_copy_32), built on first use
   bool gauge32_set;
   // staging for host<->device layout conversion
@@ -89,13 +95,13 @@ struct tmhip_ctx {
 };
 
 // ---- launch helpers implemented across the .hip files ----
-enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4 };
+enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4, EPI_CLOVER_INV = 5, EPI_CLOVER_G5 = 6, EPI_CLOVER = 7 };
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
-                         double cre, double cim, bool comm);
+                         double cre, double cim, bool comm, const v2d *cw = nullptr);
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
                              double cre, double cim, int *npartials);
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
-                           double cre, double cim, bool comm);
+                           double cre, double cim, bool comm, const v2f *cw = nullptr);
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
                                double cre, double cim, int *npartials);
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx);
@@ -104,7 +110,8 @@ int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes);
 int tmhip_field_alloc_prec(tmhip_ctx *ctx, int kind, int prec, tmhip_field **out);
 int tmhip_halo_exchange(tmhip_ctx *ctx);
 int tmhip_apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k);
-int tmhip_prepare_fp32(tmhip_ctx *ctx);  // fp32 gauge copy + fp32 scratch / solver fields
+int tmhip_prepare_fp32(tmhip_ctx *ctx);
+int tmhip_prepare_clover32(tmhip_ctx *ctx);  // fp32 gauge copy + fp32 scratch / solver fields
 // launch geometry shared by linalg.hip and cg.hip
 #define LA_BS 256
 #define LA_UNROLL 4

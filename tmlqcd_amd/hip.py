@@ -10,7 +10,7 @@ import numpy as np
 
 EO, OE = 0, 1
 FIELD_EO, FIELD_FULL = 0, 1
-OPS = {"Qtm_pm_psi": 0, "Qtm_plus_psi": 1, "Qtm_minus_psi": 2, "Mtm_plus_psi": 3, "Mtm_minus_psi": 4}
+OPS = {"Qtm_pm_psi": 0, "Qtm_plus_psi": 1, "Qtm_minus_psi": 2, "Mtm_plus_psi": 3, "Mtm_minus_psi": 4, "Qsw_pm_psi": 5}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
@@ -75,6 +75,14 @@ def load_library():
         "tmhip_diff": [vp, vp, vp, vp, i],
         "tmhip_assign": [vp, vp, vp, i],
         "tmhip_cg_her": [vp, vp, vp, i, d, i, i, i, C.POINTER(i), pd, i],
+        "tmhip_set_clover": [vp, vp, vp],
+        "tmhip_clover_inv": [vp, vp, i, d],
+        "tmhip_clover_gamma5": [vp, i, vp, vp, vp, d],
+        "tmhip_clover": [vp, i, vp, vp, vp, d],
+        "tmhip_H_eo_sw_inv_psi": [vp, vp, vp, i, i, d],
+        "tmhip_Qsw_pm_psi": [vp, vp, vp],
+        "tmhip_Msw_plus_psi": [vp, vp, vp],
+        "tmhip_Qsw_pm_psi_32": [vp, vp, vp],
         "tmhip_field_alloc32": [vp, C.POINTER(vp)],
         "tmhip_field_upload32": [vp, vp, vp, i],
         "tmhip_field_download32": [vp, vp, vp, i],
@@ -241,6 +249,28 @@ class Lattice:
             f.upload(host, host.shape[0])
         return f
 
+    # --- clover twisted mass (operator/clovertm_operators.h) ---------------
+    def set_clover(self, sw, sw_inv):
+        """sw [V][3][2][3][3][2] from sw_term, sw_inv [V][4][2][3][3][2] from sw_invert(EE, mu) (host arrays)."""
+        if sw.shape != (self.V, 3, 2, 3, 3, 2) or sw_inv.shape != (self.V, 4, 2, 3, 3, 2):
+            raise TmHipError("clover arrays must be [V][3][2][3][3][2] and [V][4][2][3][3][2]")
+        _ck(self.lib.tmhip_set_clover(self.h, _hp(sw), _hp(sw_inv)), "tmhip_set_clover")
+
+    def clover_inv(self, l, tau3sign, mu):
+        _ck(self.lib.tmhip_clover_inv(self.h, l.h, tau3sign, mu), "clover_inv")
+
+    def clover_gamma5(self, ieo, l, k, j, mu):
+        _ck(self.lib.tmhip_clover_gamma5(self.h, ieo, l.h, k.h, j.h, mu), "clover_gamma5")
+
+    def clover(self, ieo, l, k, j, mu):
+        _ck(self.lib.tmhip_clover(self.h, ieo, l.h, k.h, j.h, mu), "clover")
+
+    def H_eo_sw_inv_psi(self, l, k, ieo, tau3sign, mu):
+        _ck(self.lib.tmhip_H_eo_sw_inv_psi(self.h, l.h, k.h, ieo, tau3sign, mu), "H_eo_sw_inv_psi")
+
+    def Qsw_pm_psi_32(self, l, k):
+        _ck(self.lib.tmhip_Qsw_pm_psi_32(self.h, l.h, k.h), "Qsw_pm_psi_32")
+
     # --- mixed precision (reference names with the _32 suffix) -------------
     def assign_to_32(self, r32, s64, N):
         _ck(self.lib.tmhip_assign_to_32(self.h, r32.h, s64.h, N), "assign_to_32")
@@ -270,10 +300,11 @@ class Lattice:
     def assign_mul_add_r_32(self, R, c, S, N):
         _ck(self.lib.tmhip_assign_mul_add_r_32(self.h, R.h, c, S.h, N), "assign_mul_add_r_32")
 
-    def mixed_cg_her(self, P, Q, max_iter, eps_sq, rel_prec, N, innereps=5.0e-5, max_inner_it=5000):
-        """solver/mixed_cg_her.c with f = Qtm_pm_psi, f32 = Qtm_pm_psi_32; returns (iterations, outer iterations)."""
+    def mixed_cg_her(self, P, Q, max_iter, eps_sq, rel_prec, N, innereps=5.0e-5, max_inner_it=5000, op="Qtm_pm_psi"):
+        """solver/mixed_cg_her.c with (f, f32) = (Qtm_pm_psi, Qtm_pm_psi_32) or (Qsw_pm_psi, Qsw_pm_psi_32);
+        returns (iterations, outer iterations)."""
         it, outer = C.c_int(), C.c_int()
-        _ck(self.lib.tmhip_mixed_cg_her(self.h, P.h, Q.h, max_iter, eps_sq, rel_prec, N, OPS["Qtm_pm_psi"], innereps,
+        _ck(self.lib.tmhip_mixed_cg_her(self.h, P.h, Q.h, max_iter, eps_sq, rel_prec, N, OPS[op], innereps,
                                         max_inner_it, C.byref(it), C.byref(outer)), "mixed_cg_her")
         return it.value, outer.value
 
