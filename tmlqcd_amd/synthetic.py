@@ -52,3 +52,38 @@ def spinor_field_eo(seed, parity, T, LX, LY, LZ, nproc_t=1, proc_t=0):
         full = spinor_slice(seed, tg, LX, LY, LZ)
         out.append(full[((sxyz + tg) & 1) == parity])
     return np.ascontiguousarray(np.concatenate(out, axis=0))
+
+
+def eo2lexic_even(T, LX, LY, LZ):
+    """Lexicographic indices of the even sites in e/o order (geometry_eo.c:869-885), single rank."""
+    t, x, y, z = np.meshgrid(np.arange(T), np.arange(LX), np.arange(LY), np.arange(LZ), indexing="ij")
+    par = ((t + x + y + z) & 1).reshape(-1)
+    return np.nonzero(par == 0)[0]
+
+
+def clover_blocks(seed, T, LX, LY, LZ, mu, scale=0.15):
+    """Synthetic clover arrays in the reference's layouts (host-side input like the gauge field):
+    sw[V][3][2][3][3][2]     hermitian 6x6 blocks 1 + T per site and chirality (operator/clover_term.c:60-87)
+    sw_inv[V][4][2][3][3][2] (1 + T +- i mu g5)^-1 on the even sites, +mu set in [0,V/2), -mu set in [V/2,V)
+                             (operator/clover_invert.c:164-257)."""
+    rng = np.random.default_rng([seed, 3])
+    V = T * LX * LY * LZ
+    Vh = V // 2
+    H = rng.standard_normal((V, 2, 6, 6)) + 1j * rng.standard_normal((V, 2, 6, 6))
+    H = np.eye(6) + scale * 0.5 * (H + np.conj(np.swapaxes(H, -1, -2)))
+    sw = np.zeros((V, 3, 2, 3, 3), dtype=np.complex128)
+    sw[:, 0], sw[:, 1], sw[:, 2] = H[:, :, 0:3, 0:3], H[:, :, 0:3, 3:6], H[:, :, 3:6, 3:6]
+    swi = np.zeros((V, 4, 2, 3, 3), dtype=np.complex128)
+    ev = eo2lexic_even(T, LX, LY, LZ)
+    for s, sgn in ((0, +1.0), (1, -1.0)):
+        for chi, g5 in ((0, +1.0), (1, -1.0)):
+            Mi = np.linalg.inv(H[ev, chi] + 1j * sgn * g5 * mu * np.eye(6))
+            sl = slice(s * Vh, (s + 1) * Vh)
+            swi[sl, 0, chi], swi[sl, 1, chi] = Mi[:, 0:3, 0:3], Mi[:, 0:3, 3:6]
+            swi[sl, 2, chi], swi[sl, 3, chi] = Mi[:, 3:6, 3:6], Mi[:, 3:6, 0:3]
+
+    def pack(a):
+        out = np.empty(a.shape + (2,), dtype=np.float64)
+        out[..., 0], out[..., 1] = a.real, a.imag
+        return out
+    return pack(sw), pack(swi)
