@@ -50,6 +50,16 @@ void Qtm_minus_psi(spinor *const l, spinor *const k);
 void Mtm_plus_psi(spinor *const l, spinor *const k);
 void Mtm_plus_psi_nocom(spinor *const l, spinor *const k);
 void Mtm_minus_psi(spinor *const l, spinor *const k);
+/* symmetric e/o preconditioning, operator/tm_operators.h:57-65 */
+void Qtm_plus_sym_psi(spinor *const l, spinor *const k);
+void Qtm_plus_sym_psi_nocom(spinor *const l, spinor *const k);
+void Qtm_minus_sym_psi(spinor *const l, spinor *const k);
+void Mtm_plus_sym_psi(spinor *const l, spinor *const k);
+void Mtm_plus_sym_dagg_psi(spinor *const l, spinor *const k);
+void Mtm_minus_sym_psi(spinor *const l, spinor *const k);
+void Mtm_plus_sym_psi_nocom(spinor *const l, spinor *const k);
+void Mtm_minus_sym_psi_nocom(spinor *const l, spinor *const k);
+void Qtm_pm_sym_psi(spinor *const l, spinor *const k);
 void Qtm_pm_psi(spinor *const l, spinor *const k);
 void Qtm_pm_psi_nocom(spinor *const l, spinor *const k);
 void H_eo_tm_inv_psi(spinor *const l, spinor *const k, const int ieo, const double sign);
@@ -62,6 +72,7 @@ void assign_mul_one_pm_imu(spinor *const l, spinor *const k, const double _sign,
 void mul_one_pm_imu(spinor *const l, const double _sign);
 void mul_one_pm_imu_sub_mul(spinor *const l, spinor *const k, spinor *const j, const double _sign, const int N);
 void mul_one_pm_imu_sub_mul_gamma5(spinor *const l, spinor *const k, spinor *const j, const double _sign); /* tm_operators.c:813 */
+void mul_one_sub_mul_gamma5(spinor *const l, spinor *const k, spinor *const j);                              /* tm_operators.c:781 */
 void Mee_psi(spinor *const l, spinor *const k, const double mu);
 void Mee_inv_psi(spinor *const l, spinor *const k, const double mu);
 void Q_pm_psi(spinor *const l, spinor *const k);
@@ -98,15 +109,33 @@ void clover_gamma5(const int ieo, spinor *const l, const spinor *const k, const 
 void clover(const int ieo, spinor *const l, const spinor *const k, const spinor *const j, const double mu);        /* :535 */
 
 /* ---- solver/mixed_cg_her.h ------------------------------ */
-/* `solver_params_t` (solver/solver_params.h:46) is passed BY VALUE but not used by the reference's mixed_cg_her
- * (solver/mixed_cg_her.c:65-202 reads the globals mixcg_innereps / mixcg_maxinnersolverit, read_input.h:112-113).
- * Any struct larger than 16 bytes is passed in memory under the SysV ABI and leaves the register arguments
- * (P, Q, max_iter, eps_sq, rel_prec, N, f) where the caller put them, so it is declared opaque here; the
- * stack-passed `f32` is not read (the fp32 operator is always Qtm_pm_psi_32). */
-typedef struct { double opaque[64]; } tmlqcd_solver_params_opaque;
+/* `solver_params_t` (solver/solver_params.h:46-109) is passed BY VALUE.  Being larger than 16 bytes it travels in
+ * memory under the SysV ABI, ahead of the stack-passed `f32`, so the callee must know its exact size and the offset
+ * of the one field read on this path (mcg_delta, solver_params.h:68).  The mirror below restates that layout --
+ * field order and types are ABI, like `spinor` and `su3` -- with neutral names for the fields this library never
+ * reads.  tests/test_gpu_link_reference_caller.py has reference code build the struct and call through it. */
 typedef void (*matrix_mult32)(void *const, void *const);   /* solver/matrix_mult_typedef.h:32 */
-int mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params_opaque solver_params, const int max_iter,
+typedef struct {
+  int eigcg_i[5];                  /* eigcg_nrhs .. eigcg_ldh */
+  double eigcg_d[3];               /* eigcg_tolsq1, eigcg_tolsq, eigcg_restolsq */
+  int eigcg_rand_guess_opt;
+  float mcg_delta;                 /* reliable-update threshold of rg_mixed_cg_her */
+  int type, max_iter, rel_prec, no_shifts, sdim;
+  double squared_solver_prec;
+  void (*M_psi)(spinor *const, spinor *const);
+  matrix_mult32 M_psi32;
+  void (*M_ndpsi)(spinor *const, spinor *const, spinor *const, spinor *const);
+  void (*M_ndpsi32)(void *const, void *const, void *const, void *const);
+  double *shifts;
+  int solution_type, compression_type, sloppy_precision, external_inverter;   /* enums, misc_types.h */
+} tmlqcd_solver_params;
+/* solver/mixed_cg_her.c:65-202 reads the globals mixcg_innereps / mixcg_maxinnersolverit (read_input.h:112-113),
+ * not the struct. */
+int mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params solver_params, const int max_iter,
                  double eps_sq, const int rel_prec, const int N, matrix_mult f, matrix_mult32 f32);
+/* solver/rg_mixed_cg_her.c:180 */
+int rg_mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params solver_params, const int max_iter,
+                    const double eps_sq, const int rel_prec, const int N, matrix_mult f, matrix_mult32 f32);
 
 /* ---- residency control (additions; not in the reference) ------------------- */
 enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1 };

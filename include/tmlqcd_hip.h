@@ -92,6 +92,7 @@ int tmhip_assign_mul_one_pm_imu(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, 
 int tmhip_mul_one_pm_imu(tmhip_ctx *ctx, tmhip_field *l, double sign);
 int tmhip_mul_one_pm_imu_sub_mul(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, tmhip_field *j, double sign, int N);
 int tmhip_mul_one_pm_imu_sub_mul_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, tmhip_field *j, double sign);
+int tmhip_mul_one_sub_mul_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, tmhip_field *j); /* tm_operators.c:781-810 */
 int tmhip_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int N); /* gamma.c:77-98 */
 
 /* ---- e/o compositions (operator/tm_operators.c) -------------------------- */
@@ -103,6 +104,13 @@ int tmhip_Mtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);  /* :28
 int tmhip_Qtm_pm_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);     /* :338-345 */
 int tmhip_M_full(tmhip_ctx *ctx, tmhip_field *Even_new, tmhip_field *Odd_new,
                  tmhip_field *Even, tmhip_field *Odd);                    /* :117-128 */
+/* symmetric e/o preconditioning  1 - A^-1 H_oe A^-1 H_eo  (non-hermitian solvers of invert_eo.c:177-280) */
+int tmhip_Qtm_plus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);      /* :186-192 */
+int tmhip_Qtm_minus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);     /* :223-229 */
+int tmhip_Mtm_plus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);      /* :259-265 */
+int tmhip_Mtm_minus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);     /* :296-302 */
+int tmhip_Mtm_plus_sym_dagg_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k); /* :312-322, l != k */
+int tmhip_Qtm_pm_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);        /* :347-364 (returns what the reference returns) */
 
 /* ---- spinor linalg (linalg/ of the reference) ---------------------------- */
 /* `parallel` != 0 adds the cross-rank sum (MPI_Allreduce in the reference). */
@@ -158,6 +166,11 @@ int tmhip_assign_mul_add_r_32(tmhip_ctx *ctx, tmhip_field *R, float c, tmhip_fie
  * (default_input_values.h:193-194: 5.0e-5, 5000).  *iters = the reference's return value (-1: not converged). */
 int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N,
                        int op, double innereps, int max_inner_it, int *iters, int *outer_iters);
+/* solver/rg_mixed_cg_her.c:180-347: fp32 CG with reliable updates (restart when the iterated residual fell by `delta`
+ * relative to its maximum since the last update) and an fp64 fail-safe.  *iters = iter_out + iter_in_sp + iter_in_dp
+ * as the reference returns it, or -1; the three counters are reported separately when the pointers are non-NULL. */
+int tmhip_rg_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N,
+                          int op, double delta, int *iters, int *iter_out, int *iter_in_sp, int *iter_in_dp);
 
 /* ---- multi-GPU halo exchange (replaces xchange_field / xchange_halffield,
  *      xchange/xchange_field.c:269-470, xchange/xchange_halffield.c:176-263) -- */

@@ -111,6 +111,55 @@ def gen_clover(T, L):
     print("clover", tag, scal)
 
 
+SYM_OPS = ("Qtm_plus_sym_psi", "Qtm_minus_sym_psi", "Mtm_plus_sym_psi", "Mtm_minus_sym_psi", "Mtm_plus_sym_dagg_psi",
+           "Qtm_pm_sym_psi")
+
+
+def gen_sym(T, L):
+    """Symmetric e/o preconditioning family (tm_operators.c:186-364) on the same gauge / source as ref_fields_*."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle.refbind import RefLattice
+    kappa, mu = 0.125, 0.01
+    r = RefLattice(T, L, L, L, kappa=kappa, mu=mu, nfields=14)
+    r.random_fields(123456)
+    N = r.V // 2
+    arrs = {}
+    for name in SYM_OPS:
+        getattr(r.lib, name)(r.sp(3), r.sp(0))
+        arrs[name] = r.spinor(3, N).copy()
+    np.savez_compressed(os.path.join(GOLD, "ref_sym_fields_%dx%d.npz" % (T, L)), **arrs)
+    print("sym", T, L, {k: float((v ** 2).sum()) for k, v in arrs.items()})
+
+
+def gen_rg(T, L, full):
+    """solver/rg_mixed_cg_her.c:180 run by the reference's default (half-spinor) build: iteration counts for two
+    values of mcg_delta, and the 4^4 solution."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import numpy as np
+    from oracle.refbind import RefLattice
+    kappa, mu = 0.125, 0.01
+    r = RefLattice(T, L, L, L, kappa=kappa, mu=mu, nfields=16, hs=True)
+    r.random_fields(123456)
+    lib, N = r.lib, r.V // 2
+    lib.tmref_convert_gauge_32()
+    scal = {"T": T, "L": L, "kappa": kappa, "mu": mu, "seed": 123456, "eps_sq": 1e-20, "rel_prec": 1, "runs": []}
+    arrs = {}
+    for delta in (0.1, 5.0e-5, 0.25, 0.5):   # 0.25 ends in the fp64 fail-safe, 0.5 exhausts N_outer (-1); 5e-5 = _default_mixcg_innereps, the value operator.c:125 puts into mcg_delta
+        it = r.rg_mixed_cg_her(1, 0, delta, 2000, 1e-20, 1)
+        lib.Qtm_pm_psi(r.sp(2), r.sp(1)); lib.diff(r.sp(2), r.sp(0), r.sp(2), N)
+        res = lib.square_norm(r.sp(2), N, 0) / lib.square_norm(r.sp(0), N, 0)
+        scal["runs"].append({"delta": delta, "iters": it, "true_rel_res_sq": res})
+        if full:
+            arrs["solution_delta_%g" % delta] = r.spinor(1, N).copy()
+    tag = "%dx%d" % (T, L)
+    json.dump(scal, open(os.path.join(GOLD, "ref_rg_scalars_%s.json" % tag), "w"), indent=1)
+    if full:
+        np.savez_compressed(os.path.join(GOLD, "ref_rg_fields_%s.npz" % tag), **arrs)
+    print("rg", tag, scal)
+
+
 def gen_hs(T, L):
     """Default (half-spinor) build of the reference: fp64 cross-check + fp32 twins of the mixed-precision CG."""
     sys.path.insert(0, ROOT)
@@ -140,6 +189,10 @@ def gen_hs(T, L):
 if __name__ == "__main__":
     if len(sys.argv) == 4 and sys.argv[3] == "hs":
         gen_hs(int(sys.argv[1]), int(sys.argv[2]))
+    elif len(sys.argv) == 4 and sys.argv[3] in ("rg", "rgfull"):
+        gen_rg(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "rgfull")
+    elif len(sys.argv) == 4 and sys.argv[3] == "sym":
+        gen_sym(int(sys.argv[1]), int(sys.argv[2]))
     elif len(sys.argv) == 4 and sys.argv[3] == "clover":
         gen_clover(int(sys.argv[1]), int(sys.argv[2]))
     elif len(sys.argv) == 4:
@@ -147,5 +200,8 @@ if __name__ == "__main__":
     else:
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "hs"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "clover"])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "sym"])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "rgfull"])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "8", "8", "rg"])
         for T, L, full in ((4, 4, 1), (8, 8, 0), (6, 4, 0)):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), str(T), str(L), str(full)])

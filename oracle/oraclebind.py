@@ -44,7 +44,8 @@ def _lib():
         lib.tmo_mul_one_pm_imu_sub_mul_gamma5.argtypes = [vp, vp, vp, vp, d]
         lib.tmo_gamma5.argtypes = [vp, vp, i]
         lib.tmo_H_eo_tm_inv_psi.argtypes = [vp, vp, vp, i, d]
-        for n in ("Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi", "Qtm_pm_psi"):
+        for n in ("Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi", "Qtm_pm_psi", "Qtm_plus_sym_psi",
+                  "Qtm_minus_sym_psi", "Mtm_plus_sym_psi", "Mtm_minus_sym_psi", "Mtm_plus_sym_dagg_psi", "Qtm_pm_sym_psi"):
             getattr(lib, "tmo_" + n).argtypes = [vp, vp, vp]
         lib.tmo_M_full.argtypes = [vp] * 5
         lib.tmo_set_clover.argtypes = [vp, vp, vp]

@@ -87,6 +87,32 @@ int tmref_init(int T_, int LX_, int LY_, int LZ_, double kappa, double mu,
 #ifdef _USE_HALFSPINOR
 /* invert.c:299 */
 void tmref_convert_gauge_32(void) { convert_32_gauge_field(g_gauge_field_32, g_gauge_field, VOLUMEPLUSRAND); g_update_gauge_copy_32 = 1; }
+
+#endif
+
+#if defined(_USE_HALFSPINOR) || defined(TMREF_HOSTPROG)
+/* Calls rg_mixed_cg_her (solver/rg_mixed_cg_her.c:180) the way solver/monomial_solve.c does: solver_params_t by
+ * value with mcg_delta set, f = Qtm_pm_psi.  In the half-spinor build this is the reference's own solver with
+ * f32 = Qtm_pm_psi_32; in the host-program build (TMREF_HOSTPROG) the symbol resolves to the drop-in library,
+ * which proves the by-value struct + stack-passed f32 calling sequence against compiler-generated reference code. */
+#include "operator/tm_operators.h"
+#include "operator/tm_operators_32.h"
+#include "solver/solver_params.h"
+#include "solver/rg_mixed_cg_her.h"
+int tmref_rg_mixed_cg_her(spinor *P, spinor *Q, double delta, int max_iter, double eps_sq, int rel_prec, int N, int debug) {
+  solver_params_t sp;
+  memset(&sp, 0x5a, sizeof(sp));          /* everything but mcg_delta is junk on purpose: nothing else may be read */
+  sp.mcg_delta = (float)delta;
+  const int saved = g_debug_level;
+  g_debug_level = debug;
+#ifdef _USE_HALFSPINOR
+  const int it = rg_mixed_cg_her(P, Q, sp, max_iter, eps_sq, rel_prec, N, &Qtm_pm_psi, &Qtm_pm_psi_32);
+#else
+  const int it = rg_mixed_cg_her(P, Q, sp, max_iter, eps_sq, rel_prec, N, &Qtm_pm_psi, (matrix_mult32)0);
+#endif
+  g_debug_level = saved;
+  return it;
+}
 #endif
 
 void tmref_set_theta(double x0, double x1, double x2, double x3) {

@@ -57,7 +57,8 @@ class RefLattice:
         lib.assign.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.gamma5.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         for name in ("Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi",
-                     "D_psi", "Q_pm_psi", "Q_plus_psi", "Q_minus_psi"):
+                     "D_psi", "Q_pm_psi", "Q_plus_psi", "Q_minus_psi", "Qtm_plus_sym_psi", "Qtm_minus_sym_psi",
+                     "Mtm_plus_sym_psi", "Mtm_minus_sym_psi", "Mtm_plus_sym_dagg_psi", "Qtm_pm_sym_psi"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
             getattr(lib, name).restype = None
         lib.M_full.argtypes = [C.c_void_p] * 4
@@ -87,10 +88,17 @@ class RefLattice:
             lib.scalar_prod_r_32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
             lib.assign_add_mul_r_32.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
             lib.assign_mul_add_r_32.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int]
+            lib.tmref_rg_mixed_cg_her.restype = C.c_int
+            lib.tmref_rg_mixed_cg_her.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_int,
+                                                  C.c_int, C.c_int]
         rc = lib.tmref_init(T, LX, LY, LZ, kappa, mu, nfields, threads)
         if rc != 0:
             raise RuntimeError("tmref_init failed: %d" % rc)
         self.threads = lib.tmref_threads()
+
+    def rg_mixed_cg_her(self, iP, iQ, delta, max_iter, eps_sq, rel_prec, debug=0):
+        """solver/rg_mixed_cg_her.c:180 on g_spinor_field[iP], [iQ] (half-spinor build only)."""
+        return self.lib.tmref_rg_mixed_cg_her(self.sp(iP), self.sp(iQ), delta, max_iter, eps_sq, rel_prec, self.V // 2, debug)
 
     # ---- raw views onto the reference's own arrays (no copies) ----
     def gauge(self):

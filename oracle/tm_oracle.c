@@ -490,6 +490,72 @@ void tmo_Qtm_pm_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
   tmo_H_eo_tm_inv_psi(lat, lat->scratch[1], lat->scratch[0], EO, +1);
   tmo_tm_sub_H_eo_gamma5(lat, l, lat->scratch[0], lat->scratch[1], OE, +1);
 }
+/* operator/tm_operators.c:781-810 : l = gamma5 (k - j) */
+void tmo_mul_one_sub_mul_gamma5(tmo_lattice *lat, tmo_spinor *l, const tmo_spinor *k, const tmo_spinor *j) {
+  const int N = lat->V / 2;
+#pragma omp parallel for
+  for (int ix = 0; ix < N; ix++) {
+    const tmo_spinor *r = k + ix, *s = j + ix;
+    tmo_spinor o;
+    o.s0 = v_sub(r->s0, s->s0); o.s1 = v_sub(r->s1, s->s1); o.s2 = v_sub(s->s2, r->s2); o.s3 = v_sub(s->s3, r->s3);
+    l[ix] = o;
+  }
+}
+/* the "symmetric" family: scratch[0] <- A^-1 H_oe A^-1 H_eo k with A = 1 + sign i mu g5
+ * (first four statements of operator/tm_operators.c:186-192, 223-229, 259-265, 296-302) */
+static void tmo_sym_core(tmo_lattice *lat, tmo_spinor *k, double sign) {
+  const int N = lat->V / 2;
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
+  tmo_mul_one_pm_imu_inv(lat, lat->scratch[1], sign, N);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
+  tmo_mul_one_pm_imu_inv(lat, lat->scratch[0], sign, N);
+}
+/* operator/tm_operators.c:186-192 */
+void tmo_Qtm_plus_sym_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_sym_core(lat, k, +1.);
+  tmo_mul_one_sub_mul_gamma5(lat, l, k, lat->scratch[0]);
+}
+/* operator/tm_operators.c:223-229 */
+void tmo_Qtm_minus_sym_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_sym_core(lat, k, -1.);
+  tmo_mul_one_sub_mul_gamma5(lat, l, k, lat->scratch[0]);
+}
+/* operator/tm_operators.c:259-265 */
+void tmo_Mtm_plus_sym_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_sym_core(lat, k, +1.);
+  tmo_diff(l, k, lat->scratch[0], lat->V / 2);
+}
+/* operator/tm_operators.c:296-302 */
+void tmo_Mtm_minus_sym_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_sym_core(lat, k, -1.);
+  tmo_diff(l, k, lat->scratch[0], lat->V / 2);
+}
+/* operator/tm_operators.c:312-322 */
+void tmo_Mtm_plus_sym_dagg_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  const int N = lat->V / 2;
+  tmo_gamma5(l, k, N);
+  tmo_mul_one_pm_imu_inv(lat, l, -1., N);
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[1], l);
+  tmo_mul_one_pm_imu_inv(lat, lat->scratch[1], -1., N);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
+  tmo_gamma5(lat->scratch[1], lat->scratch[0], N);
+  tmo_diff(l, k, lat->scratch[1], N);
+}
+/* operator/tm_operators.c:347-364, statement for statement -- including the second half, which applies its
+ * stencils to scratch[0] but then rebuilds l from k and scratch[0] again (so the function does not return
+ * Q_+ Q_- in the symmetric scheme; the oracle restates what the reference computes, not what it may have meant). */
+void tmo_Qtm_pm_sym_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  const int N = lat->V / 2;
+  tmo_sym_core(lat, k, -1.);
+  tmo_diff(l, k, lat->scratch[0], N);
+  tmo_gamma5(l, l, N);
+  tmo_Hopping_Matrix(lat, EO, l, lat->scratch[0]);
+  tmo_mul_one_pm_imu_inv(lat, l, +1., N);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[1], l);
+  tmo_mul_one_pm_imu_inv(lat, lat->scratch[0], +1., N);
+  tmo_diff(l, k, lat->scratch[0], N);
+  tmo_gamma5(l, l, N);
+}
 /* operator/tm_operators.c:117-128 */
 void tmo_M_full(tmo_lattice *lat, tmo_spinor *Even_new, tmo_spinor *Odd_new,
                 const tmo_spinor *Even, const tmo_spinor *Odd) {

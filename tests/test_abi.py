@@ -14,6 +14,7 @@ def declared_functions(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     txt = re.sub(r"//.*", "", txt)
+    txt = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", txt, flags=re.S)
     txt = re.sub(r"typedef[^;]*;", "", txt)
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", txt)
     return sorted(set(n for n in names if n not in ("defined", "matrix_mult")))
@@ -38,7 +39,10 @@ def test_dropin_library_exports_reference_symbols():
                  "Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi", "M_full", "Q_full",
                  "H_eo_tm_inv_psi", "mul_one_pm_imu_inv", "assign_mul_one_pm_imu_inv", "assign_mul_one_pm_imu",
                  "mul_one_pm_imu_sub_mul", "square_norm", "scalar_prod_r", "assign_add_mul_r", "assign_mul_add_r",
-                 "assign_mul_add_r_and_square", "diff", "assign", "cg_her", "gamma5"):
+                 "assign_mul_add_r_and_square", "diff", "assign", "cg_her", "gamma5", "Qtm_plus_sym_psi",
+                 "Qtm_minus_sym_psi", "Mtm_plus_sym_psi", "Mtm_minus_sym_psi", "Mtm_plus_sym_dagg_psi", "Qtm_pm_sym_psi",
+                 "Mtm_plus_sym_psi_nocom", "Mtm_minus_sym_psi_nocom", "Qtm_plus_sym_psi_nocom", "mixed_cg_her",
+                 "Qsw_pm_psi", "clover_inv", "clover_gamma5"):
         assert must in names, must
     exp = exported(os.path.join(LIB, "libtmlqcd_dropin.so"))
     missing = [n for n in names if n not in exp]

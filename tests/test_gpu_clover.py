@@ -110,5 +110,9 @@ def test_clover_cg_and_mixed_cg(setup8):
     chk = orc.new_field(); orc.op("Qsw_pm_psi", chk, full)
     assert ((chk[:N] - q) ** 2).sum() / (q ** 2).sum() <= 1e-20
     assert rel_err(sol, P[:N]) < 1e-8
+    # reliable-update variant (solver/rg_mixed_cg_her.c:180) with f32 = Qsw_pm_psi_32
+    itr, (n_out, n_sp, n_dp) = lat.rg_mixed_cg_her(dp, dq, 5000, 1e-20, 1, N, delta=0.1, op="Qsw_pm_psi")
+    assert itr > 0 and itr == n_out + n_sp + n_dp and n_out >= 2
+    assert rel_err(dp.download(), P[:N]) < 1e-8
     for f in (dq, dp, d32, l32):
         f.free()

@@ -53,8 +53,15 @@ chk = o.new_field(); o.op("Qtm_pm_psi", chk, full)
 res = float(((chk[:N] - src) ** 2).sum() / (src ** 2).sum())
 Pref = o.new_field(); it_ref, _ = o.cg_her(Pref, src.copy(), 1000, 1e-20, 1, N)
 err = float(np.abs(sol - Pref[:N]).max() / np.abs(Pref[:N]).max())
+# reference-compiled caller builds solver_params_t (junk except mcg_delta) and passes it BY VALUE to our
+# rg_mixed_cg_her (solver/rg_mixed_cg_her.c:180); f32 travels on the stack behind the 144-byte struct
+host.tmref_rg_mixed_cg_her.restype = C.c_int
+host.tmref_rg_mixed_cg_her.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]
+view(2)[:] = 7.0                                           # the solver must zero its result field itself
+it_rg = host.tmref_rg_mixed_cg_her(sp(2), sp(0), 0.1, 1000, 1e-20, 1, N, 0)
+err_rg = float(np.abs(view(2) - Pref[:N]).max() / np.abs(Pref[:N]).max())
 dropin.tmlqcd_hip_finalize()
-print(json.dumps({"iters": it, "iters_oracle": it_ref, "true_res_rel": res, "sol_err": err}))
+print(json.dumps({"iters": it, "iters_oracle": it_ref, "true_res_rel": res, "sol_err": err, "iters_rg": it_rg, "sol_err_rg": err_rg}))
 '''
 
 
@@ -68,3 +75,6 @@ def test_reference_cg_her_object_code_drives_the_drop_in():
     assert abs(d["iters"] - gold["cg_iters"]) <= 1           # 36 iterations in the all-reference run
     assert abs(d["iters"] - d["iters_oracle"]) <= 1
     assert d["true_res_rel"] <= 4e-20 and d["sol_err"] < 1e-8
+    rg = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_rg_scalars_8x8.json")))["runs"][0]
+    assert rg["delta"] == 0.1 and abs(d["iters_rg"] - rg["iters"]) <= 6      # 59 in the all-reference run
+    assert d["sol_err_rg"] < 1e-8

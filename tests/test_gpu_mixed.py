@@ -159,3 +159,65 @@ def test_fp32_operators_against_reference_fp32_fixture():
     assert abs(lat.square_norm_32(d32, N) - s["square_norm_32_in"]) <= 1e-6 * s["square_norm_32_in"]
     assert abs(lat.scalar_prod_r_32(d32, b, N) - s["scalar_prod_r_32_in_Qpm"]) <= 1e-5 * abs(s["scalar_prod_r_32_in_Qpm"])
     lat.close()
+
+
+# ------------------------------------------------------------------ rg_mixed_cg_her (solver/rg_mixed_cg_her.c:180)
+def _rg_fixture():
+    import json, os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    f = np.load(os.path.join(gold, "ref_fields_4x4.npz"))
+    g = np.load(os.path.join(gold, "ref_rg_fields_4x4.npz"))
+    s = json.load(open(os.path.join(gold, "ref_rg_scalars_4x4.json")))
+    return f, g, s
+
+
+def test_rg_mixed_cg_her_against_reference_run():
+    """Same gauge field, source, eps and mcg_delta as the reference's own rg_mixed_cg_her (default half-spinor
+    build, oracle/make_golden.py rgfull).  fp32 rounding differs (full spinors vs half spinors, reduction order),
+    so restart points may move by an iteration or two; the solution must agree to fp64-solver accuracy."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    f, g, s = _rg_fixture()
+    lat = Lattice(4, 4, 4, 4, kappa=s["kappa"], mu=s["mu"])
+    orc = Oracle(4, 4, 4, 4, kappa=s["kappa"], mu=s["mu"])
+    gauge = np.ascontiguousarray(f["gauge"])
+    lat.set_gauge(gauge); orc.set_gauge(gauge)
+    N = lat.Vh
+    src = np.ascontiguousarray(f["in"])
+    dq, dp = lat.field(src), lat.field()
+    for run in s["runs"]:
+        dp.upload(np.full_like(src, 3.0))               # "initial guess currently not supported": P is zeroed inside
+        it, (n_out, n_sp, n_dp) = lat.rg_mixed_cg_her(dp, dq, 2000, s["eps_sq"], s["rel_prec"], N, delta=run["delta"])
+        if run["iters"] < 0:                            # delta = 0.5: N_outer exhausted -> convergence failure, like the reference
+            assert it == -1 and n_dp > 0, (run, it, n_out, n_sp, n_dp)
+            continue
+        assert it > 0 and it == n_out + n_sp + n_dp
+        assert abs(it - run["iters"]) <= max(3, run["iters"] // 8), (run, it, n_out, n_sp, n_dp)
+        sol = dp.download()
+        assert rel(sol, g["solution_delta_%g" % run["delta"]]) < 1e-8
+        full = orc.new_field(); full[:N] = sol
+        chk = orc.new_field(); orc.op("Qtm_pm_psi", chk, full)
+        assert ((chk[:N] - src) ** 2).sum() / (src ** 2).sum() <= s["eps_sq"]
+    lat.close()
+
+
+def test_rg_mixed_cg_her_8x8(setup):
+    orc, lat = setup
+    N = orc.Vh
+    q = random_spinor(14, N)
+    dq, dp = lat.field(q), lat.field()
+    P = orc.new_field(); it64, _ = orc.cg_her(P, q.copy(), 5000, 1e-20, 1, N)
+    for delta in (5.0e-5, 0.1):
+        it, (n_out, n_sp, n_dp) = lat.rg_mixed_cg_her(dp, dq, 5000, 1e-20, 1, N, delta=delta)
+        assert it > 0 and n_out >= 2 and it == n_out + n_sp + n_dp
+        assert rel(dp.download(), P[:N]) < 1e-8
+        assert n_sp + n_dp < 2.0 * it64 + 20
+    # iteration cap: max_iter smaller than needed -> -1 like rg_mixed_cg_her.c:303-304
+    it, _ = lat.rg_mixed_cg_her(dp, dq, 10, 1e-20, 1, N, delta=0.1)
+    assert it == -1
+    # absolute precision branch (rel_prec = 0)
+    it, _ = lat.rg_mixed_cg_her(dp, dq, 5000, 1e-14, 0, N, delta=0.1)
+    full = orc.new_field(); full[:N] = dp.download()
+    chk = orc.new_field(); orc.op("Qtm_pm_psi", chk, full)
+    assert it > 0 and ((chk[:N] - q) ** 2).sum() <= 1e-14
+    dq.free(); dp.free()

@@ -100,7 +100,9 @@ def test_site_diagonal_ops_and_aliasing(setup, sign):
         f.free()
 
 
-@pytest.mark.parametrize("name", ["Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi"])
+@pytest.mark.parametrize("name", ["Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi",
+                                  "Qtm_plus_sym_psi", "Qtm_minus_sym_psi", "Mtm_plus_sym_psi", "Mtm_minus_sym_psi",
+                                  "Mtm_plus_sym_dagg_psi", "Qtm_pm_sym_psi"])
 def test_eo_operators(setup, name):
     orc, lat = setup
     N = orc.Vh
@@ -255,6 +257,10 @@ def test_golden_fixture_from_reference_on_gpu():
     for name in ("Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi"):
         lat.op(name, d2, d0)
         assert rel_err(d2.download(), f[name]) < TOL, name
+    g = np.load(os.path.join(GOLD, "ref_sym_fields_4x4.npz"))
+    for name in g.files:                      # symmetric preconditioning family, tm_operators.c:186-364
+        lat.op(name, d2, d0)
+        assert rel_err(d2.download(), g[name]) < TOL, name
     c = complex(*s["cfactor"])
     lat.tm_times_Hopping_Matrix(1, d2, d1, c)
     assert rel_err(d2.download(), f["tm_times_OE_of_Heo"]) < TOL

@@ -95,6 +95,20 @@ def test_golden_4x4_operators(gold4, name):
     assert np.array_equal(out[:N], f[name])
 
 
+SYM_OPS = ["Qtm_plus_sym_psi", "Qtm_minus_sym_psi", "Mtm_plus_sym_psi", "Mtm_minus_sym_psi", "Mtm_plus_sym_dagg_psi",
+           "Qtm_pm_sym_psi"]
+
+
+@pytest.mark.parametrize("name", SYM_OPS)
+def test_golden_4x4_symmetric_preconditioning_family(gold4, name):
+    """tm_operators.c:186-364 (operators of the non-hermitian solvers, invert_eo.c:177-280)."""
+    o, f, s = gold4
+    g = np.load(os.path.join(GOLD, "ref_sym_fields_4x4.npz"))
+    out = o.new_field()
+    o.op(name, out, np.ascontiguousarray(f["in"]))
+    assert np.array_equal(out[:o.Vh], g[name])
+
+
 def test_golden_4x4_M_full_and_D_psi(gold4):
     o, f, s = gold4
     N = o.Vh

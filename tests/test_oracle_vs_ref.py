@@ -38,7 +38,8 @@ for ieo in (0, 1):
     c = -0.37 + 0.91j
     o.tm_times_Hopping_Matrix(ieo, l2, k, c); lib.tm_times_Hopping_Matrix(ieo, sp(2), sp(0), c.real, c.imag); same(l2, 2, "tm_times")
     o.tm_sub_Hopping_Matrix(ieo, l2, l, k, c); lib.tm_sub_Hopping_Matrix(ieo, sp(2), sp(1), sp(0), c.real, c.imag); same(l2, 2, "tm_sub")
-for name in ("Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi"):
+for name in ("Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi", "Qtm_plus_sym_psi",
+             "Qtm_minus_sym_psi", "Mtm_plus_sym_psi", "Mtm_minus_sym_psi", "Mtm_plus_sym_dagg_psi", "Qtm_pm_sym_psi"):
     o.op(name, q, k); getattr(lib, name)(sp(3), sp(0)); same(q, 3, name)
 # in-place Qtm_minus_psi as invert_eo.c:270 calls it
 a = k.copy(); b = o.new_field(); b[:N] = a

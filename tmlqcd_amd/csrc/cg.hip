@@ -14,6 +14,9 @@ struct CgState {
   // inner loop of mixed_cg_her (mixed_cg_her.c:141): stop when err <= innereps * sqnrm_outer, after max_inner
   // iterations, or when 1.3 err already meets the outer target
   int inner; int max_inner; double innereps, sqnrm_outer;
+  // inner loops of rg_mixed_cg_her (rg_mixed_cg_her.c:74-176), inner = 2 (float scalars) / 3 (double scalars):
+  // run while rho > delta * rhomax and iter_base + j <= max_total; leave early when 1.3 rho < eps_sq
+  double delta, rhomax; int iter_base, max_total;
 };
 
 __device__ __forceinline__ double cg_wave_reduce(double v) {
@@ -120,7 +123,35 @@ __global__ void cg_scalar_kernel(CgState *st, const double *sum, double *hist, i
   if (st->done) return;
   if (WHICH == 0) {
     st->pro = *sum;
-    st->alpha = st->normsq / st->pro;
+    if (st->inner == 2) st->alpha = (double)((float)st->normsq / (float)st->pro);   // float alpha, rg_mixed_cg_her.c:126
+    else st->alpha = st->normsq / st->pro;
+  } else if (st->inner >= 2) {
+    st->it += 1;
+    bool stop;
+    if (st->inner == 2) {          // rg_mixed_cg_her.c:122-145, scalars in float like the reference
+      const float rho = (float)*sum, eps = (float)st->eps_sq, delta = (float)st->delta;
+      float rhomax = (float)st->rhomax;
+      st->err = rho;
+      st->beta = (double)(rho / (float)st->normsq);
+      st->normsq = rho;
+      stop = 1.3 * rho < eps;
+      if (!stop) {
+        if (rho > rhomax) rhomax = rho;
+        st->rhomax = rhomax;
+        stop = !(rho > delta * rhomax && st->it + st->iter_base <= st->max_total);
+      }
+    } else {                       // inner_loop_high, rg_mixed_cg_her.c:74-108
+      const double rho = *sum;
+      st->err = rho;
+      st->beta = rho / st->normsq;
+      st->normsq = rho;
+      stop = 1.3 * rho < st->eps_sq;
+      if (!stop) {
+        if (rho > st->rhomax) st->rhomax = rho;
+        stop = !(rho > st->delta * st->rhomax && st->it + st->iter_base <= st->max_total);
+      }
+    }
+    if (stop) { st->done = 1; st->iters = st->it; }
   } else {
     const double err = *sum;
     st->err = err;
@@ -354,4 +385,170 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
   *iters = -1;
   if (outer_iters) *outer_iters = N_outer;
   return 0;
+}
+
+// ------------------------------------------------------------------ reliable-update mixed CG
+// One CG iteration enqueued on ctx->stream, fp32 or fp64 fields: q = A p ; alpha ; x += alpha p ; r -= alpha q ;
+// rho ; beta ; p = beta p + r.   f.q and f.r swap roles each iteration exactly as sf[0]/sf[1] do in tmhip_cg_her.
+struct RgFields { tmhip_field *x, *p, *q, *r; };
+
+static int rg_enqueue_iteration(tmhip_ctx *ctx, int op, bool fp32, bool fused, RgFields &f, CgState *st, int N) {
+  const dim3 g = la_grid(N);
+  const int nblk = g.x * g.y;
+  double *sum = ctx->result_dev + 1;
+  const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
+  int ndot = nblk;
+  if (fp32) {
+    if (op == TMHIP_OP_QSW_PM) {
+      if (tmhip_Qsw_pm_psi_32(ctx, f.q, f.p)) return 1;
+      hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)f.p->d32, (const v2f *)f.q->d32, f.p->ns, N, ctx->partials, st);
+    } else {
+      v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
+      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, f.p->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
+      if (tmhip_launch_hopping32(ctx, TMHIP_OE, s0, s1, f.p->d32, EPI_TM_SUB_G5, 1., -mu, true)) return 1;
+      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true)) return 1;
+      if (fused) {
+        if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, f.q->d32, s1, s0, f.p->d32, 1., mu, &ndot)) return 1;
+      } else {
+        if (tmhip_launch_hopping32(ctx, TMHIP_OE, f.q->d32, s1, s0, EPI_TM_SUB_G5, 1., mu, true)) return 1;
+        hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)f.p->d32, (const v2f *)f.q->d32, f.p->ns, N, ctx->partials, st);
+      }
+    }
+  } else {
+    if (tmhip_apply_op(ctx, op, f.q, f.p)) return 1;
+    hipLaunchKernelGGL(cg_dot_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, f.p->d, f.q->d, f.p->ns, N, ctx->partials, st);
+  }
+  hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ndot, sum, st);
+  if (cg_allreduce(ctx, sum)) return 1;
+  hipLaunchKernelGGL(cg_scalar_kernel<0>, dim3(1), dim3(1), 0, ctx->stream, st, sum, (double *)nullptr, 0);
+  if (fp32)
+    hipLaunchKernelGGL(cg_update_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, f.x->d32, (const v2f *)f.p->d32, f.q->d32, (const v2f *)f.r->d32,
+                       f.x->ns, N, ctx->partials, st);
+  else
+    hipLaunchKernelGGL(cg_update_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, f.x->d, (const v2d *)f.p->d, f.q->d, (const v2d *)f.r->d, f.x->ns, N,
+                       ctx->partials, st);
+  hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblk, sum, st);
+  if (cg_allreduce(ctx, sum)) return 1;
+  hipLaunchKernelGGL(cg_scalar_kernel<1>, dim3(1), dim3(1), 0, ctx->stream, st, sum, (double *)nullptr, 0);
+  if (fp32)
+    hipLaunchKernelGGL(cg_xpay_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, f.p->d32, (const v2f *)f.q->d32, f.p->ns, N, st);
+  else
+    hipLaunchKernelGGL(cg_xpay_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, f.p->d, (const v2d *)f.q->d, f.p->ns, N, st);
+  tmhip_field *t = f.q; f.q = f.r; f.r = t;   // the new residual now sits in the former q
+  return 0;
+}
+
+// inner_loop / inner_loop_high of rg_mixed_cg_her.c:74-176 (non-pipelined, Fletcher-Reeves beta): returns j, updates *rho1
+static int rg_inner_loop(tmhip_ctx *ctx, int op, bool fp32, bool fused, RgFields f, double *rho1, double delta, double eps_sq, int N,
+                         int iter_base, int max_iter, int *j_out) {
+  CgState *st = (CgState *)ctx->cg_state;
+  CgState h;
+  memset(&h, 0, sizeof(h));
+  h.normsq = *rho1; h.rhomax = *rho1; h.delta = delta; h.eps_sq = eps_sq;
+  h.inner = fp32 ? 2 : 3; h.iter_base = iter_base; h.max_total = max_iter;
+  *j_out = 0;
+  // the reference tests the loop condition before the first iteration as well (rho = rhomax => rho > delta rhomax iff delta < 1)
+  const bool enter = fp32 ? ((float)*rho1 > (float)delta * (float)*rho1) : (*rho1 > delta * *rho1);
+  if (!enter || iter_base > max_iter) return 0;
+  TMHIP_CHECK(hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+  int *flag = (int *)(ctx->result_host + 2);
+  const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
+  int done = 0, enq = 0;
+  while (!done) {
+    for (int b = 0; b < batch; b++)
+      if (rg_enqueue_iteration(ctx, op, fp32, fused, f, st, N)) return 1;
+    enq += batch;
+    TMHIP_CHECK(hipGetLastError());
+    TMHIP_CHECK(hipMemcpyAsync(flag, &st->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    done = *flag;
+    if (!done && enq > max_iter + batch) TMHIP_FAIL("rg_mixed_cg_her: inner loop did not terminate");
+  }
+  TMHIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *j_out = h.iters;
+  *rho1 = h.normsq;
+  return 0;
+}
+
+/* solver/rg_mixed_cg_her.c:180-347.  fp32 CG with true reliable updates: the inner loop runs until the iterated
+ * residual has dropped by `delta` relative to its maximum since the last update, then the solution is accumulated
+ * and the residual recomputed in fp64; when the outer-iteration estimate N_outer is nearly used up the solver
+ * falls back to fp64 inner loops.  Returns the reference's count iter_out + iter_in_sp + iter_in_dp, or -1. */
+extern "C" int tmhip_rg_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N,
+                                     int op, double delta_in, int *iters, int *iter_out_p, int *iter_sp_p, int *iter_dp_p) {
+  if (!P || !Q || P->kind != TMHIP_FIELD_EO || Q->kind != TMHIP_FIELD_EO || P->prec || Q->prec) TMHIP_FAIL("rg_mixed_cg_her needs fp64 one-parity fields");
+  if (N != ctx->Vh) TMHIP_FAIL("rg_mixed_cg_her: N must be VOLUME/2");
+  if (op != TMHIP_OP_QTM_PM && op != TMHIP_OP_QSW_PM) TMHIP_FAIL("rg_mixed_cg_her: fp32 operators exist for Qtm_pm_psi and Qsw_pm_psi only");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  if (tmhip_prepare_fp32(ctx)) return 1;
+  const bool clover = op == TMHIP_OP_QSW_PM;
+  if (clover && tmhip_prepare_clover32(ctx)) return 1;
+  if (!ctx->cg_state) TMHIP_CHECK(hipMalloc(&ctx->cg_state, sizeof(CgState)));
+  if (!ctx->sf_extra && tmhip_field_alloc(ctx, TMHIP_FIELD_EO, &ctx->sf_extra)) return 1;
+  const bool fused = !clover && ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
+  const float delta = (float)delta_in;                                /* :185 */
+  int iter_in_sp = 0, iter_in_dp = 0, iter_out = 0, high_control = 0, j;
+  double rho_dp, sourcesquarenorm, target_eps_sq;
+  float rho_sp;
+  tmhip_field *qhigh = ctx->sf[0], *rhigh = ctx->sf[1], *xhigh = ctx->sf[2], *phigh = ctx->sf_extra;   /* :211-214 */
+  tmhip_field *q = ctx->sf32[0], *p = ctx->sf32[1], *r = ctx->sf32[2], *x = ctx->sf32[3];             /* :216-219 */
+  if (tmhip_square_norm(ctx, Q, N, 1, &sourcesquarenorm)) return 1;
+  target_eps_sq = rel_prec == 1 ? eps_sq * sourcesquarenorm : eps_sq;  /* :225-232 */
+  const int N_outer = (int)ceil(log10(sourcesquarenorm * delta / target_eps_sq));   /* :236 */
+  if (tmhip_field_zero(ctx, x) || tmhip_field_zero(ctx, P)) return 1;
+  if (tmhip_assign(ctx, phigh, Q, N) || tmhip_assign(ctx, rhigh, Q, N)) return 1;
+  if (tmhip_square_norm(ctx, rhigh, N, 1, &rho_dp)) return 1;
+  if (tmhip_assign_to_32(ctx, r, rhigh, N)) return 1;
+  rho_sp = (float)rho_dp;
+  if (tmhip_assign_to_32(ctx, p, rhigh, N)) return 1;                   /* assign_32(p, r): same rounding of the same source */
+#define RG_SP_LOOP()                                                                                                   \
+  do {                                                                                                                 \
+    double rho1 = rho_sp;                                                                                              \
+    RgFields f = {x, p, q, r};                                                                                         \
+    if (rg_inner_loop(ctx, op, true, fused, f, &rho1, delta, (double)(float)target_eps_sq, N,                          \
+                      iter_out + iter_in_sp + iter_in_dp, max_iter, &j)) return 1;                                     \
+    rho_sp = (float)rho1; iter_in_sp += j;                                                                             \
+  } while (0)
+#define RG_RETURN(val)                                                                                                 \
+  do {                                                                                                                 \
+    *iters = (val);                                                                                                    \
+    if (iter_out_p) *iter_out_p = iter_out;                                                                            \
+    if (iter_sp_p) *iter_sp_p = iter_in_sp;                                                                            \
+    if (iter_dp_p) *iter_dp_p = iter_in_dp;                                                                            \
+    return 0;                                                                                                          \
+  } while (0)
+  RG_SP_LOOP();
+  for (iter_out = 1; iter_out < N_outer; ++iter_out) {
+    if (high_control == 0) {                                           /* :260-269 */
+      if (tmhip_add_from_32(ctx, P, x, N)) return 1;
+      if (tmhip_apply_op(ctx, op, qhigh, P)) return 1;
+      if (tmhip_diff(ctx, rhigh, Q, qhigh, N)) return 1;
+      if (tmhip_square_norm(ctx, rhigh, N, 1, &rho_dp)) return 1;
+    }
+    if (high_control == 1) {                                           /* :272-286 double precision fail-safe */
+      if (tmhip_assign(ctx, phigh, rhigh, N) || tmhip_field_zero(ctx, xhigh)) return 1;
+      RgFields f = {xhigh, phigh, qhigh, rhigh};
+      if (rg_inner_loop(ctx, op, false, false, f, &rho_dp, delta, target_eps_sq, N, iter_out + iter_in_sp + iter_in_dp, max_iter, &j)) return 1;
+      iter_in_dp += j;
+      rho_sp = (float)rho_dp;
+      if (tmhip_assign_add_mul_r(ctx, P, xhigh, 1.0, N)) return 1;     /* add(P, P, xhigh) */
+      if (tmhip_apply_op(ctx, op, qhigh, P)) return 1;
+      if (tmhip_diff(ctx, rhigh, Q, qhigh, N)) return 1;
+      if (tmhip_square_norm(ctx, rhigh, N, 1, &rho_dp)) return 1;
+    }
+    const int total = iter_in_sp + iter_in_dp + iter_out;
+    if (rho_dp <= target_eps_sq || total >= max_iter) RG_RETURN(total >= max_iter ? -1 : total);   /* :294-307 */
+    if (iter_out >= N_outer - 2) {                                     /* :310-313 */
+      high_control = 1;
+      continue;
+    }
+    if (tmhip_assign_to_32(ctx, r, rhigh, N) || tmhip_assign_to_32(ctx, p, rhigh, N)) return 1;   /* :315-318 */
+    rho_sp = (float)rho_dp;
+    if (tmhip_field_zero(ctx, x)) return 1;
+    RG_SP_LOOP();
+  }
+  RG_RETURN(-1);                                                       /* :326-330 convergence failure */
+#undef RG_SP_LOOP
+#undef RG_RETURN
 }

@@ -178,6 +178,7 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   for (int i = 0; i < 3; i++) { tmhip_field_free(ctx, ctx->scratch[i]); tmhip_field_free(ctx, ctx->sf[i]); }
+  tmhip_field_free(ctx, ctx->sf_extra);
   for (int i = 0; i < 2; i++) tmhip_field_free(ctx, ctx->scratch32[i]);
   for (int i = 0; i < 4; i++) tmhip_field_free(ctx, ctx->sf32[i]);
   if (ctx->gauge32) (void)hipFree(ctx->gauge32);
@@ -412,6 +413,48 @@ int tmhip_Qtm_pm_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
          tm_sub_H_eo_gamma5(ctx, ctx->scratch[0], k, ctx->scratch[1], TMHIP_OE, -1.) ||
          tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], ctx->scratch[0], TMHIP_EO, +1.) ||
          tm_sub_H_eo_gamma5(ctx, l, ctx->scratch[0], ctx->scratch[1], TMHIP_OE, +1.);
+}
+/* The "symmetric" e/o preconditioning family (tm_operators.c:186-192,223-229,259-265,296-302):
+ *   X_sym = k - (1 +- i mu g5)^-1 H_oe (1 +- i mu g5)^-1 H_eo k.
+ * Both inverse twists ride in the stencil epilogues (EPI_TM_TIMES); the subtraction is one streaming pass.
+ * Used by the non-hermitian solvers of invert_eo.c:177-280 (bicgstab, gmres, gcr, cgs ...). */
+static int sym_core(tmhip_ctx *ctx, tmhip_field *k, double sign) {
+  return tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, sign) ||
+         tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[0], ctx->scratch[1], TMHIP_OE, sign);
+}
+/* tm_operators.c:186-192 */
+int tmhip_Qtm_plus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  return sym_core(ctx, k, +1.) || tmhip_mul_one_sub_mul_gamma5(ctx, l, k, ctx->scratch[0]);
+}
+/* tm_operators.c:223-229 */
+int tmhip_Qtm_minus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  return sym_core(ctx, k, -1.) || tmhip_mul_one_sub_mul_gamma5(ctx, l, k, ctx->scratch[0]);
+}
+/* tm_operators.c:259-265 */
+int tmhip_Mtm_plus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  return sym_core(ctx, k, +1.) || tmhip_diff(ctx, l, k, ctx->scratch[0], ctx->Vh);
+}
+/* tm_operators.c:296-302 */
+int tmhip_Mtm_minus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  return sym_core(ctx, k, -1.) || tmhip_diff(ctx, l, k, ctx->scratch[0], ctx->Vh);
+}
+/* tm_operators.c:312-322 : (Mtm_plus_sym)^dagger = 1 - g5 H_oe A_-^-1 H_eo A_-^-1 g5 ; l is used as work space first,
+ * exactly like the reference, so l must not alias k. */
+int tmhip_Mtm_plus_sym_dagg_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (need_eo(l, "Mtm_plus_sym_dagg_psi") || need_eo(k, "Mtm_plus_sym_dagg_psi")) return 1;
+  if (l == k || l->d == k->d) TMHIP_FAIL("Mtm_plus_sym_dagg_psi: l must not alias k");
+  return tmhip_gamma5(ctx, l, k, ctx->Vh) || tmhip_mul_one_pm_imu_inv(ctx, l, -1., ctx->Vh) ||
+         tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], l, TMHIP_EO, -1.) ||
+         tmhip_hopping_matrix(ctx, TMHIP_OE, ctx->scratch[0], ctx->scratch[1]) ||
+         tmhip_gamma5(ctx, ctx->scratch[1], ctx->scratch[0], ctx->Vh) || tmhip_diff(ctx, l, k, ctx->scratch[1], ctx->Vh);
+}
+/* tm_operators.c:347-364.  The reference body overwrites its Q_- result: the second pair of stencils writes
+ * l and DUM_MATRIX+1 only, then l is rebuilt from k and DUM_MATRIX, so what it returns is
+ *   l = g5 ( k - A_+^-1 A_-^-1 H_oe A_-^-1 H_eo k ).
+ * A drop-in has to return the same field, so that is what is computed here (2 stencils instead of 4). */
+int tmhip_Qtm_pm_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  return sym_core(ctx, k, -1.) || tmhip_mul_one_pm_imu_inv(ctx, ctx->scratch[0], +1., ctx->Vh) ||
+         tmhip_mul_one_sub_mul_gamma5(ctx, l, k, ctx->scratch[0]);
 }
 /* tm_operators.c:117-128 :  X_new = (1 + i mu g5) X - H Y */
 int tmhip_M_full(tmhip_ctx *ctx, tmhip_field *En, tmhip_field *On, tmhip_field *E, tmhip_field *O) {

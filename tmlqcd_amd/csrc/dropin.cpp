@@ -6,6 +6,7 @@
 #include "../../include/tmlqcd_dropin.h"
 #include "../../include/tmlqcd_hip.h"
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -246,6 +247,15 @@ EO_OP(Qtm_minus_psi, tmhip_Qtm_minus_psi)      /* tm_operators.c:216-221 */
 EO_OP(Mtm_plus_psi, tmhip_Mtm_plus_psi)        /* tm_operators.c:245-250 */
 EO_OP(Mtm_minus_psi, tmhip_Mtm_minus_psi)      /* tm_operators.c:289-294 */
 EO_OP(Qtm_pm_psi, tmhip_Qtm_pm_psi)            /* tm_operators.c:338-345 */
+EO_OP(Qtm_plus_sym_psi, tmhip_Qtm_plus_sym_psi)            /* tm_operators.c:186-192 */
+EO_OP(Qtm_minus_sym_psi, tmhip_Qtm_minus_sym_psi)          /* tm_operators.c:223-229 */
+EO_OP(Mtm_plus_sym_psi, tmhip_Mtm_plus_sym_psi)            /* tm_operators.c:259-265 */
+EO_OP(Mtm_minus_sym_psi, tmhip_Mtm_minus_sym_psi)          /* tm_operators.c:296-302 */
+EO_OP(Mtm_plus_sym_dagg_psi, tmhip_Mtm_plus_sym_dagg_psi)  /* tm_operators.c:312-322 */
+EO_OP(Qtm_pm_sym_psi, tmhip_Qtm_pm_sym_psi)                /* tm_operators.c:347-364 */
+void Qtm_plus_sym_psi_nocom(spinor *const l, spinor *const k) { Qtm_plus_sym_psi(l, k); }   /* :194-200 */
+void Mtm_plus_sym_psi_nocom(spinor *const l, spinor *const k) { Mtm_plus_sym_psi(l, k); }   /* :267-273 */
+void Mtm_minus_sym_psi_nocom(spinor *const l, spinor *const k) { Mtm_minus_sym_psi(l, k); } /* :304-310 */
 /* The _nocom variants differ from the above only by skipping the halo exchange
  * (tm_operators.c:179-184,252-257,369-379); on one GPU they are the same function. */
 void Qtm_plus_psi_nocom(spinor *const l, spinor *const k) { Qtm_plus_psi(l, k); }
@@ -375,6 +385,13 @@ void mul_one_pm_imu_sub_mul_gamma5(spinor *const l, spinor *const k, spinor *con
   tmhip_ctx *c = refresh(false);
   tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fj = in(c, j, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
   CK(tmhip_mul_one_pm_imu_sub_mul_gamma5(c, fl, fk, fj, _sign));
+  done(c, l);
+}
+/* tm_operators.c:781-810 (external linkage in the reference although no header declares it) */
+void mul_one_sub_mul_gamma5(spinor *const l, spinor *const k, spinor *const j) {
+  tmhip_ctx *c = refresh(false);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_EO), *fj = in(c, j, TMHIP_FIELD_EO), *fl = out(c, l, TMHIP_FIELD_EO);
+  CK(tmhip_mul_one_sub_mul_gamma5(c, fl, fk, fj));
   done(c, l);
 }
 /* tm_operators.c:723-775: l = (1 + i mu g5) k with an explicit mu */
@@ -581,7 +598,9 @@ int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, 
 }
 
 /* solver/mixed_cg_her.c:65-202 with f = Qtm_pm_psi: fp32 inner CG + fp64 defect correction, all in HBM */
-int mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params_opaque, const int max_iter, double eps_sq,
+static_assert(sizeof(tmlqcd_solver_params) == 144 && offsetof(tmlqcd_solver_params, mcg_delta) == 52,
+              "solver_params_t layout (solver/solver_params.h:46-109)");
+int mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params, const int max_iter, double eps_sq,
                  const int rel_prec, const int N, matrix_mult f, matrix_mult32) {
   if ((f != &Qtm_pm_psi && f != &Qsw_pm_psi) || N != VOLUME / 2) die("mixed_cg_her: only f = Qtm_pm_psi / Qsw_pm_psi on VOLUME/2 sites runs on the device");
   const int op = f == &Qsw_pm_psi ? TMHIP_OP_QSW_PM : TMHIP_OP_QTM_PM;
@@ -591,6 +610,22 @@ int mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params_opaque, 
   tmhip_field *fq = in(c, Q, TMHIP_FIELD_EO), *fp = out(c, P, TMHIP_FIELD_EO);
   int iters = -1, outer = 0;
   CK(tmhip_mixed_cg_her(c, fp, fq, max_iter, eps_sq, rel_prec, N, op, innereps, max_inner, &iters, &outer));
+  Mirror &m = g_reg[P];
+  m.dev_valid = true; m.host_valid = false;
+  download(c, P, m);
+  if (g_mode == TMLQCD_HIP_COHERENT) m.dev_valid = false;
+  return iters;
+}
+
+/* solver/rg_mixed_cg_her.c:180-347 with (f, f32) = (Qtm_pm_psi, Qtm_pm_psi_32) or (Qsw_pm_psi, Qsw_pm_psi_32) */
+int rg_mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params solver_params, const int max_iter,
+                    const double eps_sq, const int rel_prec, const int N, matrix_mult f, matrix_mult32) {
+  if ((f != &Qtm_pm_psi && f != &Qsw_pm_psi) || N != VOLUME / 2) die("rg_mixed_cg_her: only f = Qtm_pm_psi / Qsw_pm_psi on VOLUME/2 sites runs on the device");
+  const int op = f == &Qsw_pm_psi ? TMHIP_OP_QSW_PM : TMHIP_OP_QTM_PM;
+  tmhip_ctx *c = op == TMHIP_OP_QSW_PM ? refresh_clover() : refresh(true);
+  tmhip_field *fq = in(c, Q, TMHIP_FIELD_EO), *fp = out(c, P, TMHIP_FIELD_EO);
+  int iters = -1;
+  CK(tmhip_rg_mixed_cg_her(c, fp, fq, max_iter, eps_sq, rel_prec, N, op, solver_params.mcg_delta, &iters, nullptr, nullptr, nullptr));
   Mirror &m = g_reg[P];
   m.dev_valid = true; m.host_valid = false;
   download(c, P, m);

@@ -249,6 +249,10 @@ int tmhip_mul_one_pm_imu_sub_mul_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_fi
   const double sign = _sign < 0. ? -1. : 1.;
   return launch_diag(ctx, l, k, j, 1., sign * ctx->mu, 1, 1, ctx->Vh);
 }
+/* tm_operators.c:781-810 : l = g5 (k - j) */
+int tmhip_mul_one_sub_mul_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, tmhip_field *j) {
+  return launch_diag(ctx, l, k, j, 1., 0., 1, 1, ctx->Vh);
+}
 /* gamma.c:77-98 */
 int tmhip_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int N) {
   return launch_diag(ctx, l, k, nullptr, 1., 0., 0, 1, N);

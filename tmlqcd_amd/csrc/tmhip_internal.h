@@ -80,7 +80,7 @@ struct tmhip_ctx {
   // private scratch = DUM_MATRIX..DUM_MATRIX+2 of tm_operators.c:173-176
   tmhip_field *scratch[3];
   // solver work fields
-  tmhip_field *sf[3];
+  tmhip_field *sf[3]; tmhip_field *sf_extra;   // sf_extra: 4th fp64 field of rg_mixed_cg_her (allocated on first use)
   // fp32 twins for the mixed-precision CG (allocated on first use): scratch32 = g_spinor_field32[0..1]
   // (tm_operators_32.c Qtm_pm_psi_32), sf32 = solver_field32[0..3] (mixed_cg_her.c:72-102)
   tmhip_field *scratch32[2]; tmhip_field *sf32[4];

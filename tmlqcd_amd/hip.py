@@ -66,6 +66,10 @@ def load_library():
         "tmhip_Qtm_plus_psi": [vp, vp, vp], "tmhip_Qtm_minus_psi": [vp, vp, vp],
         "tmhip_Mtm_plus_psi": [vp, vp, vp], "tmhip_Mtm_minus_psi": [vp, vp, vp],
         "tmhip_Qtm_pm_psi": [vp, vp, vp],
+        "tmhip_Qtm_plus_sym_psi": [vp, vp, vp], "tmhip_Qtm_minus_sym_psi": [vp, vp, vp],
+        "tmhip_Mtm_plus_sym_psi": [vp, vp, vp], "tmhip_Mtm_minus_sym_psi": [vp, vp, vp],
+        "tmhip_Mtm_plus_sym_dagg_psi": [vp, vp, vp], "tmhip_Qtm_pm_sym_psi": [vp, vp, vp],
+        "tmhip_mul_one_sub_mul_gamma5": [vp, vp, vp, vp],
         "tmhip_M_full": [vp, vp, vp, vp, vp],
         "tmhip_square_norm": [vp, vp, i, i, pd],
         "tmhip_scalar_prod_r": [vp, vp, vp, i, i, pd],
@@ -96,6 +100,7 @@ def load_library():
         "tmhip_assign_add_mul_r_32": [vp, vp, vp, C.c_float, i],
         "tmhip_assign_mul_add_r_32": [vp, vp, C.c_float, vp, i],
         "tmhip_mixed_cg_her": [vp, vp, vp, i, d, i, i, i, d, i, C.POINTER(i), C.POINTER(i)],
+        "tmhip_rg_mixed_cg_her": [vp, vp, vp, i, d, i, i, i, d, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)],
         "tmhip_comm_get_unique_id": [C.c_char_p],
         "tmhip_comm_init": [vp, C.c_char_p],
         "tmhip_comm_set_loopback": [vp, i],
@@ -308,6 +313,14 @@ class Lattice:
                                         max_inner_it, C.byref(it), C.byref(outer)), "mixed_cg_her")
         return it.value, outer.value
 
+    def rg_mixed_cg_her(self, P, Q, max_iter, eps_sq, rel_prec, N, delta=5.0e-5, op="Qtm_pm_psi"):
+        """solver/rg_mixed_cg_her.c:180 (reliable updates, fp64 fail-safe); delta = solver_params.mcg_delta.
+        Returns (iterations as the reference counts them, (iter_out, iter_in_sp, iter_in_dp))."""
+        it, a, b, c = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _ck(self.lib.tmhip_rg_mixed_cg_her(self.h, P.h, Q.h, max_iter, eps_sq, rel_prec, N, OPS[op], delta, C.byref(it),
+                                           C.byref(a), C.byref(b), C.byref(c)), "rg_mixed_cg_her")
+        return it.value, (a.value, b.value, c.value)
+
     # --- stencil ----------------------------------------------------------
     def Hopping_Matrix(self, ieo, l, k):
         _ck(self.lib.tmhip_hopping_matrix(self.h, ieo, l.h, k.h), "Hopping_Matrix")
@@ -342,6 +355,9 @@ class Lattice:
 
     def mul_one_pm_imu_sub_mul_gamma5(self, l, k, j, sign):
         _ck(self.lib.tmhip_mul_one_pm_imu_sub_mul_gamma5(self.h, l.h, k.h, j.h, sign), "mul_one_pm_imu_sub_mul_gamma5")
+
+    def mul_one_sub_mul_gamma5(self, l, k, j):
+        _ck(self.lib.tmhip_mul_one_sub_mul_gamma5(self.h, l.h, k.h, j.h), "mul_one_sub_mul_gamma5")
 
     def gamma5(self, l, k, N):
         _ck(self.lib.tmhip_gamma5(self.h, l.h, k.h, N), "gamma5")
