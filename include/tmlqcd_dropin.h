@@ -139,6 +139,12 @@ int rg_mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params solve
 
 /* ---- residency control (additions; not in the reference) ------------------- */
 enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1 };
+/* Device versions of sw_term(g_gauge_field, kappa, c_sw) / sw_invert(ieo, mu) (operator/clover_term.c:88,
+ * operator/clover_invert.c:170).  They carry their own names because the reference keeps other, unrelated functions in
+ * the same objects (six_det, sw_invert_nd, sw_trace ...), so those objects stay on the link line; replace the two calls
+ * in operator.c:329-330,364 / the clover monomials to use them.  The host's sw / sw_inv arrays receive copies. */
+void tmlqcd_hip_sw_term(const double kappa, const double c_sw);
+void tmlqcd_hip_sw_invert(const int ieo, const double mu);
 void tmlqcd_hip_set_residency(int mode);
 void tmlqcd_hip_sync_to_host(spinor *field);       /* download the device mirror of `field` if it is newer */
 void tmlqcd_hip_sync_all_to_host(void);

@@ -138,6 +138,13 @@ int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, d
  * (operator/clover_term.c:88), `sw_inv` = su3 sw_inv[VOLUME][4][2] from sw_invert(EE, mu)
  * (operator/clover_invert.c:170; +mu set in [0,V/2), -mu set in [V/2,V)).  Call again whenever they change. */
 int tmhip_set_clover(tmhip_ctx *ctx, const void *sw, const void *sw_inv);
+/* ... or computed on the device: sw_term(gf, kappa, c_sw) (operator/clover_term.c:88) from the host gauge field handed
+ * over exactly as for tmhip_set_gauge, then sw_invert(ieo, mu) (operator/clover_invert.c:170; the operators below expect
+ * ieo = 0 = EE as operator.c:364 uses it).  tmhip_get_clover copies the blocks back in the reference's host layouts
+ * (either pointer may be NULL) for host code that still wants them (sw_trace, sw_deriv ...). */
+int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_field, double kappa, double c_sw);
+int tmhip_sw_invert(tmhip_ctx *ctx, int ieo, double mu);
+int tmhip_get_clover(tmhip_ctx *ctx, void *sw, void *sw_inv);
 int tmhip_clover_inv(tmhip_ctx *ctx, tmhip_field *l, int tau3sign, double mu);                                   /* clovertm_operators.c:287 */
 int tmhip_clover_gamma5(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, tmhip_field *j, double mu);     /* :448 */
 int tmhip_clover(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, tmhip_field *j, double mu);            /* :535 */

@@ -49,6 +49,9 @@ def _lib():
             getattr(lib, "tmo_" + n).argtypes = [vp, vp, vp]
         lib.tmo_M_full.argtypes = [vp] * 5
         lib.tmo_set_clover.argtypes = [vp, vp, vp]
+        lib.tmo_sw_term.argtypes = [vp, vp, d, d]
+        lib.tmo_sw_invert.argtypes = [vp, vp, vp, i, d]
+        lib.tmo_sw_invert.restype = i
         lib.tmo_clover_inv.argtypes = [vp, vp, i, d]
         lib.tmo_clover_gamma5.argtypes = [vp, i, vp, vp, vp, d]
         lib.tmo_clover.argtypes = [vp, i, vp, vp, vp, d]
@@ -143,6 +146,19 @@ class Oracle:
         self._sw = np.ascontiguousarray(sw, dtype=np.float64)
         self._sw_inv = np.ascontiguousarray(sw_inv, dtype=np.float64)
         self.lib.tmo_set_clover(self.h, _p(self._sw), _p(self._sw_inv))
+
+    def sw_term(self, kappa, c_sw):
+        """operator/clover_term.c:88 on the current gauge field -> sw [V][3][2][3][3][2]."""
+        sw = np.zeros((self.V, 3, 2, 3, 3, 2))
+        self.lib.tmo_sw_term(self.h, _p(sw), kappa, c_sw)
+        return sw
+
+    def sw_invert(self, sw, ieo, mu):
+        """operator/clover_invert.c:170 -> (sw_inv [V][4][2][3][3][2], number of near-singular pivots)."""
+        swi = np.zeros((self.V, 4, 2, 3, 3, 2))
+        sw = np.ascontiguousarray(sw, dtype=np.float64)
+        fails = self.lib.tmo_sw_invert(self.h, _p(swi), _p(sw), ieo, mu)
+        return swi, fails
 
     def clover_inv(self, l, tau3sign, mu):
         self.lib.tmo_clover_inv(self.h, _p(l), tau3sign, mu)

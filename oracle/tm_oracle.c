@@ -640,6 +640,163 @@ void tmo_Msw_plus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
   tmo_clover(lat, OE, l, k, lat->scratch[0], +lat->mu);
 }
 
+/* ---------------------------------------------------------------- clover term and its inverse (host-side inputs in
+ * the reference: operator/clover_term.c:88-200, operator/clover_invert.c:88-257).  3x3 blocks are handled as
+ * m[row][col] views of tmo_su3 (su3.h:40-43 is row-major c00..c22).  */
+typedef double _Complex c33[3][3];
+#define M33(u) (*(c33 *)(u))
+/* u (+)= op(v) op(w), op = identity or dagger; sums run left to right like su3.h:583-640 */
+static inline void m33_mul(tmo_su3 *u, const tmo_su3 *v, int vdag, const tmo_su3 *w, int wdag, int acc) {
+  tmo_su3 r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double _Complex a0 = vdag ? conj(M33(v)[0][i]) : M33(v)[i][0], a1 = vdag ? conj(M33(v)[1][i]) : M33(v)[i][1],
+                      a2 = vdag ? conj(M33(v)[2][i]) : M33(v)[i][2];
+      double _Complex b0 = wdag ? conj(M33(w)[j][0]) : M33(w)[0][j], b1 = wdag ? conj(M33(w)[j][1]) : M33(w)[1][j],
+                      b2 = wdag ? conj(M33(w)[j][2]) : M33(w)[2][j];
+      M33(&r)[i][j] = a0 * b0 + a1 * b1 + a2 * b2;
+    }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      if (acc) M33(u)[i][j] += M33(&r)[i][j]; else M33(u)[i][j] = M33(&r)[i][j];
+}
+static inline const tmo_su3 *glink(const tmo_lattice *lat, int ix, int mu) { return lat->gauge + (size_t)4 * ix + mu; }
+
+/* operator/clover_term.c:88-200.  sw is [V][3][2] (clover_term.c:60-87). */
+void tmo_sw_term(tmo_lattice *lat, tmo_su3 *sw, double kappa, double c_sw) {
+  const double ka_csw_8 = kappa * c_sw / 8.;
+  const int *iup = lat->iup, *idn = lat->idn;
+#pragma omp parallel for
+  for (int x = 0; x < lat->V; x++) {
+    tmo_su3 fkl[4][4], v1, v2, plaq, electric[4], magnetic[4];
+    for (int k = 0; k < 4; k++)
+      for (int l = k + 1; l < 4; l++) {
+        const int xpk = iup[4 * x + k], xpl = iup[4 * x + l], xmk = idn[4 * x + k], xml = idn[4 * x + l];
+        const int xpkml = idn[4 * xpk + l], xplmk = idn[4 * xpl + k], xmkml = idn[4 * xml + k];
+        /* four leaves of the clover in the (k,l) plane, clover_term.c:120-151 */
+        m33_mul(&v1, glink(lat, x, k), 0, glink(lat, xpk, l), 0, 0);
+        m33_mul(&v2, glink(lat, x, l), 0, glink(lat, xpl, k), 0, 0);
+        m33_mul(&plaq, &v1, 0, &v2, 1, 0);
+        m33_mul(&v1, glink(lat, x, l), 0, glink(lat, xplmk, k), 1, 0);
+        m33_mul(&v2, glink(lat, xmk, l), 1, glink(lat, xmk, k), 0, 0);
+        m33_mul(&plaq, &v1, 0, &v2, 0, 1);
+        m33_mul(&v1, glink(lat, xmkml, l), 0, glink(lat, xmk, k), 0, 0);
+        m33_mul(&v2, glink(lat, xmkml, k), 0, glink(lat, xml, l), 0, 0);
+        m33_mul(&plaq, &v1, 1, &v2, 0, 1);
+        m33_mul(&v1, glink(lat, xml, l), 1, glink(lat, xml, k), 0, 0);
+        m33_mul(&v2, glink(lat, xpkml, l), 0, glink(lat, x, k), 1, 0);
+        m33_mul(&plaq, &v1, 0, &v2, 0, 1);
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) M33(&fkl[k][l])[i][j] = M33(&plaq)[i][j] - conj(M33(&plaq)[j][i]);   /* :152-153 */
+      }
+    for (int k = 1; k < 4; k++) electric[k] = fkl[0][k];
+    magnetic[1] = fkl[2][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M33(&magnetic[2])[i][j] = -M33(&fkl[1][3])[i][j];
+    magnetic[3] = fkl[1][2];
+    tmo_su3 *o = sw + (size_t)6 * x;    /* o[2*a+b] = sw[x][a][b] */
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        const double one = i == j ? 1. : 0.;
+        const double _Complex e1 = M33(&electric[1])[i][j], e2 = M33(&electric[2])[i][j], e3 = M33(&electric[3])[i][j];
+        const double _Complex m1 = M33(&magnetic[1])[i][j], m2 = M33(&magnetic[2])[i][j], m3 = M33(&magnetic[3])[i][j];
+        double _Complex t;
+        /* upper left 6x6, clover_term.c:174-183 */
+        t = I * (e3 - m3);                     M33(&o[0])[i][j] = one; M33(&o[0])[i][j] += ka_csw_8 * t;
+        t = I * (e1 - m1); t += (e2 - m2);     M33(&o[2])[i][j] = ka_csw_8 * t;
+        t = I * (m3 - e3);                     M33(&o[4])[i][j] = one; M33(&o[4])[i][j] += ka_csw_8 * t;
+        /* lower right 6x6, clover_term.c:187-196 */
+        t = I * (e3 + m3);                     M33(&o[1])[i][j] = one; M33(&o[1])[i][j] += (-ka_csw_8) * t;
+        t = I * (e1 + m1); t += (e2 + m2);     M33(&o[3])[i][j] = (-ka_csw_8) * t;
+        t = I * (m3 + e3);                     M33(&o[5])[i][j] = one; M33(&o[5])[i][j] += ka_csw_8 * t;
+      }
+  }
+}
+
+/* operator/clover_invert.c:88-160: in-place inverse of a 6x6 complex matrix by Householder triangularisation
+ * (no pivoting), back-substitution of the triangle, and the reflections applied from the right in reverse. */
+static int tmo_six_invert(double _Complex a[6][6]) {
+  const double tiny = 1.0e-20;            /* tiny_t, operator/clover_leaf.c */
+  double _Complex d[6], u[6], sigma, z;
+  double p[6], s, q;
+  int fail = 0;
+  for (int k = 0; k < 5; k++) {
+    s = 0.0;
+    for (int j = k + 1; j < 6; j++) s += conj(a[j][k]) * a[j][k];
+    s = sqrt(1. + s / (conj(a[k][k]) * a[k][k]));
+    sigma = s * a[k][k];
+    a[k][k] += sigma;
+    p[k] = conj(sigma) * a[k][k];
+    q = conj(sigma) * sigma;
+    if (q < tiny) fail++;
+    d[k] = -conj(sigma) / q;
+    for (int j = k + 1; j < 6; j++) {
+      z = 0.0;
+      for (int i = k; i < 6; i++) z += conj(a[i][k]) * a[i][j];
+      z /= p[k];
+      for (int i = k; i < 6; i++) a[i][j] -= z * a[i][k];
+    }
+  }
+  sigma = a[5][5];
+  q = conj(sigma) * sigma;
+  if (q < tiny) fail++;
+  d[5] = conj(sigma) / q;
+  for (int k = 5; k >= 0; k--)
+    for (int i = k - 1; i >= 0; i--) {
+      z = 0.0;
+      for (int j = i + 1; j < k; j++) z += a[i][j] * a[j][k];
+      z += a[i][k] * d[k];
+      a[i][k] = -z * d[i];
+    }
+  a[5][5] = d[5];
+  for (int k = 4; k >= 0; k--) {
+    for (int j = k; j < 6; j++) u[j] = a[j][k];
+    a[k][k] = d[k];
+    for (int j = k + 1; j < 6; j++) a[j][k] = 0.0;
+    for (int i = 0; i < 6; i++) {
+      z = 0.0;
+      for (int j = k; j < 6; j++) z += a[i][j] * u[j];
+      z /= p[k];
+      for (int j = k; j < 6; j++) a[i][j] -= conj(u[j]) * z;
+    }
+  }
+  return fail;
+}
+
+/* operator/clover_invert.c:170-257: sw_inv[icy] (+mu) and sw_inv[icy + V/2] (-mu, only when mu != 0) for the sites
+ * of parity ieo; sw_inv is [V][4][2] with blocks 0: upper-left, 1: upper-right, 2: lower-right, 3: lower-left. */
+int tmo_sw_invert(tmo_lattice *lat, tmo_su3 *sw_inv, const tmo_su3 *sw, int ieo, double mu) {
+  const int Vh = lat->V / 2, ioff = ieo == 0 ? 0 : (lat->V + lat->RAND) / 2;
+  int fails = 0;
+#pragma omp parallel for reduction(+ : fails)
+  for (int icy = 0; icy < Vh; icy++) {
+    const int x = lat->eo2lexic[icy + ioff];
+    const tmo_su3 *w = sw + (size_t)6 * x;
+    for (int set = 0; set < (fabs(mu) > 0. ? 2 : 1); set++)
+      for (int b = 0; b < 2; b++) {
+        double _Complex a[6][6];
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) {
+            a[i][j] = M33(&w[0 + b])[i][j];
+            a[i][j + 3] = M33(&w[2 + b])[i][j];
+            a[i + 3][j] = conj(M33(&w[2 + b])[j][i]);
+            a[i + 3][j + 3] = M33(&w[4 + b])[i][j];
+          }
+        const double m = (set == 0 ? 1. : -1.) * (b == 0 ? mu : -mu);
+        for (int i = 0; i < 6; i++) a[i][i] += I * m;
+        fails += tmo_six_invert(a);
+        tmo_su3 *o = sw_inv + (size_t)8 * (icy + set * Vh);   /* o[2*a+b] = sw_inv[.][a][b] */
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) {
+            M33(&o[0 + b])[i][j] = a[i][j];
+            M33(&o[2 + b])[i][j] = a[i][j + 3];
+            M33(&o[4 + b])[i][j] = a[i + 3][j + 3];
+            M33(&o[6 + b])[i][j] = a[i + 3][j];
+          }
+      }
+  }
+  return fails;
+}
+
 /* ---------------------------------------------------------------- linalg */
 /* Per-thread Kahan partials summed in thread order, as the reference does with
    g_omp_acc_re (linalg/square_norm.c:299-304). */

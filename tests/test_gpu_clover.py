@@ -116,3 +116,90 @@ def test_clover_cg_and_mixed_cg(setup8):
     assert rel_err(dp.download(), P[:N]) < 1e-8
     for f in (dq, dp, d32, l32):
         f.free()
+
+
+# ------------------------------------------------------------------ sw_term / sw_invert computed on the device
+def test_device_sw_term_and_sw_invert_against_reference_fixture():
+    """operator/clover_term.c:88 + operator/clover_invert.c:170 on the GPU from the gauge field of the 4^4 fixture ==
+    the arrays the reference's own sw_term / sw_invert(EE, mu) produced (oracle/make_golden.py clover)."""
+    from tmlqcd_amd import Lattice
+    f = np.load(os.path.join(GOLD, "ref_fields_4x4.npz"))
+    c = np.load(os.path.join(GOLD, "ref_clover_fields_4x4.npz"))
+    s = json.load(open(os.path.join(GOLD, "ref_clover_scalars_4x4.json")))
+    lat = Lattice(4, 4, 4, 4, kappa=s["kappa"], mu=s["mu"])
+    gauge = np.ascontiguousarray(f["gauge"])
+    lat.set_gauge(gauge)
+    lat.sw_term(gauge, s["kappa"], s["c_sw"])
+    lat.sw_invert(0, s["mu"])
+    sw, swi = lat.get_clover()
+    assert rel_err(sw, c["sw"]) < TOL and rel_err(swi, c["sw_inv"]) < TOL
+    # and the operator built on the device-computed blocks reproduces the reference's Qsw_pm_psi
+    dk, dl = lat.field(np.ascontiguousarray(f["in"])), lat.field()
+    lat.op("Qsw_pm_psi", dl, dk)
+    assert rel_err(dl.download(), c["Qsw_pm_psi"]) < TOL
+    lat.close()
+
+
+@pytest.mark.parametrize("dims,mu", [((8, 6, 4, 12), 0.02), ((4, 4, 6, 2), 0.0), ((2, 2, 2, 2), 0.3)])
+def test_device_sw_term_and_sw_invert_against_oracle(dims, mu):
+    """Ragged extents (incl. the 2-site wrap where +mu and -mu neighbours coincide) and mu = 0, where only the first
+    half of sw_inv is produced (clover_invert.c:225)."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T, LX, LY, LZ = dims
+    kappa, c_sw = 0.137, 1.57
+    orc = Oracle(T, LX, LY, LZ, kappa=kappa, mu=mu, threads=8)
+    lat = Lattice(T, LX, LY, LZ, kappa=kappa, mu=mu)
+    g = random_gauge(81, orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    sw_ref = orc.sw_term(kappa, c_sw)
+    swi_ref, fails = orc.sw_invert(sw_ref, 0, mu)
+    assert fails == 0
+    lat.sw_term(g, kappa, c_sw)
+    for ieo in (1, 0):                       # the odd-site inverse is legal too; leave the even one in place
+        lat.sw_invert(ieo, mu)
+        sw, swi = lat.get_clover()
+        ref_i, _ = orc.sw_invert(sw_ref, ieo, mu)
+        n = orc.V if mu != 0.0 else orc.V // 2
+        assert rel_err(sw, sw_ref) < TOL
+        assert rel_err(swi[:n], ref_i[:n]) < TOL
+        if mu == 0.0:
+            assert not swi[n:].any()         # untouched, like the reference's second half
+    orc.set_clover(sw_ref, swi_ref)
+    k = random_spinor(82, orc.Vh)
+    ref = orc.new_field(); orc.op("Qsw_pm_psi", ref, k.copy())
+    dk, dl = lat.field(k), lat.field()
+    lat.op("Qsw_pm_psi", dl, dk)
+    assert rel_err(dl.download(), ref[:orc.Vh]) < TOL
+    lat.close()
+
+
+def test_device_sw_term_on_t_split_ranks():
+    """Two T-slabs (nproc_t = 2) compute their clover blocks from their own gauge field + halo slabs and reproduce the
+    slices of the unsplit lattice; set_clover accepts per-rank host arrays as well."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T, L, world = 2, 4, 2
+    Tg = T * world
+    kappa, mu, c_sw = 0.13, 0.05, 1.3
+    g = Oracle(Tg, L, L, L, kappa=kappa, mu=mu, threads=4)
+    g.set_gauge(syn.gauge_field(5, Tg, L, L, L))
+    sw_ref = g.sw_term(kappa, c_sw)
+    swi_ref, _ = g.sw_invert(sw_ref, 0, mu)
+    Vg = g.V
+    for r in range(world):
+        lat = Lattice(T, L, L, L, kappa=kappa, mu=mu, nproc_t=world, proc_t=r)
+        gr = syn.gauge_field(5, T, L, L, L, world, r)
+        lat.set_gauge(gr)
+        lat.sw_term(gr, kappa, c_sw)
+        lat.sw_invert(0, mu)
+        sw, swi = lat.get_clover()
+        V, Vh = lat.V, lat.Vh
+        assert rel_err(sw, sw_ref[r * V:(r + 1) * V]) < TOL
+        assert rel_err(swi[:Vh], swi_ref[r * Vh:(r + 1) * Vh]) < TOL
+        assert rel_err(swi[Vh:], swi_ref[Vg // 2 + r * Vh:Vg // 2 + (r + 1) * Vh]) < TOL
+        lat.set_clover(np.ascontiguousarray(sw_ref[r * V:(r + 1) * V]), np.ascontiguousarray(swi))   # upload path on a split rank
+        sw2, swi2 = lat.get_clover()
+        assert np.array_equal(sw2, sw_ref[r * V:(r + 1) * V]) and np.array_equal(swi2, swi)
+        lat.close()

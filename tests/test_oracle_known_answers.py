@@ -181,6 +181,11 @@ def test_golden_4x4_clover(gold4):
         M = np.block([[A, B], [B.conj().T, Cc]]) + 1j * sgn * mu * np.eye(6)
         Minv = np.block([[swi[5, 0, chi], swi[5, 1, chi]], [swi[5, 3, chi], swi[5, 2, chi]]])
         assert np.abs(M @ Minv - np.eye(6)).max() < 1e-13
+    # the oracle's own sw_term / sw_invert reproduce both arrays from the fixture's gauge field, bit for bit
+    sw_o = o.sw_term(cs["kappa"], cs["c_sw"])
+    assert np.array_equal(sw_o, c["sw"])
+    swi_o, fails = o.sw_invert(sw_o, 0, mu)
+    assert fails == 0 and np.array_equal(swi_o, c["sw_inv"])
     k = np.ascontiguousarray(f["in"])
     for sign, key in ((-1, "clover_inv_minus"), (+1, "clover_inv_plus")):
         l = o.new_field(); l[:N] = k

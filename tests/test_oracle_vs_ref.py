@@ -72,6 +72,13 @@ Pc = o.new_field(); it, hist = o.cg_her(Pc, k.copy(), 500, 1e-18, 1, N)
 r.spinor(10)[:] = 0; lib.assign(sp(11), sp(0), N)
 it2 = lib.cg_her(sp(10), sp(11), 500, 1e-18, 1, N, r.fnptr("Qtm_pm_psi"))
 assert it == it2, (it, it2); same(Pc, 10, "cg solution")
+# clover term and its inverse (operator/clover_term.c:88, operator/clover_invert.c:170): the reference's sw_term /
+# sw_invert(EE, mu) on its own gauge field vs the restatement, +mu and -mu sets
+sw_ref, swi_ref = r.clover(1.37, 0.02)
+sw = o.sw_term(kappa, 1.37)
+assert np.array_equal(sw, sw_ref), "sw_term"
+swi, fails = o.sw_invert(sw, 0, 0.02)
+assert fails == 0 and np.array_equal(swi, swi_ref), "sw_invert"
 print("OK", T, LX, LY, LZ, "cg iters", it)
 '''
 

@@ -89,6 +89,253 @@ __global__ __launch_bounds__(256) void clover_site_kernel(v2d *L, const v2d *K, 
   }
 }
 
+
+// ------------------------------------------------------------------ sw_term / sw_invert on the device
+// (operator/clover_term.c:88-200, operator/clover_invert.c:88-257).  Once per gauge configuration (or per MD step
+// in the HMC), so these favour clarity over the last GB/s: the leaf kernel walks the raw lexicographic gauge field
+// [VPR][4][9] exactly as the reference indexes g_gauge_field, halo slabs included, which makes T-split ranks work
+// without an edge exchange (only +-1 steps in two different directions are needed).
+struct M3 { v2d e[9]; };
+__device__ __forceinline__ v2d m3_cmul(v2d a, v2d b) { return v2d{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ v2d m3_conj(v2d a) { return v2d{a.x, -a.y}; }
+__device__ __forceinline__ M3 m3_load(const v2d *__restrict__ raw, int ix, int mu) {
+  M3 r;
+  const v2d *p = raw + ((size_t)ix * 4 + mu) * 9;
+#pragma unroll
+  for (int e = 0; e < 9; e++) r.e[e] = p[e];
+  return r;
+}
+// op(a) op(b), op = dagger when the flag is set
+template <bool AD, bool BD>
+__device__ __forceinline__ M3 m3_mul(const M3 &a, const M3 &b) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      v2d acc = v2d{0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const v2d x = AD ? m3_conj(a.e[3 * k + i]) : a.e[3 * i + k];
+        const v2d y = BD ? m3_conj(b.e[3 * j + k]) : b.e[3 * k + j];
+        acc += m3_cmul(x, y);
+      }
+      r.e[3 * i + j] = acc;
+    }
+  return r;
+}
+__device__ __forceinline__ void m3_acc(M3 &a, const M3 &b) {
+#pragma unroll
+  for (int e = 0; e < 9; e++) a.e[e] += b.e[e];
+}
+
+struct LexGeom { int T, LX, LY, LZ, V, split; };
+// geometry_eo.c:279-299: Index() of the PARALLELT / serial layouts; c[0] may be -1 or T
+__device__ __forceinline__ int lex_index(const LexGeom &g, int t, int x, int y, int z) {
+  x = (x + g.LX) % g.LX; y = (y + g.LY) % g.LY; z = (z + g.LZ) % g.LZ;
+  const int sp = (x * g.LY + y) * g.LZ + z, XYZ = g.LX * g.LY * g.LZ;
+  if (g.split) {
+    if (t == g.T) return g.V + sp;
+    if (t == -1) return g.V + XYZ + sp;
+  }
+  t = (t + g.T) % g.T;
+  return t * XYZ + sp;
+}
+
+// F_kl(x) = Q_kl(x) - Q_kl(x)^dagger, Q = sum of the four plaquette leaves (clover_term.c:104-154); plane p = (k,l), k < l
+__global__ __launch_bounds__(128) void sw_leaf_kernel(const v2d *__restrict__ raw, v2d *__restrict__ F, LexGeom g) {
+  const int ix = blockIdx.x * 128 + threadIdx.x;
+  if (ix >= g.V) return;
+  const int p = blockIdx.y;
+  const int k = p < 3 ? 0 : (p < 5 ? 1 : 2), l = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
+  int c[4];
+  int r = ix;
+  c[3] = r % g.LZ; r /= g.LZ; c[2] = r % g.LY; r /= g.LY; c[1] = r % g.LX; c[0] = r / g.LX;
+  auto at = [&](int dk, int dl) {
+    int d[4] = {c[0], c[1], c[2], c[3]};
+    d[k] += dk; d[l] += dl;
+    return lex_index(g, d[0], d[1], d[2], d[3]);
+  };
+  const int xpk = at(1, 0), xpl = at(0, 1), xmk = at(-1, 0), xml = at(0, -1), xpkml = at(1, -1), xplmk = at(-1, 1), xmkml = at(-1, -1);
+  M3 q, v1, v2;
+  v1 = m3_mul<false, false>(m3_load(raw, ix, k), m3_load(raw, xpk, l));
+  v2 = m3_mul<false, false>(m3_load(raw, ix, l), m3_load(raw, xpl, k));
+  q = m3_mul<false, true>(v1, v2);
+  v1 = m3_mul<false, true>(m3_load(raw, ix, l), m3_load(raw, xplmk, k));
+  v2 = m3_mul<true, false>(m3_load(raw, xmk, l), m3_load(raw, xmk, k));
+  m3_acc(q, m3_mul<false, false>(v1, v2));
+  v1 = m3_mul<false, false>(m3_load(raw, xmkml, l), m3_load(raw, xmk, k));
+  v2 = m3_mul<false, false>(m3_load(raw, xmkml, k), m3_load(raw, xml, l));
+  m3_acc(q, m3_mul<true, false>(v1, v2));
+  v1 = m3_mul<true, false>(m3_load(raw, xml, l), m3_load(raw, xml, k));
+  v2 = m3_mul<false, true>(m3_load(raw, xpkml, l), m3_load(raw, ix, k));
+  m3_acc(q, m3_mul<false, false>(v1, v2));
+  v2d *o = F + (size_t)p * 9 * g.V + ix;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) o[(size_t)(3 * i + j) * g.V] = q.e[3 * i + j] - m3_conj(q.e[3 * j + i]);
+}
+
+// clover_term.c:156-197: E_k = F_0k, B_1 = F_23, B_2 = -F_13, B_3 = F_12 combined into the six 3x3 blocks, written
+// straight into the device layout swd[par][2a+b][e][i].  Planes are stored as p = 0..5 <-> (01,02,03,12,13,23).
+__global__ __launch_bounds__(256) void sw_assemble_kernel(const v2d *__restrict__ F, v2d *__restrict__ d, int gs, int Vh, int V, int LX, int LY,
+                                                          int LZ, int toff, double ka_csw_8) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Vh) return;
+  const int par = blockIdx.y;
+  const int LZh = LZ / 2;
+  int r = i / LZh;
+  const int y = r % LY;
+  r /= LY;
+  const int x = r % LX, t = r / LX;
+  const int o = (t + x + y + toff + par) & 1;
+  const size_t ix = 2 * (size_t)i + o;
+  v2d *dst = d + (size_t)par * 54 * gs + i;
+#pragma unroll
+  for (int e = 0; e < 9; e++) {
+    const v2d e1 = F[((size_t)0 * 9 + e) * V + ix], e2 = F[((size_t)1 * 9 + e) * V + ix], e3 = F[((size_t)2 * 9 + e) * V + ix];
+    const v2d m3 = F[((size_t)3 * 9 + e) * V + ix], f13 = F[((size_t)4 * 9 + e) * V + ix], m1 = F[((size_t)5 * 9 + e) * V + ix];
+    const v2d m2 = v2d{-f13.x, -f13.y};
+    const double one = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+    auto itimes = [](v2d a) { return v2d{-a.y, a.x}; };
+    v2d a;
+    a = itimes(e3 - m3);                 dst[(size_t)(0 * 9 + e) * gs] = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y};          // sw[x][0][0]
+    a = itimes(e3 + m3);                 dst[(size_t)(1 * 9 + e) * gs] = v2d{one - ka_csw_8 * a.x, -ka_csw_8 * a.y};         // sw[x][0][1]
+    a = itimes(e1 - m1) + (e2 - m2);     dst[(size_t)(2 * 9 + e) * gs] = v2d{ka_csw_8 * a.x, ka_csw_8 * a.y};                // sw[x][1][0]
+    a = itimes(e1 + m1) + (e2 + m2);     dst[(size_t)(3 * 9 + e) * gs] = v2d{-ka_csw_8 * a.x, -ka_csw_8 * a.y};              // sw[x][1][1]
+    a = itimes(m3 - e3);                 dst[(size_t)(4 * 9 + e) * gs] = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y};          // sw[x][2][0]
+    a = itimes(m3 + e3);                 dst[(size_t)(5 * 9 + e) * gs] = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y};          // sw[x][2][1]
+  }
+}
+
+// clover_invert.c:88-160: 6x6 complex inverse by Householder triangularisation without pivoting, inversion of the
+// triangle in place, then the reflections from the right in reverse order.  Fully unrolled => `a` lives in registers.
+__device__ __forceinline__ int six_invert_dev(v2d (&a)[6][6]) {
+  const double tiny = 1.0e-20;   // clover_leaf.c:55
+  v2d d[6], u[6];
+  double p[6];
+  int fail = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = k + 1; j < 6; j++) s += a[j][k].x * a[j][k].x + a[j][k].y * a[j][k].y;
+    s = sqrt(1.0 + s / (a[k][k].x * a[k][k].x + a[k][k].y * a[k][k].y));
+    const v2d sigma = v2d{s * a[k][k].x, s * a[k][k].y};
+    a[k][k] += sigma;
+    p[k] = sigma.x * a[k][k].x + sigma.y * a[k][k].y;
+    const double q = sigma.x * sigma.x + sigma.y * sigma.y;
+    if (q < tiny) fail++;
+    d[k] = v2d{-sigma.x / q, sigma.y / q};
+#pragma unroll
+    for (int j = k + 1; j < 6; j++) {
+      v2d z = v2d{0.0, 0.0};
+#pragma unroll
+      for (int i = k; i < 6; i++) z += m3_cmul(m3_conj(a[i][k]), a[i][j]);
+      z = v2d{z.x / p[k], z.y / p[k]};
+#pragma unroll
+      for (int i = k; i < 6; i++) a[i][j] -= m3_cmul(z, a[i][k]);
+    }
+  }
+  {
+    const v2d sigma = a[5][5];
+    const double q = sigma.x * sigma.x + sigma.y * sigma.y;
+    if (q < tiny) fail++;
+    d[5] = v2d{sigma.x / q, -sigma.y / q};
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; k--)
+#pragma unroll
+    for (int i = k - 1; i >= 0; i--) {
+      v2d z = v2d{0.0, 0.0};
+#pragma unroll
+      for (int j = i + 1; j < k; j++) z += m3_cmul(a[i][j], a[j][k]);
+      z += m3_cmul(a[i][k], d[k]);
+      const v2d w = m3_cmul(z, d[i]);
+      a[i][k] = v2d{-w.x, -w.y};
+    }
+  a[5][5] = d[5];
+#pragma unroll
+  for (int k = 4; k >= 0; k--) {
+#pragma unroll
+    for (int j = k; j < 6; j++) u[j] = a[j][k];
+    a[k][k] = d[k];
+#pragma unroll
+    for (int j = k + 1; j < 6; j++) a[j][k] = v2d{0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      v2d z = v2d{0.0, 0.0};
+#pragma unroll
+      for (int j = k; j < 6; j++) z += m3_cmul(a[i][j], u[j]);
+      z = v2d{z.x / p[k], z.y / p[k]};
+#pragma unroll
+      for (int j = k; j < 6; j++) a[i][j] -= m3_cmul(m3_conj(u[j]), z);
+    }
+  }
+  return fail;
+}
+
+// clover_invert.c:170-257: thread = (site i of parity ieo, chirality block b, set: 0 -> +mu, 1 -> -mu)
+__global__ __launch_bounds__(64) void sw_invert_kernel(const v2d *__restrict__ swp, v2d *__restrict__ swi, int gs, int Vh, double mu, int *fails) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= Vh) return;
+  const int b = blockIdx.y, set = blockIdx.z;
+  v2d a[6][6];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      a[r][c] = swp[((size_t)(0 + b) * 9 + 3 * r + c) * gs + i];
+      const v2d off = swp[((size_t)(2 + b) * 9 + 3 * r + c) * gs + i];
+      a[r][c + 3] = off;
+      a[c + 3][r] = m3_conj(off);
+      a[r + 3][c + 3] = swp[((size_t)(4 + b) * 9 + 3 * r + c) * gs + i];
+    }
+  const double m = (set == 0 ? 1.0 : -1.0) * (b == 0 ? mu : -mu);
+#pragma unroll
+  for (int r = 0; r < 6; r++) a[r][r].y += m;
+  const int f = six_invert_dev(a);
+  if (f) atomicAdd(fails, f);
+  v2d *o = swi + (size_t)set * 72 * gs + i;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      o[((size_t)(0 + b) * 9 + 3 * r + c) * gs] = a[r][c];
+      o[((size_t)(2 + b) * 9 + 3 * r + c) * gs] = a[r][c + 3];
+      o[((size_t)(4 + b) * 9 + 3 * r + c) * gs] = a[r + 3][c + 3];
+      o[((size_t)(6 + b) * 9 + 3 * r + c) * gs] = a[r + 3][c];
+    }
+}
+
+// inverse of sw_sort_kernel / swinv_sort_kernel: device layout -> the reference's host layout
+__global__ __launch_bounds__(256) void sw_unsort_kernel(v2d *__restrict__ raw, const v2d *__restrict__ d, int gs, int Vh, int LX, int LY, int LZ,
+                                                        int toff) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Vh) return;
+  const int par = blockIdx.y;
+  const int LZh = LZ / 2;
+  int r = i / LZh;
+  const int y = r % LY;
+  r /= LY;
+  const int x = r % LX, t = r / LX;
+  const int o = (t + x + y + toff + par) & 1;
+  v2d *dst = raw + (2 * (size_t)i + o) * 54;
+  const v2d *src = d + (size_t)par * 54 * gs + i;
+#pragma unroll 6
+  for (int e = 0; e < 54; e++) dst[e] = src[(size_t)e * gs];
+}
+__global__ __launch_bounds__(256) void swinv_unsort_kernel(v2d *__restrict__ raw, const v2d *__restrict__ d, int gs, int Vh) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Vh) return;
+  const int sign = blockIdx.y;
+  v2d *dst = raw + ((size_t)sign * Vh + i) * 72;
+  const v2d *src = d + (size_t)sign * 72 * gs + i;
+#pragma unroll 6
+  for (int e = 0; e < 72; e++) dst[e] = src[(size_t)e * gs];
+}
+
 static int need64(const tmhip_field *f, const char *who) {
   if (!f || f->kind != TMHIP_FIELD_EO || f->prec != 0) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity fp64 field\n", who); return 1; }
   return 0;
@@ -117,7 +364,6 @@ extern "C" {
 
 int tmhip_set_clover(tmhip_ctx *ctx, const void *sw_host, const void *sw_inv_host) {
   if (!sw_host || !sw_inv_host) TMHIP_FAIL("tmhip_set_clover: null argument");
-  if (ctx->g.nproc_t > 1) TMHIP_FAIL("tmhip_set_clover: single-rank lattices only in this round");
   TMHIP_CHECK(hipSetDevice(ctx->device));
   const size_t n1 = (size_t)2 * 54 * ctx->gs, n2 = (size_t)2 * 72 * ctx->gs;
   if (!ctx->sw) TMHIP_CHECK(hipMalloc((void **)&ctx->sw, n1 * sizeof(v2d)));
@@ -135,7 +381,91 @@ int tmhip_set_clover(tmhip_ctx *ctx, const void *sw_host, const void *sw_inv_hos
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   TMHIP_CHECK(hipFree(raw));
   ctx->clover_set = true;
+  ctx->sw_set = true;
+  ctx->sw_inv_sets = 2;
   ctx->clover32_set = false;
+  return 0;
+}
+
+static int clover_alloc(tmhip_ctx *ctx) {
+  const size_t n1 = (size_t)2 * 54 * ctx->gs, n2 = (size_t)2 * 72 * ctx->gs;
+  if (!ctx->sw) TMHIP_CHECK(hipMalloc((void **)&ctx->sw, n1 * sizeof(v2d)));
+  if (!ctx->sw_inv) TMHIP_CHECK(hipMalloc((void **)&ctx->sw_inv, n2 * sizeof(v2d)));
+  if (!ctx->sw_fail) TMHIP_CHECK(hipMalloc((void **)&ctx->sw_fail, sizeof(int)));
+  return 0;
+}
+
+/* operator/clover_term.c:88 sw_term(gf, kappa, c_sw): gf is the host gauge field exactly as for tmhip_set_gauge
+ * ([VOLUMEPLUSRAND][4] su3, halo slabs filled on T-split ranks).  Result stays in HBM (fetch with tmhip_get_clover). */
+int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_sw) {
+  if (!gauge_host) TMHIP_FAIL("tmhip_sw_term: null gauge field");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  if (clover_alloc(ctx)) return 1;
+  const size_t gbytes = (size_t)ctx->VPR * 4 * 9 * sizeof(v2d), fbytes = (size_t)6 * 9 * ctx->V * sizeof(v2d);
+  void *raw = nullptr, *F = nullptr;
+  TMHIP_CHECK(hipMalloc(&raw, gbytes));
+  TMHIP_CHECK(hipMalloc(&F, fbytes));
+  TMHIP_CHECK(hipMemcpyAsync(raw, gauge_host, gbytes, hipMemcpyHostToDevice, ctx->stream));
+  LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, ctx->g.nproc_t > 1 ? 1 : 0};
+  hipLaunchKernelGGL(sw_leaf_kernel, dim3((ctx->V + 127) / 128, 6), dim3(128), 0, ctx->stream, (const v2d *)raw, (v2d *)F, g);
+  hipLaunchKernelGGL(sw_assemble_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (const v2d *)F, ctx->sw, ctx->gs, ctx->Vh,
+                     ctx->V, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.proc_t * ctx->g.T, kappa * c_sw / 8.);
+  TMHIP_CHECK(hipGetLastError());
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  TMHIP_CHECK(hipFree(F));
+  TMHIP_CHECK(hipFree(raw));
+  ctx->sw_set = true;
+  ctx->clover_set = false;     // sw_inv no longer matches
+  ctx->clover32_set = false;
+  return 0;
+}
+
+/* operator/clover_invert.c:170 sw_invert(ieo, mu): inverse of (1 + T +- i mu g5) on the sites of parity ieo, +mu set and
+ * (mu != 0) -mu set, into the one sw_inv array -- like the reference's global, it holds one parity at a time and the
+ * operators of this library expect ieo = EE (0), as operator.c:364 and invert_clover_eo.c use it. */
+int tmhip_sw_invert(tmhip_ctx *ctx, int ieo, double mu) {
+  if (!ctx->sw_set) TMHIP_FAIL("tmhip_sw_invert called before tmhip_sw_term / tmhip_set_clover");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  if (clover_alloc(ctx)) return 1;
+  TMHIP_CHECK(hipMemsetAsync(ctx->sw_fail, 0, sizeof(int), ctx->stream));
+  const int nsets = fabs(mu) > 0. ? 2 : 1;   /* clover_invert.c:225 */
+  hipLaunchKernelGGL(sw_invert_kernel, dim3((ctx->Vh + 63) / 64, 2, nsets), dim3(64), 0, ctx->stream, swpar(ctx, ieo), ctx->sw_inv, ctx->gs,
+                     ctx->Vh, mu, ctx->sw_fail);
+  TMHIP_CHECK(hipGetLastError());
+  int fails = 0;
+  TMHIP_CHECK(hipMemcpyAsync(&fails, ctx->sw_fail, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (fails > 0 && ctx->g.proc_t == 0) printf("# inversion failed in six_invert code %d\n", fails);   /* clover_invert.c:213-216 */
+  ctx->sw_inv_sets = nsets;
+  ctx->clover_set = true;
+  ctx->clover32_set = false;
+  return 0;
+}
+
+/* Copies the device-resident blocks back in the reference's layouts (either pointer may be NULL):
+ * sw[VOLUME][3][2], sw_inv[VOLUME][4][2] su3. */
+int tmhip_get_clover(tmhip_ctx *ctx, void *sw_host, void *sw_inv_host) {
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  if (sw_host && !ctx->sw_set) TMHIP_FAIL("tmhip_get_clover: no clover term on the device");
+  if (sw_inv_host && !ctx->clover_set) TMHIP_FAIL("tmhip_get_clover: no inverse clover term on the device");
+  const size_t b1 = (size_t)ctx->V * 54 * sizeof(v2d), b2 = (size_t)ctx->V * 72 * sizeof(v2d);
+  void *raw = nullptr;
+  TMHIP_CHECK(hipMalloc(&raw, b2));
+  if (sw_host) {
+    hipLaunchKernelGGL(sw_unsort_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (v2d *)raw, (const v2d *)ctx->sw, ctx->gs, ctx->Vh,
+                       ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.proc_t * ctx->g.T);
+    TMHIP_CHECK(hipMemcpyAsync(sw_host, raw, b1, hipMemcpyDeviceToHost, ctx->stream));
+    TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  if (sw_inv_host) {
+    // like the reference, leave the -mu half of the host array alone when it was not computed (mu == 0)
+    hipLaunchKernelGGL(swinv_unsort_kernel, dim3((ctx->Vh + 255) / 256, ctx->sw_inv_sets), dim3(256), 0, ctx->stream, (v2d *)raw,
+                       (const v2d *)ctx->sw_inv, ctx->gs, ctx->Vh);
+    TMHIP_CHECK(hipMemcpyAsync(sw_inv_host, raw, b2 / 2 * ctx->sw_inv_sets, hipMemcpyDeviceToHost, ctx->stream));
+    TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  TMHIP_CHECK(hipGetLastError());
+  TMHIP_CHECK(hipFree(raw));
   return 0;
 }
 

@@ -308,6 +308,21 @@ static tmhip_ctx *refresh_clover() {
   return c;
 }
 void tmlqcd_hip_update_clover(void) { g_clover_uploaded = false; }
+/* sw_term(g_gauge_field, kappa, c_sw) (operator/clover_term.c:88) computed in HBM; the host's sw array, if the program
+ * has one (init_sw_fields), receives a copy so that host-side consumers (sw_trace, sw_deriv ...) keep working. */
+void tmlqcd_hip_sw_term(const double kappa, const double c_sw) {
+  tmhip_ctx *c = refresh(false);
+  CK(tmhip_sw_term(c, &g_gauge_field[0][0], kappa, c_sw));
+  if (&sw && sw) CK(tmhip_get_clover(c, &sw[0][0][0], nullptr));
+  g_clover_uploaded = false;
+}
+/* sw_invert(ieo, mu) (operator/clover_invert.c:170) from the device-resident clover term */
+void tmlqcd_hip_sw_invert(const int ieo, const double mu) {
+  tmhip_ctx *c = refresh(false);
+  CK(tmhip_sw_invert(c, ieo, mu));
+  if (&sw_inv && sw_inv) CK(tmhip_get_clover(c, nullptr, &sw_inv[0][0][0]));
+  g_clover_uploaded = true;   // the device copy is the fresh one
+}
 EO_OP_CLOVER(Qsw_pm_psi, tmhip_Qsw_pm_psi)      /* clovertm_operators.c:233-245 */
 EO_OP_CLOVER(Msw_plus_psi, tmhip_Msw_plus_psi)  /* clovertm_operators.c:256-261 */
 /* clovertm_operators.c:268-272 */

@@ -69,7 +69,10 @@ struct tmhip_ctx {
   // clover twisted mass: site-local blocks uploaded from the host's sw / sw_inv
   v2d *sw;             // [2 parity][6][9][gs]   sw[ix][a][b] -> block 2a+b
   v2d *sw_inv;         // [2 sign: +mu, -mu][8][9][gs]  sw_inv[icy][a][b] -> block 2a+b (even sites)
-  bool clover_set;
+  bool clover_set;     // sw and sw_inv both valid
+  bool sw_set;         // sw valid (after tmhip_sw_term / tmhip_set_clover)
+  int sw_inv_sets;     // 2 when the -mu set of sw_inv is valid as well (mu != 0), else 1
+  int *sw_fail;        // device counter of near-singular pivots met by tmhip_sw_invert
   v2f *sw32, *sw_inv32; bool clover32_set;
   v2f *gauge32;        // fp32 twin of the gauge copy (g_gauge_field_copy_32), built on first use
   bool gauge32_set;

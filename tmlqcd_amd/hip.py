@@ -80,6 +80,9 @@ def load_library():
         "tmhip_assign": [vp, vp, vp, i],
         "tmhip_cg_her": [vp, vp, vp, i, d, i, i, i, C.POINTER(i), pd, i],
         "tmhip_set_clover": [vp, vp, vp],
+        "tmhip_sw_term": [vp, vp, d, d],
+        "tmhip_sw_invert": [vp, i, d],
+        "tmhip_get_clover": [vp, vp, vp],
         "tmhip_clover_inv": [vp, vp, i, d],
         "tmhip_clover_gamma5": [vp, i, vp, vp, vp, d],
         "tmhip_clover": [vp, i, vp, vp, vp, d],
@@ -260,6 +263,23 @@ class Lattice:
         if sw.shape != (self.V, 3, 2, 3, 3, 2) or sw_inv.shape != (self.V, 4, 2, 3, 3, 2):
             raise TmHipError("clover arrays must be [V][3][2][3][3][2] and [V][4][2][3][3][2]")
         _ck(self.lib.tmhip_set_clover(self.h, _hp(sw), _hp(sw_inv)), "tmhip_set_clover")
+
+    def sw_term(self, gauge, kappa, c_sw):
+        """operator/clover_term.c:88 on the device; `gauge` as for set_gauge ([VPR][4][3][3][2])."""
+        if gauge.shape != (self.VPR, 4, 3, 3, 2):
+            raise TmHipError("gauge field must be [%d][4][3][3][2]" % self.VPR)
+        _ck(self.lib.tmhip_sw_term(self.h, _hp(gauge), kappa, c_sw), "tmhip_sw_term")
+
+    def sw_invert(self, ieo, mu):
+        """operator/clover_invert.c:170 on the device (needs sw_term or set_clover first)."""
+        _ck(self.lib.tmhip_sw_invert(self.h, ieo, mu), "tmhip_sw_invert")
+
+    def get_clover(self, want_sw=True, want_sw_inv=True):
+        """Device-resident clover blocks in the reference's host layouts: (sw [V][3][2][3][3][2], sw_inv [V][4][2][3][3][2])."""
+        sw = np.zeros((self.V, 3, 2, 3, 3, 2)) if want_sw else None
+        swi = np.zeros((self.V, 4, 2, 3, 3, 2)) if want_sw_inv else None
+        _ck(self.lib.tmhip_get_clover(self.h, _hp(sw) if want_sw else None, _hp(swi) if want_sw_inv else None), "tmhip_get_clover")
+        return sw, swi
 
     def clover_inv(self, l, tau3sign, mu):
         _ck(self.lib.tmhip_clover_inv(self.h, l.h, tau3sign, mu), "clover_inv")
