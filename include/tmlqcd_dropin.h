@@ -137,6 +137,21 @@ int mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params solver_p
 int rg_mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params solver_params, const int max_iter,
                     const double eps_sq, const int rel_prec, const int N, matrix_mult f, matrix_mult32 f32);
 
+/* ---- deriv_Sb.h: hopping part of the fermion force -------- */
+typedef struct { double d1, d2, d3, d4, d5, d6, d7, d8; } su3adj;           /* su3adj.h:23-26 */
+typedef struct {                                                             /* hamiltonian_field.h:26-32 */
+  su3 **gaugefield;
+  su3adj **momenta;
+  su3adj **derivative;
+  int update_gauge_copy;
+  int traj_counter;
+} hamiltonian_field_t;
+/* deriv_Sb.c:401.  Coherent mode: the contribution is added to hf->derivative before returning.  Resident mode: it
+ * stays in the device accumulator until tmlqcd_hip_flush_derivative(hf) adds it to hf->derivative (call that once,
+ * after the last deriv_Sb of a force computation, e.g. at the end of det_derivative, monomial/det_monomial.c:56-117). */
+void deriv_Sb(const int ieo, spinor *const l, spinor *const k, hamiltonian_field_t *const hf, const double factor);
+void tmlqcd_hip_flush_derivative(hamiltonian_field_t *const hf);
+
 /* ---- residency control (additions; not in the reference) ------------------- */
 enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1 };
 /* Device versions of sw_term(g_gauge_field, kappa, c_sw) / sw_invert(ieo, mu) (operator/clover_term.c:88,

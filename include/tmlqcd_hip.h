@@ -133,6 +133,15 @@ enum { TMHIP_OP_QTM_PM = 0, TMHIP_OP_QTM_PLUS = 1, TMHIP_OP_QTM_MINUS = 2, TMHIP
 int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec,
                  int N, int op, int *iters, double *res_hist, int hist_len);
 
+/* ---- fermion force, hopping part (deriv_Sb.c:401-700) ------------------------------
+ * deriv_Sb(ieo, l, k, hf, factor) accumulates 2 factor trlambda(...) of the one-hop terms into hf->derivative.  Here the
+ * accumulator is device-resident: zero it, call tmhip_deriv_Sb any number of times (one call per deriv_Sb call of the
+ * reference, same ieo / l / k / factor), then fetch it in the host layout su3adj df[VOLUME][4] (8 doubles per link,
+ * lexicographic sites), either overwriting or adding to the host array.  Single-rank lattices for now. */
+int tmhip_derivative_zero(tmhip_ctx *ctx);
+int tmhip_deriv_Sb(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, double factor);
+int tmhip_derivative_download(tmhip_ctx *ctx, void *df, int accumulate);
+
 /* ---- clover twisted mass (invert_clover_eo.c:63-165) ------
  * The 6x6 site blocks are inputs like the gauge field: `sw` = su3 sw[VOLUME][3][2] from sw_term
  * (operator/clover_term.c:88), `sw_inv` = su3 sw_inv[VOLUME][4][2] from sw_invert(EE, mu)

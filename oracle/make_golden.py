@@ -132,6 +132,21 @@ def gen_sym(T, L):
     print("sym", T, L, {k: float((v ** 2).sum()) for k, v in arrs.items()})
 
 
+def gen_force(T, L):
+    """deriv_Sb.c:401 on the gauge field / source of ref_fields_*: l = in, k = Heo (as det_derivative pairs X_o with
+    the hopped field), EO then OE with different factors, accumulated."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle.refbind import RefLattice
+    r = RefLattice(T, L, L, L, kappa=0.125, mu=0.01, nfields=14)
+    r.random_fields(123456)
+    r.lib.Hopping_Matrix(0, r.sp(1), r.sp(0))
+    r.deriv_Sb(1, 0, 1, 0.5)      # l on odd sites... parity labels are the caller's business: OE
+    r.deriv_Sb(0, 1, 0, -0.25)    # EO with the roles swapped
+    np.savez_compressed(os.path.join(GOLD, "ref_force_%dx%d.npz" % (T, L)), derivative=r.derivative().copy())
+    print("force", T, L, float(np.abs(r.derivative()).max()))
+
+
 def gen_rg(T, L, full):
     """solver/rg_mixed_cg_her.c:180 run by the reference's default (half-spinor) build: iteration counts for two
     values of mcg_delta, and the 4^4 solution."""
@@ -191,6 +206,8 @@ if __name__ == "__main__":
         gen_hs(int(sys.argv[1]), int(sys.argv[2]))
     elif len(sys.argv) == 4 and sys.argv[3] in ("rg", "rgfull"):
         gen_rg(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "rgfull")
+    elif len(sys.argv) == 4 and sys.argv[3] == "force":
+        gen_force(int(sys.argv[1]), int(sys.argv[2]))
     elif len(sys.argv) == 4 and sys.argv[3] == "sym":
         gen_sym(int(sys.argv[1]), int(sys.argv[2]))
     elif len(sys.argv) == 4 and sys.argv[3] == "clover":
@@ -201,6 +218,7 @@ if __name__ == "__main__":
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "hs"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "clover"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "sym"])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "force"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "rgfull"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "8", "8", "rg"])
         for T, L, full in ((4, 4, 1), (8, 8, 0), (6, 4, 0)):

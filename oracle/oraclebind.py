@@ -50,6 +50,7 @@ def _lib():
         lib.tmo_M_full.argtypes = [vp] * 5
         lib.tmo_set_clover.argtypes = [vp, vp, vp]
         lib.tmo_sw_term.argtypes = [vp, vp, d, d]
+        lib.tmo_deriv_Sb.argtypes = [vp, i, vp, vp, vp, d]
         lib.tmo_sw_invert.argtypes = [vp, vp, vp, i, d]
         lib.tmo_sw_invert.restype = i
         lib.tmo_clover_inv.argtypes = [vp, vp, i, d]
@@ -146,6 +147,11 @@ class Oracle:
         self._sw = np.ascontiguousarray(sw, dtype=np.float64)
         self._sw_inv = np.ascontiguousarray(sw_inv, dtype=np.float64)
         self.lib.tmo_set_clover(self.h, _p(self._sw), _p(self._sw_inv))
+
+    def deriv_Sb(self, ieo, l, k, df, factor):
+        """deriv_Sb.c:401: accumulates the hopping part of the fermion force into df [VPR][4][8] (su3adj)."""
+        assert df.shape == (self.VPR, 4, 8) and df.flags.c_contiguous
+        self.lib.tmo_deriv_Sb(self.h, ieo, _p(l), _p(k), _p(df), factor)
 
     def sw_term(self, kappa, c_sw):
         """operator/clover_term.c:88 on the current gauge field -> sw [V][3][2][3][3][2]."""

@@ -115,6 +115,28 @@ int tmref_rg_mixed_cg_her(spinor *P, spinor *Q, double delta, int max_iter, doub
 }
 #endif
 
+#ifndef TMREF_HOSTPROG
+/* Fermion force, hopping part: deriv_Sb(ieo, l, k, hf, factor) (deriv_Sb.c:401) accumulating into a derivative field
+ * owned by the harness, laid out like df0 (su3adj [VOLUMEPLUSRAND][4], init/init_moment_field.c). */
+#include "hamiltonian_field.h"
+#include "deriv_Sb.h"
+static su3adj *tmref_df = NULL, **tmref_dfp = NULL;
+double *tmref_derivative(void) {
+  if (!tmref_df) {
+    tmref_df = calloc((size_t)4 * VOLUMEPLUSRAND, sizeof(su3adj));
+    tmref_dfp = malloc((size_t)VOLUMEPLUSRAND * sizeof(su3adj *));
+    for (int i = 0; i < VOLUMEPLUSRAND; i++) tmref_dfp[i] = tmref_df + 4 * (size_t)i;
+  }
+  return (double *)tmref_df;
+}
+void tmref_deriv_Sb(int ieo, spinor *l, spinor *k, double factor) {
+  hamiltonian_field_t hf;
+  (void)tmref_derivative();
+  hf.gaugefield = g_gauge_field; hf.momenta = NULL; hf.derivative = tmref_dfp; hf.update_gauge_copy = 0; hf.traj_counter = 0;
+  deriv_Sb(ieo, l, k, &hf, factor);
+}
+#endif
+
 void tmref_set_theta(double x0, double x1, double x2, double x3) {
   X0 = x0; X1 = x1; X2 = x2; X3 = x3;
   boundary(g_kappa);

@@ -96,6 +96,17 @@ class RefLattice:
             raise RuntimeError("tmref_init failed: %d" % rc)
         self.threads = lib.tmref_threads()
 
+    def deriv_Sb(self, ieo, il, ik, factor):
+        """deriv_Sb.c:401 on g_spinor_field[il] (left) and [ik] (right), accumulating into the harness's derivative field."""
+        self.lib.tmref_deriv_Sb.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double]
+        self.lib.tmref_deriv_Sb(ieo, self.sp(il), self.sp(ik), factor)
+
+    def derivative(self):
+        """View of the accumulated derivative field, su3adj [V][4] as float64 [V][4][8]."""
+        self.lib.tmref_derivative.restype = C.c_void_p
+        n = self.V * 4 * 8
+        return np.frombuffer((C.c_double * n).from_address(self.lib.tmref_derivative()), dtype=np.float64).reshape(self.V, 4, 8)
+
     def rg_mixed_cg_her(self, iP, iQ, delta, max_iter, eps_sq, rel_prec, debug=0):
         """solver/rg_mixed_cg_her.c:180 on g_spinor_field[iP], [iQ] (half-spinor build only)."""
         return self.lib.tmref_rg_mixed_cg_her(self.sp(iP), self.sp(iQ), delta, max_iter, eps_sq, rel_prec, self.V // 2, debug)

@@ -797,6 +797,66 @@ int tmo_sw_invert(tmo_lattice *lat, tmo_su3 *sw_inv, const tmo_su3 *sw, int ieo,
   return fails;
 }
 
+/* ---------------------------------------------------------------- fermion force, hopping part
+ * deriv_Sb.c:401-700 (generic branch, _GAUGE_COPY): for every site x of parity ieo, left vector g5 l(x), right field k:
+ *   df[x][mu]      += 2 factor trlambda( ka_mu U_mu(x)      [ (P+ g5 l(x)) (x) (P+ k(x+mu))^dagger ]^dagger )
+ *   df[x-mu][mu]   += 2 factor trlambda( ka_mu U_mu(x-mu)   [ (P- k(x-mu)) (x) (P- g5 l(x))^dagger ]^dagger )
+ * with the two-component projections of hopping.h and trlambda of su3adj.h:164-172.  Every link receives exactly one
+ * contribution per call, so the site loop is race-free.  df is su3adj [VPR][4] = 8 doubles per link. */
+static inline void tmo_project(const tmo_spinor *s, int mu, int plus, tmo_su3_vector *a, tmo_su3_vector *b) {
+  switch (2 * mu + (plus ? 0 : 1)) {
+    case 0: *a = v_add(s->s0, s->s2);   *b = v_add(s->s1, s->s3);   break;   /* deriv_Sb.c:470-474 */
+    case 1: *a = v_sub(s->s0, s->s2);   *b = v_sub(s->s1, s->s3);   break;   /* :492-496 */
+    case 2: *a = v_i_add(s->s0, s->s3); *b = v_i_add(s->s1, s->s2); break;   /* :515-519 */
+    case 3: *a = v_i_sub(s->s0, s->s3); *b = v_i_sub(s->s1, s->s2); break;   /* :537-541 */
+    case 4: *a = v_add(s->s0, s->s3);   *b = v_sub(s->s1, s->s2);   break;   /* :559-563 */
+    case 5: *a = v_sub(s->s0, s->s3);   *b = v_add(s->s1, s->s2);   break;   /* :581-585 */
+    case 6: *a = v_i_add(s->s0, s->s2); *b = v_i_sub(s->s1, s->s3); break;   /* :603-607 */
+    default: *a = v_i_sub(s->s0, s->s2); *b = v_i_add(s->s1, s->s3); break;  /* :625-629 */
+  }
+}
+/* t = u (x) v^dagger + w (x) z^dagger (su3.h:706-715); v2 = U t^dagger (su3.h:605-614); v1 = c v2; df += fac trlambda(v1) */
+static inline void tmo_force_link(double *d, const tmo_su3 *U, double _Complex c, double fac, const tmo_su3_vector *u,
+                                  const tmo_su3_vector *v, const tmo_su3_vector *w, const tmo_su3_vector *z) {
+  const double _Complex *uu = &u->c0, *vv = &v->c0, *ww = &w->c0, *zz = &z->c0;
+  tmo_su3 t, v2, a;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) M33(&t)[i][j] = uu[i] * conj(vv[j]) + ww[i] * conj(zz[j]);
+  m33_mul(&v2, U, 0, &t, 1, 0);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) M33(&a)[i][j] = c * M33(&v2)[i][j];
+  d[0] += fac * (-cimag(a.c10) - cimag(a.c01));
+  d[1] += fac * (+creal(a.c10) - creal(a.c01));
+  d[2] += fac * (-cimag(a.c00) + cimag(a.c11));
+  d[3] += fac * (-cimag(a.c20) - cimag(a.c02));
+  d[4] += fac * (+creal(a.c20) - creal(a.c02));
+  d[5] += fac * (-cimag(a.c21) - cimag(a.c12));
+  d[6] += fac * (+creal(a.c21) - creal(a.c12));
+  d[7] += fac * ((-cimag(a.c00) - cimag(a.c11) + 2.0 * cimag(a.c22)) * 0.577350269189625);
+}
+void tmo_deriv_Sb(tmo_lattice *lat, int ieo, const tmo_spinor *l, const tmo_spinor *k, double *df, double factor) {
+  if (lat->gauge_dirty) tmo_update_backward_gauge(lat);     /* deriv_Sb.c:416-420 */
+  const int ioff = ieo == 0 ? 0 : lat->VPR / 2, Vh = lat->V / 2;
+#pragma omp parallel for
+  for (int icx = ioff; icx < Vh + ioff; icx++) {
+    const int ix = lat->eo2lexic[icx];
+    const tmo_su3 *u = lat->gauge_copy + 8 * (size_t)icx;   /* [2mu] = U_mu(x), [2mu+1] = U_mu(x-mu) */
+    tmo_spinor rr = l[icx - ioff];
+    rr.s2.c0 = -rr.s2.c0; rr.s2.c1 = -rr.s2.c1; rr.s2.c2 = -rr.s2.c2;   /* gamma5, deriv_Sb.c:455-456 */
+    rr.s3.c0 = -rr.s3.c0; rr.s3.c1 = -rr.s3.c1; rr.s3.c2 = -rr.s3.c2;
+    for (int mu = 0; mu < 4; mu++) {
+      tmo_su3_vector psia, psib, phia, phib;
+      const int iyp = lat->iup[4 * ix + mu], iym = lat->idn[4 * ix + mu];
+      tmo_project(k + lat->lexic2eosub[iyp], mu, 1, &psia, &psib);
+      tmo_project(&rr, mu, 1, &phia, &phib);
+      tmo_force_link(df + ((size_t)4 * ix + mu) * 8, &u[2 * mu], lat->ka[mu], 2. * factor, &phia, &psia, &phib, &psib);
+      tmo_project(k + lat->lexic2eosub[iym], mu, 0, &psia, &psib);
+      tmo_project(&rr, mu, 0, &phia, &phib);
+      tmo_force_link(df + ((size_t)4 * iym + mu) * 8, &u[2 * mu + 1], lat->ka[mu], 2. * factor, &psia, &phia, &psib, &phib);
+    }
+  }
+}
+
 /* ---------------------------------------------------------------- linalg */
 /* Per-thread Kahan partials summed in thread order, as the reference does with
    g_omp_acc_re (linalg/square_norm.c:299-304). */

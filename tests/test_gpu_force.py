@@ -1,0 +1,104 @@
+"""GPU: hopping part of the fermion force, deriv_Sb (deriv_Sb.c:401-700), against the reference's
+4^4 fixture and the CPU oracle (which is bit-exact against the reference, tests/test_oracle_vs_ref.py)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import TOL, random_gauge, random_spinor, rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_deriv_Sb_fixture_from_reference():
+    from tmlqcd_amd import Lattice
+    f = np.load(os.path.join(GOLD, "ref_fields_4x4.npz"))
+    want = np.load(os.path.join(GOLD, "ref_force_4x4.npz"))["derivative"]
+    lat = Lattice(4, 4, 4, 4, kappa=0.125, mu=0.01)
+    lat.set_gauge(np.ascontiguousarray(f["gauge"]))
+    a, b = lat.field(np.ascontiguousarray(f["in"])), lat.field(np.ascontiguousarray(f["Heo"]))
+    lat.derivative_zero()
+    lat.deriv_Sb(1, a, b, 0.5)
+    lat.deriv_Sb(0, b, a, -0.25)
+    assert rel_err(lat.derivative(), want) < TOL
+    lat.close()
+
+
+@pytest.mark.parametrize("dims", [(8, 6, 4, 12), (4, 2, 6, 2), (2, 2, 2, 2)])
+def test_deriv_Sb_against_oracle(dims):
+    """Ragged extents incl. the 2-site wrap (x+mu == x-mu), twisted boundary phases in every direction, both parities,
+    accumulation over calls, and the accumulate / overwrite download modes."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T, LX, LY, LZ = dims
+    kappa, mu, theta = 0.131, 0.02, (1.0, 0.5, -0.25, 0.125)
+    orc = Oracle(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta, threads=8)
+    lat = Lattice(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta)
+    g = random_gauge(91, orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    N = orc.Vh
+    l, k = random_spinor(92, N), random_spinor(93, N)
+    lo, ko = orc.new_field(), orc.new_field(); lo[:N] = l; ko[:N] = k
+    dl, dk = lat.field(l), lat.field(k)
+    df = np.zeros((orc.VPR, 4, 8))
+    lat.derivative_zero()
+    for ieo, fac in ((0, 0.7), (1, -1.3), (0, 0.11)):
+        orc.deriv_Sb(ieo, lo, ko, df, fac)
+        lat.deriv_Sb(ieo, dl, dk, fac)
+    got = lat.derivative()
+    assert rel_err(got, df[:orc.V]) < TOL
+    base = np.random.default_rng(94).standard_normal((orc.V, 4, 8))      # other monomials' forces already on the host
+    acc = base.copy()
+    lat.derivative(into=acc)
+    assert rel_err(acc, base + df[:orc.V]) < TOL
+    assert np.array_equal(dl.download(), l) and np.array_equal(dk.download(), k)   # inputs untouched
+    lat.derivative_zero()
+    assert not lat.derivative().any()
+    lat.close()
+
+
+def test_deriv_Sb_drop_in_symbol(host_stub):
+    """deriv_Sb under its reference name: host AoS spinors, hamiltonian_field_t by pointer, contribution ADDED to
+    hf->derivative (coherent mode) or held back until tmlqcd_hip_flush_derivative (resident mode)."""
+    from oracle.oraclebind import Oracle
+    stub, d = host_stub
+    VP = C.c_void_p
+    T, L = 4, 6
+    kappa, mu, theta = 0.127, 0.01, (1.0, 0.0, 0.0, 0.0)
+    V = T * L ** 3
+    N = V // 2
+    gptr = stub.stub_init(T, L, L, L)
+    g = random_gauge(95, V)
+    C.memmove(gptr, g.ctypes.data_as(VP), g.nbytes)
+    stub.stub_boundary(kappa, *theta)
+    stub.stub_set_mu(mu)
+    orc = Oracle(T, L, L, L, kappa=kappa, mu=mu, theta=theta, threads=4)
+    orc.set_gauge(g)
+
+    class HF(C.Structure):        # hamiltonian_field.h:26-32
+        _fields_ = [("gaugefield", VP), ("momenta", VP), ("derivative", VP), ("update_gauge_copy", C.c_int), ("traj_counter", C.c_int)]
+    df_host = np.random.default_rng(96).standard_normal((V, 4, 8))
+    start = df_host.copy()
+    rows = (VP * V)(*[df_host.ctypes.data + 4 * 8 * 8 * i for i in range(V)])      # su3adj **derivative
+    hf = HF(None, None, C.cast(rows, VP), 0, 0)
+    d.deriv_Sb.argtypes = [C.c_int, VP, VP, C.POINTER(HF), C.c_double]
+    d.deriv_Sb.restype = None
+    d.tmlqcd_hip_flush_derivative.argtypes = [C.POINTER(HF)]
+    d.tmlqcd_hip_set_residency.argtypes = [C.c_int]
+    l, k = random_spinor(97, N), random_spinor(98, N)
+    lo, ko = orc.new_field(), orc.new_field(); lo[:N] = l; ko[:N] = k
+    ref = np.zeros((orc.VPR, 4, 8))
+    d.deriv_Sb(1, l.ctypes.data_as(VP), k.ctypes.data_as(VP), C.byref(hf), 0.9)
+    orc.deriv_Sb(1, lo, ko, ref, 0.9)
+    assert rel_err(df_host, start + ref[:V]) < TOL
+    d.tmlqcd_hip_set_residency(1)
+    d.deriv_Sb(0, k.ctypes.data_as(VP), l.ctypes.data_as(VP), C.byref(hf), -0.4)
+    d.deriv_Sb(1, l.ctypes.data_as(VP), k.ctypes.data_as(VP), C.byref(hf), 0.2)
+    assert rel_err(df_host, start + ref[:V]) < TOL                      # nothing flushed yet
+    orc.deriv_Sb(0, ko, lo, ref, -0.4); orc.deriv_Sb(1, lo, ko, ref, 0.2)
+    d.tmlqcd_hip_flush_derivative(C.byref(hf))
+    assert rel_err(df_host, start + ref[:V]) < TOL
+    d.tmlqcd_hip_set_residency(0)
+    d.tmlqcd_hip_finalize()

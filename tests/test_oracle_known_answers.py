@@ -109,6 +109,19 @@ def test_golden_4x4_symmetric_preconditioning_family(gold4, name):
     assert np.array_equal(out[:o.Vh], g[name])
 
 
+def test_golden_4x4_fermion_force(gold4):
+    """deriv_Sb.c:401: two calls with swapped roles accumulated, as oracle/make_golden.py force made them."""
+    o, f, s = gold4
+    want = np.load(os.path.join(GOLD, "ref_force_4x4.npz"))["derivative"]
+    N = o.Vh
+    a, b = o.new_field(), o.new_field()
+    a[:N] = f["in"]; b[:N] = f["Heo"]
+    df = np.zeros((o.VPR, 4, 8))
+    o.deriv_Sb(1, a, b, df, 0.5)
+    o.deriv_Sb(0, b, a, df, -0.25)
+    assert np.array_equal(df[:o.V], want)
+
+
 def test_golden_4x4_M_full_and_D_psi(gold4):
     o, f, s = gold4
     N = o.Vh

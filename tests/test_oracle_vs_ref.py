@@ -72,6 +72,12 @@ Pc = o.new_field(); it, hist = o.cg_her(Pc, k.copy(), 500, 1e-18, 1, N)
 r.spinor(10)[:] = 0; lib.assign(sp(11), sp(0), N)
 it2 = lib.cg_her(sp(10), sp(11), 500, 1e-18, 1, N, r.fnptr("Qtm_pm_psi"))
 assert it == it2, (it, it2); same(Pc, 10, "cg solution")
+# fermion force, hopping part (deriv_Sb.c:401): both parities accumulated into one derivative field
+df = np.zeros((o.VPR, 4, 8))
+lsp, ksp = o.new_field(), o.new_field(); lsp[:N] = r.spinor(1, N); ksp[:N] = r.spinor(2, N)
+for ieo, fac in ((0, 0.7), (1, -1.3)):
+    r.deriv_Sb(ieo, 1, 2, fac); o.deriv_Sb(ieo, lsp, ksp, df, fac)
+assert np.array_equal(df[:V], r.derivative()) and np.abs(df).max() > 0, "deriv_Sb"
 # clover term and its inverse (operator/clover_term.c:88, operator/clover_invert.c:170): the reference's sw_term /
 # sw_invert(EE, mu) on its own gauge field vs the restatement, +mu and -mu sets
 sw_ref, swi_ref = r.clover(1.37, 0.02)

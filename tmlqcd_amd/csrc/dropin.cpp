@@ -648,6 +648,23 @@ int rg_mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params solve
   return iters;
 }
 
+// ------------------------------------------------------------------ fermion force
+static bool g_deriv_pending = false;
+/* deriv_Sb.c:401-700 */
+void deriv_Sb(const int ieo, spinor *const l, spinor *const k, hamiltonian_field_t *const hf, const double factor) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fl = in(c, l, TMHIP_FIELD_EO), *fk = in(c, k, TMHIP_FIELD_EO);
+  if (!g_deriv_pending) CK(tmhip_derivative_zero(c));
+  CK(tmhip_deriv_Sb(c, ieo, fl, fk, factor));
+  g_deriv_pending = true;
+  if (g_mode == TMLQCD_HIP_COHERENT) tmlqcd_hip_flush_derivative(hf);
+}
+void tmlqcd_hip_flush_derivative(hamiltonian_field_t *const hf) {
+  if (!g_deriv_pending) return;
+  CK(tmhip_derivative_download(ctx(), &hf->derivative[0][0], 1));
+  g_deriv_pending = false;
+}
+
 // ------------------------------------------------------------------ benchmark helper
 /* benchmark.c:291-300 with the three fields resident in HBM */
 double tmlqcd_hip_benchmark_loop(spinor *f0, spinor *f1, spinor *f2, int iters) {

@@ -91,6 +91,8 @@ struct tmhip_ctx {
   ncclComm_t comm; bool comm_ready; bool loopback; bool loopback_rccl;
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
   unsigned int *sync_flags; unsigned int hop_seq;  // [0] in-ready, [1] boundary-done, [2] timeout error
+  // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
+  double *deriv;
   // device-resident CG state (cg.hip)
   void *cg_state; double *cg_hist; int cg_hist_len;
   // options

@@ -81,6 +81,9 @@ def load_library():
         "tmhip_cg_her": [vp, vp, vp, i, d, i, i, i, C.POINTER(i), pd, i],
         "tmhip_set_clover": [vp, vp, vp],
         "tmhip_sw_term": [vp, vp, d, d],
+        "tmhip_derivative_zero": [vp],
+        "tmhip_deriv_Sb": [vp, i, vp, vp, d],
+        "tmhip_derivative_download": [vp, vp, i],
         "tmhip_sw_invert": [vp, i, d],
         "tmhip_get_clover": [vp, vp, vp],
         "tmhip_clover_inv": [vp, vp, i, d],
@@ -263,6 +266,23 @@ class Lattice:
         if sw.shape != (self.V, 3, 2, 3, 3, 2) or sw_inv.shape != (self.V, 4, 2, 3, 3, 2):
             raise TmHipError("clover arrays must be [V][3][2][3][3][2] and [V][4][2][3][3][2]")
         _ck(self.lib.tmhip_set_clover(self.h, _hp(sw), _hp(sw_inv)), "tmhip_set_clover")
+
+    # --- fermion force (deriv_Sb.h) ------------------------------------------
+    def derivative_zero(self):
+        _ck(self.lib.tmhip_derivative_zero(self.h), "tmhip_derivative_zero")
+
+    def deriv_Sb(self, ieo, l, k, factor):
+        """deriv_Sb.c:401: accumulate the hopping part of the fermion force into the device-resident derivative field."""
+        _ck(self.lib.tmhip_deriv_Sb(self.h, ieo, l.h, k.h, factor), "deriv_Sb")
+
+    def derivative(self, into=None):
+        """The accumulated derivative as su3adj df[V][4][8]; with `into`, added to that host array (accumulate)."""
+        if into is None:
+            out = np.zeros((self.V, 4, 8))
+            _ck(self.lib.tmhip_derivative_download(self.h, _hp(out), 0), "tmhip_derivative_download")
+            return out
+        _ck(self.lib.tmhip_derivative_download(self.h, _hp(into), 1), "tmhip_derivative_download")
+        return into
 
     def sw_term(self, gauge, kappa, c_sw):
         """operator/clover_term.c:88 on the device; `gauge` as for set_gauge ([VPR][4][3][3][2])."""
