@@ -210,8 +210,15 @@ int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_
 /* generic event slots (0..15) recorded on the context's compute stream */
 int tmhip_event_record(tmhip_ctx *ctx, int slot);
 int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double *ms);
-/* kernel variant selection for A/B measurements (0 = default). */
+/* kernel variant selection for A/B measurements (0 = default).  One option changes what is read from memory:
+ * "gauge_recon" = 12 makes the fp64 twisted-mass stencil launches fetch only the first two rows of every link and
+ * rebuild the third as conj(row0 x row1) in registers (the 12-real compression the reference exposes for its external
+ * inverters, misc_types.h:29-33 COMPRESSION_12) -- 25 % fewer bytes per site.  It is opt-in and guarded: the links
+ * of the resident gauge field must be SU(3) to 1e-13 (measured on the device at set_gauge / when the option is set),
+ * otherwise the option is refused with a message and the full 18-real read stays in force. */
 int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value);
+/* max |row2 - conj(row0 x row1)| over all links of the resident gauge field */
+int tmhip_gauge_su3_deviation(tmhip_ctx *ctx, double *maxdev);
 
 #ifdef __cplusplus
 }

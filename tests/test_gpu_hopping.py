@@ -138,3 +138,50 @@ def test_small_and_ragged_lattices(dims):
     assert rel_err(dl.download(), ref[:N]) < TOL
     assert abs(lat.square_norm(dl, N) - orc.square_norm(ref, N)) <= TOL * orc.square_norm(ref, N)
     lat.close()
+
+
+def test_gauge_recon_12_is_exact_for_su3_links_and_refused_otherwise(setup16):
+    """Opt-in 12-real gauge read (COMPRESSION_12 of misc_types.h:29-33): third row rebuilt in registers.  Same results
+    to TOL on SU(3) links -- plain stencil, all fused epilogues, Qtm_pm_psi, cg_her with the fused dot -- and the option
+    is refused (full read stays) when the resident links are not unitary to rounding."""
+    orc, lat = setup16
+    N = orc.Vh
+    assert lat.gauge_su3_deviation() < 1e-14
+    k, p = random_spinor(31, N), random_spinor(32, N)
+    dk, dp, dl = lat.field(k), lat.field(p), lat.field()
+    ref = orc.new_field()
+    lat.set_option("gauge_recon", 12)
+    try:
+        for ieo in (0, 1):
+            orc.Hopping_Matrix(ieo, ref, k); lat.Hopping_Matrix(ieo, dl, dk)
+            assert rel_err(dl.download(), ref[:N]) < TOL
+            c = -0.37 + 0.91j
+            orc.tm_times_Hopping_Matrix(ieo, ref, k, c); lat.tm_times_Hopping_Matrix(ieo, dl, dk, c)
+            assert rel_err(dl.download(), ref[:N]) < TOL
+            orc.tm_sub_Hopping_Matrix(ieo, ref, p, k, c); lat.tm_sub_Hopping_Matrix(ieo, dl, dp, dk, c)
+            assert rel_err(dl.download(), ref[:N]) < TOL
+        for name in ("Qtm_pm_psi", "Mtm_plus_psi"):
+            orc.op(name, ref, k.copy()); lat.op(name, dl, dk)
+            assert rel_err(dl.download(), ref[:N]) < TOL
+        P = orc.new_field(); it_ref, _ = orc.cg_her(P, k.copy(), 2000, 1e-18, 1, N)
+        dl.zero(); it, _ = lat.cg_her(dl, dk, 2000, 1e-18, 1, N)
+        assert abs(it - it_ref) <= 1 and rel_err(dl.download(), P[:N]) < 1e-8
+    finally:
+        lat.set_option("gauge_recon", 18)
+    # a field that is not SU(3): one link scaled by 1 + 1e-6
+    g = orc._gauge.copy()
+    g[7, 2] *= 1.0 + 1e-6
+    orc.set_gauge(g); lat.set_gauge(g)
+    try:
+        assert lat.gauge_su3_deviation() > 1e-7
+        lat.set_option("gauge_recon", 12)        # refused with a message on stderr: full 18-real read stays
+        orc.Hopping_Matrix(0, ref, k); lat.Hopping_Matrix(0, dl, dk)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+        orc.Hopping_Matrix(1, ref, k); lat.Hopping_Matrix(1, dl, dk)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+    finally:
+        lat.set_option("gauge_recon", 18)
+        g0 = random_gauge(11, orc.VPR)
+        orc.set_gauge(g0); lat.set_gauge(g0)
+    for f in (dk, dp, dl):
+        f.free()

@@ -74,6 +74,26 @@ __global__ __launch_bounds__(256) void gauge_sort_kernel(const v2d *__restrict__
   }
 }
 
+// max over all links of |row2 - conj(row0 x row1)|: how far the resident links are from exact SU(3).  Non-negative
+// doubles order like their bit patterns, so the maximum is an integer atomicMax.
+__global__ __launch_bounds__(256) void gauge_recon_dev_kernel(const v2d *__restrict__ g, int gs, int Vh, unsigned long long *out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double dev = 0.0;
+  if (i < Vh) {
+    const v2d *gp = g + (size_t)blockIdx.y * 9 * gs + i;    // blockIdx.y = parity * 8 + direction
+    v2d u[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) u[e] = gp[(size_t)e * gs];
+    auto cm = [](v2d a, v2d b) { return v2d{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; };
+    const v2d a0 = cm(u[1], u[5]) - cm(u[2], u[4]), a1 = cm(u[2], u[3]) - cm(u[0], u[5]), a2 = cm(u[0], u[4]) - cm(u[1], u[3]);
+    dev = fmax(fmax(fabs(u[6].x - a0.x), fabs(u[6].y + a0.y)), fmax(fmax(fabs(u[7].x - a1.x), fabs(u[7].y + a1.y)),
+                                                                    fmax(fabs(u[8].x - a2.x), fabs(u[8].y + a2.y))));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_xor(dev, off, 64));
+  if ((threadIdx.x & 63) == 0 && dev > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(dev));
+}
+
 // ------------------------------------------------------------------ helpers
 int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes) {
   if (ctx->stage_bytes >= bytes) return 0;
@@ -136,7 +156,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->V = g.T * g.LX * g.LY * g.LZ; ctx->Vh = ctx->V / 2; ctx->face = g.LX * g.LY * g.LZ / 2;
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
-  ctx->opt_block = 256; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_variant = 0; ctx->opt_cg_sync = 0; ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 1; ctx->opt_gaux = -1; ctx->opt_gdrop = 0; ctx->opt_fp32_pairs = 1;
+  ctx->opt_block = 256; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_variant = 0; ctx->opt_cg_sync = 0; ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 1; ctx->opt_gaux = -1; ctx->opt_gdrop = 0; ctx->opt_fp32_pairs = 1; ctx->opt_recon = 0; ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
     int lo = 0, hi = 0;
@@ -234,6 +254,16 @@ int tmhip_set_ka(tmhip_ctx *ctx, const double ka[8]) {
 
 int tmhip_set_mu(tmhip_ctx *ctx, double mu) { ctx->mu = mu; return 0; }
 
+int tmhip_gauge_su3_deviation(tmhip_ctx *ctx, double *maxdev) {
+  if (!ctx->gauge_set) TMHIP_FAIL("tmhip_gauge_su3_deviation called before tmhip_set_gauge");
+  const int saved = ctx->opt_recon;
+  ctx->opt_recon = 0;                       // measure only, do not toggle the option
+  if (tmhip_check_gauge_recon(ctx)) return 1;
+  ctx->opt_recon = saved;
+  *maxdev = ctx->gauge_recon_dev;
+  return 0;
+}
+
 int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "block")) { if (value != 64 && value != 256) TMHIP_FAIL("block must be 64 or 256"); ctx->opt_block = value; }
   else if (!strcmp(name, "minw")) ctx->opt_minw = value;
@@ -247,6 +277,11 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "fusedface")) ctx->opt_fusedface = value;
   else if (!strcmp(name, "gaux")) ctx->opt_gaux = value;
   else if (!strcmp(name, "gdrop")) ctx->opt_gdrop = value;
+  else if (!strcmp(name, "gauge_recon")) {
+    if (value != 12 && value != 18 && value != 0) TMHIP_FAIL("gauge_recon must be 12 or 18");
+    ctx->opt_recon = value == 12 ? 12 : 0;
+    if (ctx->opt_recon == 12) return tmhip_check_gauge_recon(ctx);
+  }
   else if (!strcmp(name, "fp32_pairs")) ctx->opt_fp32_pairs = value;
   else if (!strcmp(name, "shape")) ctx->opt_shape = value;
   else if (!strcmp(name, "cg_sync")) ctx->opt_cg_sync = value;
@@ -271,6 +306,30 @@ int tmhip_set_gauge(tmhip_ctx *ctx, const void *host) {
   TMHIP_CHECK(hipFree(raw));
   ctx->gauge_set = true;
   ctx->gauge32_set = false;  // the fp32 twin is rebuilt lazily from the new links
+  ctx->gauge_recon_dev = -1.0;
+  if (ctx->opt_recon == 12) return tmhip_check_gauge_recon(ctx);
+  return 0;
+}
+
+/* "gauge_recon" = 12 is only exact for SU(3) links: measure how far the resident links are from it and drop back to the
+ * full 18-real read (with a message) when they are not unitary to rounding, e.g. smeared or deliberately non-SU(3) input. */
+int tmhip_check_gauge_recon(tmhip_ctx *ctx) {
+  if (!ctx->gauge_set) return 0;     // checked again by tmhip_set_gauge
+  if (ctx->gauge_recon_dev < 0.0) {
+    unsigned long long *d = (unsigned long long *)ctx->result_dev;
+    TMHIP_CHECK(hipMemsetAsync(d, 0, sizeof(*d), ctx->stream));
+    hipLaunchKernelGGL(gauge_recon_dev_kernel, dim3((ctx->Vh + 255) / 256, 16), dim3(256), 0, ctx->stream, (const v2d *)ctx->gauge, ctx->gs, ctx->Vh, d);
+    TMHIP_CHECK(hipGetLastError());
+    unsigned long long h = 0;
+    TMHIP_CHECK(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(&ctx->gauge_recon_dev, &h, sizeof(double));
+  }
+  if (ctx->opt_recon == 12 && ctx->gauge_recon_dev > 1.0e-13) {
+    fprintf(stderr, "[tmlqcd_hip] gauge_recon=12 refused: links deviate from SU(3) by %.3e (> 1e-13); using the full 18-real read\n",
+            ctx->gauge_recon_dev);
+    ctx->opt_recon = 0;
+  }
   return 0;
 }
 

@@ -96,7 +96,8 @@ struct tmhip_ctx {
   // device-resident CG state (cg.hip)
   void *cg_state; double *cg_hist; int cg_hist_len;
   // options
-  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_variant; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface; int opt_gaux; int opt_gdrop; int opt_fp32_pairs;
+  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_variant; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface; int opt_gaux; int opt_gdrop; int opt_fp32_pairs; int opt_recon;   // opt_recon: 12 = rebuild the third row of every link in registers (opt-in)
+  double gauge_recon_dev;   // max |U_row2 - conj(row0 x row1)| over all links of the resident gauge field (-1: not measured)
 };
 
 // ---- launch helpers implemented across the .hip files ----
@@ -111,6 +112,7 @@ int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in,
                                double cre, double cim, int *npartials);
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx);
 int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out);
+extern "C" int tmhip_check_gauge_recon(tmhip_ctx *ctx);   // context.hip: unitarity guard of the gauge_recon=12 option
 int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes);
 int tmhip_field_alloc_prec(tmhip_ctx *ctx, int kind, int prec, tmhip_field **out);
 int tmhip_halo_exchange(tmhip_ctx *ctx);

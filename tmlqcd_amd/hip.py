@@ -81,6 +81,7 @@ def load_library():
         "tmhip_cg_her": [vp, vp, vp, i, d, i, i, i, C.POINTER(i), pd, i],
         "tmhip_set_clover": [vp, vp, vp],
         "tmhip_sw_term": [vp, vp, d, d],
+        "tmhip_gauge_su3_deviation": [vp, pd],
         "tmhip_derivative_zero": [vp],
         "tmhip_deriv_Sb": [vp, i, vp, vp, d],
         "tmhip_derivative_download": [vp, vp, i],
@@ -240,6 +241,12 @@ class Lattice:
 
     def set_option(self, name, value):
         _ck(self.lib.tmhip_set_option(self.h, name.encode(), int(value)), "tmhip_set_option")
+
+    def gauge_su3_deviation(self):
+        """max |row2 - conj(row0 x row1)| over the resident links (what the gauge_recon=12 guard looks at)."""
+        out = C.c_double()
+        _ck(self.lib.tmhip_gauge_su3_deviation(self.h, C.byref(out)), "tmhip_gauge_su3_deviation")
+        return out.value
 
     def sync(self):
         _ck(self.lib.tmhip_sync(self.h), "tmhip_sync")
