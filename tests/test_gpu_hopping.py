@@ -36,7 +36,7 @@ def test_hopping_matrix_16(setup16, ieo):
     dk.free(); dl.free()
 
 
-@pytest.mark.parametrize("block,nt,xcd,minw,occ", [(64, 0, 0, 0, 0), (64, 1, 2, 4, 2), (256, 1, 1, 0, 3), (256, 0, 2, 4, 0)])
+@pytest.mark.parametrize("block,nt,xcd,minw,occ", [(64, 0, 0, 0, 0), (64, 1, 2, 4, 2), (256, 1, 1, 0, 3), (256, 0, 2, 4, 0), (256, 1, 3, 0, 3), (64, 1, 3, 0, 0)])
 def test_kernel_variants_agree(setup16, block, nt, xcd, minw, occ):
     orc, lat = setup16
     N = orc.Vh
@@ -185,3 +185,37 @@ def test_gauge_recon_12_is_exact_for_su3_links_and_refused_otherwise(setup16):
         orc.set_gauge(g0); lat.set_gauge(g0)
     for f in (dk, dp, dl):
         f.free()
+
+
+def test_slab_block_order_with_uneven_slabs():
+    """xcd = 3 (XCD j owns the j-th eighth of every time-slice): 9 blocks per slice do not split into 8 equal slabs, so
+    the last slab is short and its spare block slots exit -- also in the fused stencil+dot launch of cg_her, whose
+    partial sums then include zero-filled slots."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T, LX, LY, LZ = 8, 12, 16, 24            # face = 2304 sites = 9 blocks of 256; 72 blocks per launch
+    kappa, mu, theta = 0.13, 0.02, (1.0, 0.0, 0.5, 0.0)
+    orc = Oracle(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta, threads=8)
+    lat = Lattice(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta)
+    g = random_gauge(41, orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    N = orc.Vh
+    k = random_spinor(42, N)
+    dk, dl = lat.field(k), lat.field()
+    ref = orc.new_field()
+    for xcd in (3, 2, 4, 1):
+        lat.set_option("xcd", xcd)
+        for ieo in (0, 1):
+            orc.Hopping_Matrix(ieo, ref, k); lat.Hopping_Matrix(ieo, dl, dk)
+            assert rel_err(dl.download(), ref[:N]) < TOL, (xcd, ieo)
+        orc.op("Qtm_pm_psi", ref, k.copy()); lat.op("Qtm_pm_psi", dl, dk)
+        assert rel_err(dl.download(), ref[:N]) < TOL, xcd
+    lat.set_option("xcd", 3)
+    P = orc.new_field(); it_ref, _ = orc.cg_her(P, k.copy(), 2000, 1e-18, 1, N)
+    dl.zero(); it, _ = lat.cg_her(dl, dk, 2000, 1e-18, 1, N)
+    assert abs(it - it_ref) <= 1 and rel_err(dl.download(), P[:N]) < 1e-8
+    k32 = k.astype(np.float32)
+    d32, l32 = lat.field32(k32), lat.field32()
+    orc.Hopping_Matrix(1, ref, k32.astype(np.float64)); lat.Hopping_Matrix_32(1, l32, d32)     # 512-site blocks: 4.5 per slice -> tile order
+    assert rel_err(l32.download().astype(np.float64), ref[:N]) < 2e-6
+    lat.close()

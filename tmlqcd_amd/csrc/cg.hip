@@ -119,8 +119,7 @@ __global__ __launch_bounds__(256) void cg_sum_kernel(const double *__restrict__ 
 // WHICH 0: after the dot  -> alpha = normsq / pro            (cg_her.c:93-94)
 // WHICH 1: after |sf0|^2  -> stopping test, beta, normsq      (cg_her.c:101-126)
 template <int WHICH>
-__global__ void cg_scalar_kernel(CgState *st, const double *sum, double *hist, int hist_len) {
-  if (st->done) return;
+__device__ __forceinline__ void cg_scalar_update(CgState *st, const double *sum, double *hist, int hist_len) {
   if (WHICH == 0) {
     st->pro = *sum;
     if (st->inner == 2) st->alpha = (double)((float)st->normsq / (float)st->pro);   // float alpha, rg_mixed_cg_her.c:126
@@ -165,6 +164,32 @@ __global__ void cg_scalar_kernel(CgState *st, const double *sum, double *hist, i
       conv = ((err <= st->eps_sq) && (st->rel_prec == 0)) || ((err <= st->eps_sq * st->squarenorm) && (st->rel_prec == 1));
     if (conv) { st->done = 1; st->iters = st->it; }
     else { st->beta = err / st->normsq; st->normsq = err; }
+  }
+}
+
+template <int WHICH>
+__global__ void cg_scalar_kernel(CgState *st, const double *sum, double *hist, int hist_len) {
+  if (st->done) return;
+  cg_scalar_update<WHICH>(st, sum, hist, hist_len);
+}
+
+// single rank: the fixed-order sum of the partials and the scalar update in one launch (no all-reduce in between)
+template <int WHICH>
+__global__ __launch_bounds__(256) void cg_sum_scalar_kernel(const double *__restrict__ partials, int n, double *out, CgState *st, double *hist,
+                                                            int hist_len) {
+  if (st->done) return;
+  __shared__ double sm[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *out = sm[0];
+    cg_scalar_update<WHICH>(st, out, hist, hist_len);
   }
 }
 
@@ -215,6 +240,20 @@ static int cg_allreduce(tmhip_ctx *ctx, double *x) {
   return 0;
 }
 
+// partials -> (all-reduce over ranks) -> alpha (WHICH 0) or stopping test / beta (WHICH 1) in the device state
+template <int WHICH>
+static int cg_reduce_update(tmhip_ctx *ctx, int n, CgState *st, double *hist, int hist_len) {
+  double *sum = ctx->result_dev + 1;
+  if (ctx->comm_ready && ctx->g.nproc_t > 1) {
+    hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, n, sum, st);
+    if (cg_allreduce(ctx, sum)) return 1;
+    hipLaunchKernelGGL(cg_scalar_kernel<WHICH>, dim3(1), dim3(1), 0, ctx->stream, st, sum, hist, hist_len);
+  } else {
+    hipLaunchKernelGGL(cg_sum_scalar_kernel<WHICH>, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, n, sum, st, hist, hist_len);
+  }
+  return 0;
+}
+
 extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N,
                             int op, int *iters, double *res_hist, int hist_len) {
   if (!P || !Q || P->kind != TMHIP_FIELD_EO || Q->kind != TMHIP_FIELD_EO) TMHIP_FAIL("cg_her needs one-parity (EO) fields");
@@ -241,7 +280,6 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
   TMHIP_CHECK(hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
   const dim3 g = la_grid(N);
   const int nblk = g.x * g.y;
-  double *sum = ctx->result_dev + 1;
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
   const bool fused = ctx->opt_cg_fused_dot && op == TMHIP_OP_QTM_PM && ctx->g.nproc_t == 1 && !ctx->loopback && ctx->opt_block == 256 && ctx->Vh % 256 == 0;
   int enq = 0, done = 0;
@@ -262,13 +300,9 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
         if (tmhip_apply_op(ctx, op, sf0, sf2)) return 1;
         hipLaunchKernelGGL(cg_dot_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, sf2->d, sf0->d, sf2->ns, N, ctx->partials, st);
       }
-      hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ndot, sum, st);
-      if (cg_allreduce(ctx, sum)) return 1;
-      hipLaunchKernelGGL(cg_scalar_kernel<0>, dim3(1), dim3(1), 0, ctx->stream, st, sum, ctx->cg_hist, max_iter);
+      if (cg_reduce_update<0>(ctx, ndot, st, ctx->cg_hist, max_iter)) return 1;
       hipLaunchKernelGGL(cg_update_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, P->d, sf2->d, sf0->d, sf1->d, P->ns, N, ctx->partials, st);
-      hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblk, sum, st);
-      if (cg_allreduce(ctx, sum)) return 1;
-      hipLaunchKernelGGL(cg_scalar_kernel<1>, dim3(1), dim3(1), 0, ctx->stream, st, sum, ctx->cg_hist, max_iter);
+      if (cg_reduce_update<1>(ctx, nblk, st, ctx->cg_hist, max_iter)) return 1;
       hipLaunchKernelGGL(cg_xpay_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, sf2->d, sf0->d, sf2->ns, N, st);
       stmp = sf0; sf0 = sf1; sf1 = stmp;
     }
@@ -314,7 +348,6 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
   if (tmhip_field_zero(ctx, P)) return 1;
   const dim3 g = la_grid(N);
   const int nblk = g.x * g.y;
-  double *sum = ctx->result_dev + 1;
   int *flag = (int *)(ctx->result_host + 2);
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
   const bool fused = !clover && ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
@@ -349,14 +382,10 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
           hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, ctx->partials, st);
         }
         }
-        hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ndot, sum, st);
-        if (cg_allreduce(ctx, sum)) return 1;
-        hipLaunchKernelGGL(cg_scalar_kernel<0>, dim3(1), dim3(1), 0, ctx->stream, st, sum, (double *)nullptr, 0);
+        if (cg_reduce_update<0>(ctx, ndot, st, (double *)nullptr, 0)) return 1;
         hipLaunchKernelGGL(cg_update_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, x->d32, (const v2f *)sf2->d32, sf0->d32, (const v2f *)sf1->d32,
                            x->ns, N, ctx->partials, st);
-        hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblk, sum, st);
-        if (cg_allreduce(ctx, sum)) return 1;
-        hipLaunchKernelGGL(cg_scalar_kernel<1>, dim3(1), dim3(1), 0, ctx->stream, st, sum, (double *)nullptr, 0);
+        if (cg_reduce_update<1>(ctx, nblk, st, (double *)nullptr, 0)) return 1;
         hipLaunchKernelGGL(cg_xpay_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, st);
         stmp = sf0; sf0 = sf1; sf1 = stmp;
       }
@@ -395,7 +424,6 @@ struct RgFields { tmhip_field *x, *p, *q, *r; };
 static int rg_enqueue_iteration(tmhip_ctx *ctx, int op, bool fp32, bool fused, RgFields &f, CgState *st, int N) {
   const dim3 g = la_grid(N);
   const int nblk = g.x * g.y;
-  double *sum = ctx->result_dev + 1;
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   int ndot = nblk;
   if (fp32) {
@@ -418,18 +446,14 @@ static int rg_enqueue_iteration(tmhip_ctx *ctx, int op, bool fp32, bool fused, R
     if (tmhip_apply_op(ctx, op, f.q, f.p)) return 1;
     hipLaunchKernelGGL(cg_dot_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, f.p->d, f.q->d, f.p->ns, N, ctx->partials, st);
   }
-  hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ndot, sum, st);
-  if (cg_allreduce(ctx, sum)) return 1;
-  hipLaunchKernelGGL(cg_scalar_kernel<0>, dim3(1), dim3(1), 0, ctx->stream, st, sum, (double *)nullptr, 0);
+  if (cg_reduce_update<0>(ctx, ndot, st, (double *)nullptr, 0)) return 1;
   if (fp32)
     hipLaunchKernelGGL(cg_update_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, f.x->d32, (const v2f *)f.p->d32, f.q->d32, (const v2f *)f.r->d32,
                        f.x->ns, N, ctx->partials, st);
   else
     hipLaunchKernelGGL(cg_update_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, f.x->d, (const v2d *)f.p->d, f.q->d, (const v2d *)f.r->d, f.x->ns, N,
                        ctx->partials, st);
-  hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblk, sum, st);
-  if (cg_allreduce(ctx, sum)) return 1;
-  hipLaunchKernelGGL(cg_scalar_kernel<1>, dim3(1), dim3(1), 0, ctx->stream, st, sum, (double *)nullptr, 0);
+  if (cg_reduce_update<1>(ctx, nblk, st, (double *)nullptr, 0)) return 1;
   if (fp32)
     hipLaunchKernelGGL(cg_xpay_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, f.p->d32, (const v2f *)f.q->d32, f.p->ns, N, st);
   else

@@ -168,7 +168,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   for (int i = 0; i < 16; i++) TMHIP_CHECK(hipEventCreate(&ctx->ev_slots[i]));
   TMHIP_CHECK(hipMalloc((void **)&ctx->gauge, (size_t)2 * 72 * ctx->gs * sizeof(v2d)));
   ctx->max_partials = 12 * ((ctx->ns + 1023) / 1024 + 1);
-  if (ctx->max_partials < (ctx->ns + 255) / 256 + 8) ctx->max_partials = (ctx->ns + 255) / 256 + 8;  // fused stencil+dot: one per block
+  if (ctx->max_partials < (ctx->ns + 255) / 256 + 8 + 7 * ctx->g.T) ctx->max_partials = (ctx->ns + 255) / 256 + 8 + 7 * ctx->g.T;  // fused stencil+dot: one per block of the (padded) grid
   TMHIP_CHECK(hipMalloc((void **)&ctx->partials, ctx->max_partials * sizeof(double)));
   TMHIP_CHECK(hipMalloc((void **)&ctx->result_dev, 4 * sizeof(double)));
   TMHIP_CHECK(hipHostMalloc((void **)&ctx->result_host, 4 * sizeof(double)));
