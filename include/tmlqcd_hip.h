@@ -137,10 +137,12 @@ int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, d
  * deriv_Sb(ieo, l, k, hf, factor) accumulates 2 factor trlambda(...) of the one-hop terms into hf->derivative.  Here the
  * accumulator is device-resident: zero it, call tmhip_deriv_Sb any number of times (one call per deriv_Sb call of the
  * reference, same ieo / l / k / factor), then fetch it in the host layout su3adj df[VOLUME][4] (8 doubles per link,
- * lexicographic sites), either overwriting or adding to the host array.  Single-rank lattices for now. */
+ * lexicographic sites), either overwriting or adding to the host array.  T-split ranks exchange the t=0 slices of both fields with the ring
+ * neighbour first (xchange_2fields, deriv_Sb.c:102); tmhip_multi_deriv_Sb is the single-process ring of n contexts. */
 int tmhip_derivative_zero(tmhip_ctx *ctx);
 int tmhip_deriv_Sb(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, double factor);
 int tmhip_derivative_download(tmhip_ctx *ctx, void *df, int accumulate);
+int tmhip_multi_deriv_Sb(int n, tmhip_ctx **ctxs, int ieo, tmhip_field **l, tmhip_field **k, double factor);
 
 /* ---- clover twisted mass (invert_clover_eo.c:63-165) ------
  * The 6x6 site blocks are inputs like the gauge field: `sw` = su3 sw[VOLUME][3][2] from sw_term

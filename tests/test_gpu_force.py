@@ -59,6 +59,51 @@ def test_deriv_Sb_against_oracle(dims):
     lat.close()
 
 
+def test_deriv_Sb_split_path_loopback_and_two_t_slabs():
+    """T-split ranks: the +t neighbours of the last time-slice come from the exchanged t=0 slices of BOTH fields
+    (xchange_2fields, deriv_Sb.c:102).  (1) one rank with the exchange looped back onto itself, (2) two contexts holding
+    the two halves of the lattice (halo gauge links, global parity offset, peer copies) == the unsplit lattice."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    from tmlqcd_amd.hip import multi_deriv_Sb
+    T, L, world = 2, 4, 2
+    Tg = T * world
+    kappa, mu, theta = 0.13, 0.02, (1.0, 0.25, 0.0, 0.5)
+    g = Oracle(Tg, L, L, L, kappa=kappa, mu=mu, theta=theta, threads=4)
+    g.set_gauge(syn.gauge_field(6, Tg, L, L, L))
+    Ng = g.Vh
+    lg, kg = g.new_field(), g.new_field()
+    # l lives on parity ieo, k on the other one; use ieo = 1 then 0 with the roles swapped, like det_derivative
+    lg[:Ng] = syn.spinor_field_eo(7, 1, Tg, L, L, L); kg[:Ng] = syn.spinor_field_eo(8, 0, Tg, L, L, L)
+    ref = np.zeros((g.VPR, 4, 8))
+    g.deriv_Sb(1, lg, kg, ref, 0.6)
+    g.deriv_Sb(0, kg, lg, ref, -0.3)
+    # (1) loopback on the unsplit lattice
+    one = Lattice(Tg, L, L, L, kappa=kappa, mu=mu, theta=theta)
+    one.set_gauge(syn.gauge_field(6, Tg, L, L, L))
+    dl, dk = one.field(np.ascontiguousarray(lg[:Ng])), one.field(np.ascontiguousarray(kg[:Ng]))
+    one.set_loopback(1)
+    one.derivative_zero()
+    one.deriv_Sb(1, dl, dk, 0.6); one.deriv_Sb(0, dk, dl, -0.3)
+    one.set_loopback(0)
+    assert rel_err(one.derivative(), ref[:g.V]) < TOL
+    one.close()
+    # (2) two T-slabs
+    lats = [Lattice(T, L, L, L, kappa=kappa, mu=mu, theta=theta, nproc_t=world, proc_t=r) for r in range(world)]
+    for r, lat in enumerate(lats):
+        lat.set_gauge(syn.gauge_field(6, T, L, L, L, world, r))
+        lat.derivative_zero()
+    ls = [lat.field(syn.spinor_field_eo(7, 1, T, L, L, L, world, r)) for r, lat in enumerate(lats)]
+    ks = [lat.field(syn.spinor_field_eo(8, 0, T, L, L, L, world, r)) for r, lat in enumerate(lats)]
+    multi_deriv_Sb(lats, 1, ls, ks, 0.6)
+    multi_deriv_Sb(lats, 0, ks, ls, -0.3)
+    V = lats[0].V
+    for r, lat in enumerate(lats):
+        assert rel_err(lat.derivative(), ref[r * V:(r + 1) * V]) < TOL, r
+        lat.close()
+
+
 def test_deriv_Sb_drop_in_symbol(host_stub):
     """deriv_Sb under its reference name: host AoS spinors, hamiltonian_field_t by pointer, contribution ADDED to
     hf->derivative (coherent mode) or held back until tmlqcd_hip_flush_derivative (resident mode)."""

@@ -208,6 +208,8 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->sw_inv32) (void)hipFree(ctx->sw_inv32);
   if (ctx->sw_fail) (void)hipFree(ctx->sw_fail);
   if (ctx->deriv) (void)hipFree(ctx->deriv);
+  if (ctx->force_send) (void)hipFree(ctx->force_send);
+  if (ctx->force_recv) (void)hipFree(ctx->force_recv);
   if (ctx->comm_ready) ncclCommDestroy(ctx->comm);
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);

@@ -480,6 +480,35 @@ void Q_pm_psi(spinor *const l, spinor *const k) {
   g5_full(c, fl, fl);
   done(c, l);
 }
+/* tm_operators.c:453-461 : Q_pm_psi with the first twist scaled by 10 (mu -> -10 mu, then +mu) */
+void Q_pm_psi2(spinor *const l, spinor *const k) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL), *tmp = full_tmp(c);
+  CK(tmhip_set_mu(c, -10. * g_mu)); CK(tmhip_D_psi(c, fl, fk));
+  g5_full(c, tmp, fl);
+  CK(tmhip_set_mu(c, g_mu)); CK(tmhip_D_psi(c, fl, tmp));
+  g5_full(c, fl, fl);
+  done(c, l);
+}
+/* tm_operators.c:440-449 : "version for the gpu", gamma5 applied to the INPUT in place first, none at the end */
+void Q_pm_psi_gpu(spinor *const l, spinor *const k) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL), *tmp = full_tmp(c);
+  g5_full(c, fk, fk);
+  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, fl, fk));
+  g5_full(c, tmp, fl);
+  CK(tmhip_set_mu(c, g_mu)); CK(tmhip_D_psi(c, fl, tmp));
+  done(c, k); done(c, l);
+}
+/* tm_operators.c:476-483 */
+void Q_minus_psi_gpu(spinor *const l, spinor *const k) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL);
+  g5_full(c, fk, fk);
+  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, fl, fk)); CK(tmhip_set_mu(c, g_mu));
+  g5_full(c, fl, fl);
+  done(c, k); done(c, l);
+}
 /* tm_operators.c:390-397 */
 void D_dagg_psi(spinor *const l, spinor *const k) {
   tmhip_ctx *c = refresh(true);

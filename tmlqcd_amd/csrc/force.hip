@@ -18,6 +18,9 @@ struct ForceArgs {
   const v2d *g;           // gauge [2][8][9][gs]
   double *deriv;          // [2][4][8][Vh]
   int ns, gs, Vh, T, LX, LY, LZ, ieo;
+  int toff;               // proc_t * T: global parity offset of a T-split rank
+  const v2d *halo;        // T-split: [24][face] = t=0 slices of the up-neighbour's l (components 0..11) and k (12..23)
+  int face;
   double ka[4][2];
   double fac;             // 2 * factor
 };
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(128) void deriv_Sb_kernel(ForceArgs a) {
   const int y = r % a.LY;
   r /= a.LY;
   const int x = r % a.LX, t = r / a.LX;
-  const int o = (t + x + y + par) & 1;
+  const int o = (t + x + y + par + a.toff) & 1;
   const int z = 2 * kz + o;
   const int row = (t * a.LX + x) * a.LY + y;   // lexic = row * LZ + z
   int up[4];
@@ -78,7 +81,10 @@ __global__ __launch_bounds__(128) void deriv_Sb_kernel(ForceArgs a) {
 #pragma unroll
   for (int mu = 0; mu < 4; mu++) {
     v2d nb[4][3];
-    f_load(a.own[1 - par], a.ns, up[mu], !plus, nb);
+    if (mu == 0 && a.halo && t == a.T - 1)   // +t neighbour lives on the next rank: its t=0 slice was exchanged (xchange_2fields, deriv_Sb.c:102)
+      f_load(a.halo + (size_t)(plus ? 12 : 0) * a.face, a.face, i - (a.T - 1) * a.face, !plus, nb);
+    else
+      f_load(a.own[1 - par], a.ns, up[mu], !plus, nb);
     v2d phia[3], phib[3], psia[3], psib[3];
     // phi* <- projections of g5 l, psi* <- projections of k
     if (plus) { f_project(own, mu, true, phia, phib); f_project(nb, mu, true, psia, psib); }
@@ -121,7 +127,15 @@ __global__ __launch_bounds__(128) void deriv_Sb_kernel(ForceArgs a) {
 }
 
 // deriv[par][mu][8][Vh] -> su3adj df[V][4] (lexicographic)
-__global__ __launch_bounds__(256) void deriv_to_lexic_kernel(const double *__restrict__ d, double *__restrict__ out, int Vh, int LX, int LY, int LZ) {
+// t=0 slices of l and k -> [24][face] send buffer (full spinors: the force needs all four spin components)
+__global__ __launch_bounds__(256) void force_pack_kernel(const v2d *__restrict__ l, const v2d *__restrict__ k, int ns, int face, v2d *__restrict__ send) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= face) return;
+  const int c = blockIdx.y;                       // 0..23
+  send[(size_t)c * face + j] = c < 12 ? l[(size_t)c * ns + j] : k[(size_t)(c - 12) * ns + j];
+}
+
+__global__ __launch_bounds__(256) void deriv_to_lexic_kernel(const double *__restrict__ d, double *__restrict__ out, int Vh, int LX, int LY, int LZ, int toff) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= Vh) return;
   const int par = blockIdx.y;
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(256) void deriv_to_lexic_kernel(const double *__res
   const int y = r % LY;
   r /= LY;
   const int x = r % LX, t = r / LX;
-  const int o = (t + x + y + par) & 1;
+  const int o = (t + x + y + par + toff) & 1;
   double *dst = out + (2 * (size_t)i + o) * 32;
   const double *src = d + (size_t)par * 32 * Vh + i;
 #pragma unroll 8
@@ -147,21 +161,80 @@ int tmhip_derivative_zero(tmhip_ctx *ctx) {
   return 0;
 }
 
-/* deriv_Sb(ieo, l, k, hf, factor)  deriv_Sb.c:401 -- accumulates into the device-resident derivative field */
-int tmhip_deriv_Sb(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, double factor) {
+static int force_check(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
   if (!l || !k || l->kind != TMHIP_FIELD_EO || k->kind != TMHIP_FIELD_EO || l->prec || k->prec) TMHIP_FAIL("deriv_Sb needs fp64 one-parity fields");
-  if (ctx->g.nproc_t > 1) TMHIP_FAIL("deriv_Sb: T-split ranks need the full-spinor halo of xchange_2fields (deriv_Sb.c:102), not built yet");
   if (!ctx->gauge_set) TMHIP_FAIL("deriv_Sb called before tmhip_set_gauge");
+  if (l->ns != k->ns) TMHIP_FAIL("deriv_Sb: fields with different strides");
   if (!ctx->deriv && tmhip_derivative_zero(ctx)) return 1;
+  return 0;
+}
+static int force_halo_alloc(tmhip_ctx *ctx) {
+  const size_t bytes = (size_t)24 * ctx->face * sizeof(v2d);
+  if (!ctx->force_send) TMHIP_CHECK(hipMalloc((void **)&ctx->force_send, bytes));
+  if (!ctx->force_recv) TMHIP_CHECK(hipMalloc((void **)&ctx->force_recv, bytes));
+  return 0;
+}
+static int force_pack(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  hipLaunchKernelGGL(force_pack_kernel, dim3((ctx->face + 255) / 256, 24), dim3(256), 0, ctx->stream, (const v2d *)l->d, (const v2d *)k->d, l->ns,
+                     ctx->face, ctx->force_send);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+static int force_launch(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, double factor, const v2d *halo) {
   ForceArgs a;
+  memset(&a, 0, sizeof(a));
   a.own[ieo ? 1 : 0] = l->d; a.own[ieo ? 0 : 1] = k->d;
   a.g = ctx->gauge; a.deriv = ctx->deriv;
   a.ns = l->ns; a.gs = ctx->gs; a.Vh = ctx->Vh; a.T = ctx->g.T; a.LX = ctx->g.LX; a.LY = ctx->g.LY; a.LZ = ctx->g.LZ; a.ieo = ieo ? 1 : 0;
+  a.toff = ctx->g.proc_t * ctx->g.T; a.halo = halo; a.face = ctx->face;
   for (int mu = 0; mu < 4; mu++) { a.ka[mu][0] = ctx->ka[mu][0]; a.ka[mu][1] = ctx->ka[mu][1]; }
   a.fac = 2. * factor;
-  if (l->ns != k->ns) TMHIP_FAIL("deriv_Sb: fields with different strides");
   hipLaunchKernelGGL(deriv_Sb_kernel, dim3((ctx->Vh + 127) / 128, 2), dim3(128), 0, ctx->stream, a);
   TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* deriv_Sb(ieo, l, k, hf, factor)  deriv_Sb.c:401 -- accumulates into the device-resident derivative field.
+ * T-split ranks first exchange the t=0 slices of both fields with the ring neighbours (the reference's xchange_2fields,
+ * deriv_Sb.c:102; only the +t halo is needed here because every thread looks forward): RCCL send to rank-1 / receive
+ * from rank+1 on the compute stream.  The force is not latency-critical, so no overlap is attempted. */
+int tmhip_deriv_Sb(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, double factor) {
+  if (force_check(ctx, l, k)) return 1;
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  if (ctx->g.nproc_t == 1 && !ctx->loopback) return force_launch(ctx, ieo, l, k, factor, nullptr);
+  if (force_halo_alloc(ctx) || force_pack(ctx, l, k)) return 1;
+  const size_t n = (size_t)24 * ctx->face * 2;   // doubles
+  if (ctx->g.nproc_t == 1) {                      // loopback self-test: our own t=0 slice is the periodic +t neighbour
+    TMHIP_CHECK(hipMemcpyAsync(ctx->force_recv, ctx->force_send, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    if (!ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
+    const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
+    TMHIP_NCCL_CHECK(ncclGroupStart());
+    TMHIP_NCCL_CHECK(ncclSend(ctx->force_send, n, ncclDouble, dn, ctx->comm, ctx->stream));
+    TMHIP_NCCL_CHECK(ncclRecv(ctx->force_recv, n, ncclDouble, up, ctx->comm, ctx->stream));
+    TMHIP_NCCL_CHECK(ncclGroupEnd());
+  }
+  return force_launch(ctx, ieo, l, k, factor, ctx->force_recv);
+}
+
+/* Single-process ring (n contexts holding a T-split lattice, as tmhip_multi_hopping_matrix): slices move by peer copies. */
+int tmhip_multi_deriv_Sb(int n, tmhip_ctx **ctxs, int ieo, tmhip_field **l, tmhip_field **k, double factor) {
+  if (n < 2) TMHIP_FAIL("tmhip_multi_deriv_Sb needs >= 2 contexts");
+  for (int r = 0; r < n; r++) {
+    tmhip_ctx *c = ctxs[r];
+    if (c->g.nproc_t != n || c->g.proc_t != r) TMHIP_FAIL("context %d is not rank %d of a %d-way T split", r, r, n);
+    TMHIP_CHECK(hipSetDevice(c->device));
+    if (force_check(c, l[r], k[r]) || force_halo_alloc(c) || force_pack(c, l[r], k[r])) return 1;
+  }
+  for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
+  const size_t bytes = (size_t)24 * ctxs[0]->face * sizeof(v2d);
+  for (int r = 0; r < n; r++) {
+    tmhip_ctx *c = ctxs[r], *up = ctxs[(r + 1) % n];
+    TMHIP_CHECK(hipSetDevice(c->device));
+    TMHIP_CHECK(hipMemcpyPeerAsync(c->force_recv, c->device, up->force_send, up->device, bytes, c->stream));
+    if (force_launch(c, ieo, l[r], k[r], factor, c->force_recv)) return 1;
+  }
+  for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
   return 0;
 }
 
@@ -174,7 +247,7 @@ int tmhip_derivative_download(tmhip_ctx *ctx, void *host_df, int accumulate) {
   const size_t n = (size_t)ctx->V * 32, bytes = n * sizeof(double);
   if (tmhip_stage_reserve(ctx, bytes)) return 1;
   hipLaunchKernelGGL(deriv_to_lexic_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (const double *)ctx->deriv,
-                     (double *)ctx->stage, ctx->Vh, ctx->g.LX, ctx->g.LY, ctx->g.LZ);
+                     (double *)ctx->stage, ctx->Vh, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.proc_t * ctx->g.T);
   TMHIP_CHECK(hipGetLastError());
   if (!accumulate) {
     TMHIP_CHECK(hipMemcpyAsync(host_df, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));

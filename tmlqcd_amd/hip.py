@@ -85,6 +85,7 @@ def load_library():
         "tmhip_derivative_zero": [vp],
         "tmhip_deriv_Sb": [vp, i, vp, vp, d],
         "tmhip_derivative_download": [vp, vp, i],
+        "tmhip_multi_deriv_Sb": [i, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), d],
         "tmhip_sw_invert": [vp, i, d],
         "tmhip_get_clover": [vp, vp, vp],
         "tmhip_clover_inv": [vp, vp, i, d],
@@ -493,3 +494,11 @@ def multi_Hopping_Matrix(lats, ieo, ls, ks):
     arr = C.c_void_p * n
     _ck(lats[0].lib.tmhip_multi_hopping_matrix(n, arr(*[l.h for l in lats]), ieo, arr(*[f.h for f in ls]),
                                                arr(*[f.h for f in ks])), "tmhip_multi_hopping_matrix")
+
+
+def multi_deriv_Sb(lats, ieo, ls, ks, factor):
+    """deriv_Sb on a T-split lattice held by several contexts of THIS process (peer-copy ring)."""
+    n = len(lats)
+    arr = C.c_void_p * n
+    _ck(lats[0].lib.tmhip_multi_deriv_Sb(n, arr(*[l.h for l in lats]), ieo, arr(*[f.h for f in ls]), arr(*[f.h for f in ks]),
+                                         factor), "tmhip_multi_deriv_Sb")
