@@ -219,7 +219,13 @@ def main():
             tt = torch.tensor([dt12, ev12], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt12, ev12 = float(tt[0]), float(tt[1])
-        recon = {"value": world * 1608.0 / (1e6 * dt12 / (args.steps * V)), "unit": "Mflop/s",
+        P.zero()
+        lat.sync()
+        t4 = time.perf_counter()
+        lat.cg_her(P, Q, args.cg_iters, 0.0, 1, lat.Vh)
+        lat.sync()
+        cg12 = args.cg_iters / (time.perf_counter() - t4)
+        recon = {"value": world * 1608.0 / (1e6 * dt12 / (args.steps * V)), "unit": "Mflop/s", "cg_iters_per_s": cg12,
                  "us_per_launch": 1e3 * ev12 / (2 * args.steps), "alg_bytes_per_site": 1152,
                  "achieved_GBps": 1152.0 * (V // 2) / (ev12 * 1e-3 / (2 * args.steps)) / 1e9,
                  "note": "opt-in tmhip_set_option(gauge_recon, 12); COMPRESSION_12 of misc_types.h:29-33"}
