@@ -28,11 +28,13 @@ def setup():
     lat.close()
 
 
-@pytest.mark.parametrize("pairs", [1, 0])
-def test_fp32_stencil_and_operator(setup, pairs):
-    """pairs=1: two sites per thread (16-byte accesses, LZ % 4 == 0); pairs=0: one site per thread."""
+@pytest.mark.parametrize("pairs,recon", [(1, 18), (0, 18), (1, 12), (0, 12)])
+def test_fp32_stencil_and_operator(setup, pairs, recon):
+    """pairs=1: two sites per thread (16-byte accesses, LZ % 4 == 0); pairs=0: one site per thread.
+    recon=12: the opt-in 12-real gauge read (third row rebuilt in fp32 registers)."""
     orc, lat = setup
     lat.set_option("fp32_pairs", pairs)
+    lat.set_option("gauge_recon", recon)
     N = orc.Vh
     k32 = random_spinor(1, N).astype(np.float32)
     k = k32.astype(np.float64)
@@ -51,7 +53,16 @@ def test_fp32_stencil_and_operator(setup, pairs):
         lat.Hopping_Matrix_32(ieo, dl, dk)
         assert rel(dl.download().astype(np.float64), ref[:N]) < TOL32
     lat.set_loopback(0)
-    lat.set_option("fp32_pairs", 1)
+    if recon == 12:                                       # and the mixed solver on top of it
+        q = random_spinor(2, N)
+        dq, dp = lat.field(q), lat.field()
+        it, outer = lat.mixed_cg_her(dp, dq, 5000, 1e-20, 1, N)
+        full = orc.new_field(); full[:N] = dp.download()
+        chk = orc.new_field(); orc.op("Qtm_pm_psi", chk, full)
+        assert it > 0 and ((chk[:N] - q) ** 2).sum() / (q ** 2).sum() <= 1e-20
+        dq.free(); dp.free()
+    lat.set_option("gauge_recon", 18)
+    lat.set_option("fp32_pairs", 0)                      # back to the default (one site per thread)
     dk.free(); dl.free()
 
 

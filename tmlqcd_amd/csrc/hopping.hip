@@ -38,7 +38,9 @@ TMHIP_SCALAR_COMPLEX_OPS(v2d, double)
 #define HOP_SITES 1
 #define HOP_CTX_GAUGE(ctx) ((ctx)->gauge)
 #define HOP_CTX_GAUGE_READY(ctx) ((ctx)->gauge_set)
+#define HOP_CTX_OCC(ctx) ((ctx)->opt_occ)
 #include "hopping_impl.inc"
+#undef HOP_CTX_OCC
 #undef HOP_CTX_GAUGE
 #undef HOP_CTX_GAUGE_READY
 #undef HOP_SITES
@@ -46,6 +48,7 @@ TMHIP_SCALAR_COMPLEX_OPS(v2d, double)
 
 #define HOP_CTX_GAUGE(ctx) ((ctx)->gauge32)
 #define HOP_CTX_GAUGE_READY(ctx) ((ctx)->gauge32_set)
+#define HOP_CTX_OCC(ctx) ((ctx)->opt_occ32)
 namespace hop32 {
 TMHIP_SCALAR_COMPLEX_OPS(v2f, float)
 #define HOP_SITES 1
@@ -88,6 +91,7 @@ __device__ __forceinline__ double cdotd(V2T w, V2T r) {
 #include "hopping_impl.inc"
 #undef HOP_SITES
 }  // namespace hop32p
+#undef HOP_CTX_OCC
 #undef HOP_CTX_GAUGE
 #undef HOP_CTX_GAUGE_READY
 

@@ -18,7 +18,10 @@ sw, swi = syn.clover_blocks(3, L, L, L, L, 0.01)
 lat.set_clover(sw, swi)
 del sw, swi
 iters = 20
-for rnd in range(3):
+for rnd in range(4):
+    lat.set_option("gauge_recon", 12 if rnd == 3 else 18)
+    if rnd == 3:
+        print("-- gauge_recon = 12 (clover launches keep the full read)", flush=True)
     for name, fn in (("Qtm_pm_psi    fp64", lambda: lat.Qtm_pm_psi(l64, k64)), ("Qtm_pm_psi_32 fp32", lambda: lat.Qtm_pm_psi_32(l32, k32)),
                      ("Qsw_pm_psi    fp64", lambda: lat.op("Qsw_pm_psi", l64, k64)), ("Qsw_pm_psi_32 fp32", lambda: lat.Qsw_pm_psi_32(l32, k32)),
                      ("Hopping_Matrix    fp64", lambda: lat.Hopping_Matrix(1, l64, k64)), ("Hopping_Matrix_32 fp32", lambda: lat.Hopping_Matrix_32(1, l32, k32))):
