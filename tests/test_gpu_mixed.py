@@ -110,7 +110,7 @@ def test_fp32_linalg_and_conversions(setup):
         f.free()
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [2, 1, 0])
 def test_mixed_cg_her_reaches_fp64_residual(setup, fused):
     orc, lat = setup
     lat.set_option("cg_fused_dot", fused)
@@ -131,7 +131,7 @@ def test_mixed_cg_her_reaches_fp64_residual(setup, fused):
     # same right-hand side through the fp64 solver on the GPU for reference
     dp2 = lat.field(); it_gpu, _ = lat.cg_her(dp2, dq, 5000, eps_sq, 1, N)
     assert rel(sol, dp2.download()) < 1e-8
-    lat.set_option("cg_fused_dot", 1)
+    lat.set_option("cg_fused_dot", 2)
     for f in (dq, dp, dp2):
         f.free()
 

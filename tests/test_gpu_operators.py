@@ -207,10 +207,11 @@ def test_cg_her_matches_oracle(setup, cg_sync, batch):
     dq.free(); dp.free()
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [2, 1, 0])
 def test_cg_fused_scalar_product_path(fused):
-    """V/2 % 256 == 0 (8^4): cg_her fuses scalar_prod_r into the last stencil of Qtm_pm_psi; same iterations,
-    same solution as the unfused path and as the oracle."""
+    """V/2 % 256 == 0 (8^4).  2 (default): pro = |Q_- p|^2 from the second stencil, r -= alpha A p and |r|^2 in the
+    epilogue of the fourth, one pass for (P, p); 1: scalar_prod_r fused into the last stencil only; 0: separate linalg
+    kernels.  Same iterations, same residual history, same solution as the oracle for all three."""
     from oracle.oraclebind import Oracle
     from tmlqcd_amd import Lattice
     from tmlqcd_amd import synthetic as syn
@@ -230,6 +231,18 @@ def test_cg_fused_scalar_product_path(fused):
     m = min(len(hist), len(hist_ref)) - 1
     assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6)
     assert rel_err(dp.download(), P[:N]) < 1e-9
+    # a non-zero initial guess, an iteration cap that ends mid-batch and a second solve on the same context
+    x0 = 0.5 * P[:N] + 0.01 * syn.spinor_field_eo(23, 1, T, L, L, L)
+    Pr = orc.new_field(); Pr[:N] = x0
+    it_ref2, _ = orc.cg_her(Pr, q.copy(), 500, 1e-20, 1, N)
+    dp.upload(np.ascontiguousarray(x0))
+    it2, _ = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
+    assert abs(it2 - it_ref2) <= 1 and rel_err(dp.download(), Pr[:N]) < 1e-9
+    dp.zero()
+    it3, hist3 = lat.cg_her(dp, dq, 7, 1e-30, 1, N)
+    Pc = orc.new_field(); it_c, hist_c = orc.cg_her(Pc, q.copy(), 7, 1e-30, 1, N)
+    assert it3 == -1 and it_c == -1 and len(hist3) == 7
+    assert rel_err(dp.download(), Pc[:N]) < 1e-9          # P after exactly 7 updates, no extra / missing alpha p
     lat.close()
 
 

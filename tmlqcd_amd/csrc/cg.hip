@@ -17,6 +17,8 @@ struct CgState {
   // inner loops of rg_mixed_cg_her (rg_mixed_cg_her.c:74-176), inner = 2 (float scalars) / 3 (double scalars):
   // run while rho > delta * rhomax and iter_base + j <= max_total; leave early when 1.3 rho < eps_sq
   double delta, rhomax; int iter_base, max_total;
+  // fused Qtm_pm_psi iteration: alpha is known (and P += alpha p still owed) between the two scalar updates
+  int x_pending;
 };
 
 __device__ __forceinline__ double cg_wave_reduce(double v) {
@@ -101,6 +103,31 @@ __global__ __launch_bounds__(LA_BS) void cg_xpay_kernel(V2 *__restrict__ SF2, co
   }
 }
 
+// Fused-iteration tail: P += alpha p (cg_her.c:95, owed since alpha became known) and p = beta p + r (cg_her.c:122) in
+// one pass over p.  After convergence the direction update is skipped but the owed P update still happens -- exactly
+// once: the next alpha-kernel clears x_pending when it finds `done` set.
+template <class V2>
+__global__ __launch_bounds__(LA_BS) void cg_xp_kernel(V2 *__restrict__ X, V2 *__restrict__ Pd, const V2 *__restrict__ Rr, int ns, int N,
+                                                      const CgState *st) {
+  const bool upd_x = st->x_pending != 0, upd_p = !st->done;
+  if (!upd_x && !upd_p) return;
+  typedef decltype(V2{}.x) R;
+  const R alpha = (R)st->alpha, beta = (R)st->beta;
+  const size_t off = (size_t)blockIdx.y * ns;
+  V2 *x = X + off, *p = Pd + off;
+  const V2 *r = Rr + off;
+  const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < LA_UNROLL; u++) {
+    const int i = base + u * LA_BS;
+    if (i < N) {
+      const V2 pv = p[i];
+      if (upd_x) { const V2 a = x[i]; x[i] = V2{a.x + alpha * pv.x, a.y + alpha * pv.y}; }
+      if (upd_p) { const V2 b = r[i]; p[i] = V2{beta * pv.x + b.x, beta * pv.y + b.y}; }
+    }
+  }
+}
+
 // fixed-order sum of the per-block partials into *out (same scheme as linalg.hip)
 __global__ __launch_bounds__(256) void cg_sum_kernel(const double *__restrict__ partials, int n, double *out, const CgState *st) {
   if (st->done) return;
@@ -124,6 +151,7 @@ __device__ __forceinline__ void cg_scalar_update(CgState *st, const double *sum,
     st->pro = *sum;
     if (st->inner == 2) st->alpha = (double)((float)st->normsq / (float)st->pro);   // float alpha, rg_mixed_cg_her.c:126
     else st->alpha = st->normsq / st->pro;
+    st->x_pending = 1;
   } else if (st->inner >= 2) {
     st->it += 1;
     bool stop;
@@ -169,7 +197,7 @@ __device__ __forceinline__ void cg_scalar_update(CgState *st, const double *sum,
 
 template <int WHICH>
 __global__ void cg_scalar_kernel(CgState *st, const double *sum, double *hist, int hist_len) {
-  if (st->done) return;
+  if (st->done) { if (WHICH == 0) st->x_pending = 0; return; }
   cg_scalar_update<WHICH>(st, sum, hist, hist_len);
 }
 
@@ -177,7 +205,7 @@ __global__ void cg_scalar_kernel(CgState *st, const double *sum, double *hist, i
 template <int WHICH>
 __global__ __launch_bounds__(256) void cg_sum_scalar_kernel(const double *__restrict__ partials, int n, double *out, CgState *st, double *hist,
                                                             int hist_len) {
-  if (st->done) return;
+  if (st->done) { if (WHICH == 0 && threadIdx.x == 0) st->x_pending = 0; return; }
   __shared__ double sm[256];
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
@@ -254,6 +282,43 @@ static int cg_reduce_update(tmhip_ctx *ctx, int n, CgState *st, double *hist, in
   return 0;
 }
 
+// One CG iteration on Qtm_pm_psi = Q_+ Q_- (tm_operators.c:338-345) with every vector operation except the final
+// (P, p) update riding in stencil epilogues (single rank, whole blocks):
+//   s1 = A_-^-1 H_eo p                         stencil 1
+//   s0 = Q_- p ,  pro = |s0|^2                 stencil 2 + norm      (<p, Q_+ Q_- p> = |Q_- p|^2 as Q_+ = Q_-^dagger)
+//   alpha = normsq / pro                       one small kernel
+//   s1 = A_+^-1 H_eo s0                        stencil 3
+//   r -= alpha Q_+ s0 ,  err = |r|^2           stencil 4 + residual update; A p itself is never written
+//   stopping test, beta, normsq                one small kernel
+//   P += alpha p ; p = beta p + r              one pass
+// i.e. cg_her.c:91-126 with 960 B/site of vector traffic next to the four stencils instead of 1728.
+static int cg_enqueue_fused_qtm(tmhip_ctx *ctx, bool fp32, tmhip_field *x, tmhip_field *p, tmhip_field *r, CgState *st, double *hist,
+                                int hist_len, int N) {
+  const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
+  const dim3 g = la_grid(N);
+  int n1 = 0, n2 = 0;
+  if (fp32) {
+    v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
+    if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, p->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
+    if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, s0, s1, p->d32, nullptr, 1., -mu, &n1, 1)) return 1;
+    if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
+    if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true)) return 1;
+    if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d32, &st->alpha)) return 1;
+    if (cg_reduce_update<1>(ctx, n2, st, hist, hist_len)) return 1;
+    hipLaunchKernelGGL(cg_xp_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, x->d32, p->d32, (const v2f *)r->d32, p->ns, N, st);
+  } else {
+    v2d *s0 = ctx->scratch[0]->d, *s1 = ctx->scratch[1]->d;
+    if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
+    if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 1., -mu, &n1, 1)) return 1;
+    if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
+    if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true)) return 1;
+    if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d, &st->alpha)) return 1;
+    if (cg_reduce_update<1>(ctx, n2, st, hist, hist_len)) return 1;
+    hipLaunchKernelGGL(cg_xp_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, x->d, p->d, (const v2d *)r->d, p->ns, N, st);
+  }
+  return 0;
+}
+
 extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N,
                             int op, int *iters, double *res_hist, int hist_len) {
   if (!P || !Q || P->kind != TMHIP_FIELD_EO || Q->kind != TMHIP_FIELD_EO) TMHIP_FAIL("cg_her needs one-parity (EO) fields");
@@ -288,6 +353,10 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
     const int nb = (max_iter - enq) < batch ? (max_iter - enq) : batch;
     for (int b = 0; b < nb; b++) {
       int ndot = nblk;
+      if (fused && ctx->opt_cg_fused_dot >= 2) {   // default: everything but the (P, p) update rides in stencil epilogues
+        if (cg_enqueue_fused_qtm(ctx, false, P, sf2, sf1, st, ctx->cg_hist, max_iter, N)) return 1;
+        continue;
+      }
       if (fused) {
         // Qtm_pm_psi (tm_operators.c:338-345) with pro = <sf2, Q sf2> accumulated by the last stencil's epilogue
         const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
@@ -368,6 +437,10 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
       for (int b = 0; b < batch; b++) {
         int ndot = nblk;
         v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
+        if (fused && ctx->opt_cg_fused_dot >= 2) {
+          if (cg_enqueue_fused_qtm(ctx, true, x, sf2, sf1, st, (double *)nullptr, 0, N)) return 1;
+          continue;
+        }
         if (clover) {
           if (tmhip_Qsw_pm_psi_32(ctx, sf0, sf2)) return 1;
           hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, ctx->partials, st);
@@ -426,6 +499,7 @@ static int rg_enqueue_iteration(tmhip_ctx *ctx, int op, bool fp32, bool fused, R
   const int nblk = g.x * g.y;
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   int ndot = nblk;
+  if (fp32 && fused && ctx->opt_cg_fused_dot >= 2) return cg_enqueue_fused_qtm(ctx, true, f.x, f.p, f.r, st, (double *)nullptr, 0, N);
   if (fp32) {
     if (op == TMHIP_OP_QSW_PM) {
       if (tmhip_Qsw_pm_psi_32(ctx, f.q, f.p)) return 1;
