@@ -203,3 +203,35 @@ def test_device_sw_term_on_t_split_ranks():
         sw2, swi2 = lat.get_clover()
         assert np.array_equal(sw2, sw_ref[r * V:(r + 1) * V]) and np.array_equal(swi2, swi)
         lat.close()
+
+
+@pytest.mark.parametrize("fused", [2, 0])
+def test_clover_cg_with_reductions_fused_into_the_stencils(fused):
+    """8^4 (V/2 % 256 == 0): cg_her on Qsw_pm_psi with pro = |Q_- p|^2 out of the second stencil's clover_gamma5 epilogue and
+    r -= alpha A p, |r|^2 out of the fourth (cg_fused_dot = 2, the default) == the plain path == the oracle; the fp32 inner
+    loops of mixed_cg_her / rg_mixed_cg_her take the same route."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T = L = 8
+    kappa, mu = 0.13, 0.02
+    orc = Oracle(T, L, L, L, kappa=kappa, mu=mu, threads=8)
+    lat = Lattice(T, L, L, L, kappa=kappa, mu=mu)
+    g = random_gauge(75, orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    sw = orc.sw_term(kappa, 1.3)
+    swi, _ = orc.sw_invert(sw, 0, mu)
+    orc.set_clover(sw, swi); lat.set_clover(sw, swi)
+    lat.set_option("cg_fused_dot", fused)
+    N = orc.Vh
+    q = random_spinor(76, N)
+    P = orc.new_field(); it_ref, hist_ref = orc.cg_her(P, q.copy(), 2000, 1e-20, 1, N, "Qsw_pm_psi")
+    dq, dp = lat.field(q), lat.field()
+    it, hist = lat.cg_her(dp, dq, 2000, 1e-20, 1, N, op="Qsw_pm_psi")
+    assert abs(it - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9
+    m = min(len(hist), len(hist_ref)) - 1
+    assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6)
+    for solver in (lambda: lat.mixed_cg_her(dp, dq, 5000, 1e-20, 1, N, op="Qsw_pm_psi")[0],
+                   lambda: lat.rg_mixed_cg_her(dp, dq, 5000, 1e-20, 1, N, delta=0.1, op="Qsw_pm_psi")[0]):
+        assert solver() > 0
+        assert rel_err(dp.download(), P[:N]) < 1e-8
+    lat.close()

@@ -293,26 +293,45 @@ static int cg_reduce_update(tmhip_ctx *ctx, int n, CgState *st, double *hist, in
 //   P += alpha p ; p = beta p + r              one pass
 // i.e. cg_her.c:91-126 with 960 B/site of vector traffic next to the four stencils instead of 1728.
 static int cg_enqueue_fused_qtm(tmhip_ctx *ctx, bool fp32, tmhip_field *x, tmhip_field *p, tmhip_field *r, CgState *st, double *hist,
-                                int hist_len, int N) {
+                                int hist_len, int N, bool clover = false) {
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   const dim3 g = la_grid(N);
+  const size_t gs = ctx->gs;
   int n1 = 0, n2 = 0;
   if (fp32) {
     v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
-    if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, p->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
-    if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, s0, s1, p->d32, nullptr, 1., -mu, &n1, 1)) return 1;
-    if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
-    if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true)) return 1;
-    if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d32, &st->alpha)) return 1;
+    if (clover) {   // Qsw_pm_psi_32 (clovertm_operators_32.c): clover_inv / clover_gamma5 epilogues instead of the twists
+      const v2f *wim = ctx->sw_inv32 + (size_t)(fabs(mu) > 0 ? 1 : 0) * 72 * gs, *wip = ctx->sw_inv32, *wo = ctx->sw32 + (size_t)54 * gs;
+      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, p->d32, nullptr, EPI_CLOVER_INV, 0, 0, true, wim)) return 1;
+      if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, s0, s1, p->d32, nullptr, 0, -mu, &n1, 1, nullptr, nullptr, wo)) return 1;
+      if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
+      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_CLOVER_INV, 0, 0, true, wip)) return 1;
+      if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 0, +mu, &n2, 2, r->d32, &st->alpha, wo)) return 1;
+    } else {
+      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, p->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
+      if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, s0, s1, p->d32, nullptr, 1., -mu, &n1, 1)) return 1;
+      if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
+      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true)) return 1;
+      if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d32, &st->alpha)) return 1;
+    }
     if (cg_reduce_update<1>(ctx, n2, st, hist, hist_len)) return 1;
     hipLaunchKernelGGL(cg_xp_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, x->d32, p->d32, (const v2f *)r->d32, p->ns, N, st);
   } else {
     v2d *s0 = ctx->scratch[0]->d, *s1 = ctx->scratch[1]->d;
-    if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
-    if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 1., -mu, &n1, 1)) return 1;
-    if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
-    if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true)) return 1;
-    if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d, &st->alpha)) return 1;
+    if (clover) {   // Qsw_pm_psi (clovertm_operators.c:233-245)
+      const v2d *wim = ctx->sw_inv + (size_t)(fabs(mu) > 0 ? 1 : 0) * 72 * gs, *wip = ctx->sw_inv, *wo = ctx->sw + (size_t)54 * gs;
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_CLOVER_INV, 0, 0, true, wim)) return 1;
+      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 0, -mu, &n1, 1, nullptr, nullptr, wo)) return 1;
+      if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_CLOVER_INV, 0, 0, true, wip)) return 1;
+      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 0, +mu, &n2, 2, r->d, &st->alpha, wo)) return 1;
+    } else {
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
+      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 1., -mu, &n1, 1)) return 1;
+      if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, true)) return 1;
+      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d, &st->alpha)) return 1;
+    }
     if (cg_reduce_update<1>(ctx, n2, st, hist, hist_len)) return 1;
     hipLaunchKernelGGL(cg_xp_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, x->d, p->d, (const v2d *)r->d, p->ns, N, st);
   }
@@ -346,15 +365,17 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
   const dim3 g = la_grid(N);
   const int nblk = g.x * g.y;
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
-  const bool fused = ctx->opt_cg_fused_dot && op == TMHIP_OP_QTM_PM && ctx->g.nproc_t == 1 && !ctx->loopback && ctx->opt_block == 256 && ctx->Vh % 256 == 0;
+  const bool fusable = ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && ctx->opt_block == 256 && ctx->Vh % 256 == 0;
+  const bool fused = fusable && op == TMHIP_OP_QTM_PM;                                      // scalar product in the last stencil (cg_fused_dot = 1)
+  const bool fused_full = fusable && ctx->opt_cg_fused_dot >= 2 && (op == TMHIP_OP_QTM_PM || op == TMHIP_OP_QSW_PM);
   int enq = 0, done = 0;
   int *flag = (int *)(ctx->result_host + 2);
   while (enq < max_iter && !done) {
     const int nb = (max_iter - enq) < batch ? (max_iter - enq) : batch;
     for (int b = 0; b < nb; b++) {
       int ndot = nblk;
-      if (fused && ctx->opt_cg_fused_dot >= 2) {   // default: everything but the (P, p) update rides in stencil epilogues
-        if (cg_enqueue_fused_qtm(ctx, false, P, sf2, sf1, st, ctx->cg_hist, max_iter, N)) return 1;
+      if (fused_full) {   // default: everything but the (P, p) update rides in stencil epilogues
+        if (cg_enqueue_fused_qtm(ctx, false, P, sf2, sf1, st, ctx->cg_hist, max_iter, N, op == TMHIP_OP_QSW_PM)) return 1;
         continue;
       }
       if (fused) {
@@ -419,7 +440,7 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
   const int nblk = g.x * g.y;
   int *flag = (int *)(ctx->result_host + 2);
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
-  const bool fused = !clover && ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
+  const bool fused = ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   int iter = 0;
   for (int i = 0; i < N_outer; i++) {
@@ -438,7 +459,7 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
         int ndot = nblk;
         v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
         if (fused && ctx->opt_cg_fused_dot >= 2) {
-          if (cg_enqueue_fused_qtm(ctx, true, x, sf2, sf1, st, (double *)nullptr, 0, N)) return 1;
+          if (cg_enqueue_fused_qtm(ctx, true, x, sf2, sf1, st, (double *)nullptr, 0, N, clover)) return 1;
           continue;
         }
         if (clover) {
@@ -499,7 +520,7 @@ static int rg_enqueue_iteration(tmhip_ctx *ctx, int op, bool fp32, bool fused, R
   const int nblk = g.x * g.y;
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   int ndot = nblk;
-  if (fp32 && fused && ctx->opt_cg_fused_dot >= 2) return cg_enqueue_fused_qtm(ctx, true, f.x, f.p, f.r, st, (double *)nullptr, 0, N);
+  if (fp32 && fused && ctx->opt_cg_fused_dot >= 2) return cg_enqueue_fused_qtm(ctx, true, f.x, f.p, f.r, st, (double *)nullptr, 0, N, op == TMHIP_OP_QSW_PM);
   if (fp32) {
     if (op == TMHIP_OP_QSW_PM) {
       if (tmhip_Qsw_pm_psi_32(ctx, f.q, f.p)) return 1;
@@ -584,7 +605,7 @@ extern "C" int tmhip_rg_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field
   if (clover && tmhip_prepare_clover32(ctx)) return 1;
   if (!ctx->cg_state) TMHIP_CHECK(hipMalloc(&ctx->cg_state, sizeof(CgState)));
   if (!ctx->sf_extra && tmhip_field_alloc(ctx, TMHIP_FIELD_EO, &ctx->sf_extra)) return 1;
-  const bool fused = !clover && ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
+  const bool fused = ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
   const float delta = (float)delta_in;                                /* :185 */
   int iter_in_sp = 0, iter_in_dp = 0, iter_out = 0, high_control = 0, j;
   double rho_dp, sourcesquarenorm, target_eps_sq;

@@ -103,8 +103,8 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
   return hop64::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
 }
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
-                             double cre, double cim, int *npartials, int mode, v2d *resid, const double *scal) {
-  return hop64::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal);
+                             double cre, double cim, int *npartials, int mode, v2d *resid, const double *scal, const v2d *cw) {
+  return hop64::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw);
 }
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
                            double cre, double cim, bool comm, const v2f *cw) {
@@ -112,9 +112,9 @@ int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, con
   return hop32::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
 }
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
-                               double cre, double cim, int *npartials, int mode, v2f *resid, const double *scal) {
-  if (fp32_pairs(ctx)) return hop32p::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal);
-  return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal);
+                               double cre, double cim, int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw) {
+  if (fp32_pairs(ctx)) return hop32p::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw);
+  return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw);
 }
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx) { return ctx->Vh % (fp32_pairs(ctx) ? 512 : 256) == 0; }
 
