@@ -370,8 +370,12 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
   const bool fused_full = fusable && ctx->opt_cg_fused_dot >= 2 && (op == TMHIP_OP_QTM_PM || op == TMHIP_OP_QSW_PM);
   int enq = 0, done = 0;
   int *flag = (int *)(ctx->result_host + 2);
+  double *err_host = ctx->result_host + 3;
+  const double target = rel_prec == 1 ? eps_sq * h.squarenorm : eps_sq;
+  bool near = false;   // within 10^3 of the target: poll every iteration so that no stencil is enqueued past convergence
   while (enq < max_iter && !done) {
-    const int nb = (max_iter - enq) < batch ? (max_iter - enq) : batch;
+    const int want = near ? 1 : batch;
+    const int nb = (max_iter - enq) < want ? (max_iter - enq) : want;
     for (int b = 0; b < nb; b++) {
       int ndot = nblk;
       if (fused_full) {   // default: everything but the (P, p) update rides in stencil epilogues
@@ -399,8 +403,10 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
     enq += nb;
     TMHIP_CHECK(hipGetLastError());
     TMHIP_CHECK(hipMemcpyAsync(flag, &st->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    TMHIP_CHECK(hipMemcpyAsync(err_host, &st->err, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     done = *flag;
+    near = *err_host <= 1.0e3 * target;
   }
   TMHIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
