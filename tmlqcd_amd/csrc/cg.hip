@@ -460,8 +460,15 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
     h.eps_sq = eps_sq; h.rel_prec = rel_prec; h.inner = 1; h.max_inner = max_inner_it; h.innereps = innereps;
     TMHIP_CHECK(hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
     int done = 0, enq = 0;
+    // the inner loops are short (a handful of iterations each): poll every iteration once the residual is within 10^3 of
+    // whichever stopping rule of mixed_cg_her.c:141 is closer, so that no stencil is enqueued past the restart
+    double *err_host = ctx->result_host + 3;
+    const double t_outer = (rel_prec == 1 ? eps_sq * sourcesquarenorm : eps_sq) / 1.3, t_inner = innereps * h.sqnrm_outer;
+    const double tgt = t_inner > t_outer ? t_inner : t_outer;
+    bool near = false;
     while (!done && enq <= max_inner_it) {
-      for (int b = 0; b < batch; b++) {
+      const int want = near ? 1 : batch;
+      for (int b = 0; b < want; b++) {
         int ndot = nblk;
         v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
         if (fused && ctx->opt_cg_fused_dot >= 2) {
@@ -489,11 +496,13 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
         hipLaunchKernelGGL(cg_xpay_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, st);
         stmp = sf0; sf0 = sf1; sf1 = stmp;
       }
-      enq += batch;
+      enq += want;
       TMHIP_CHECK(hipGetLastError());
       TMHIP_CHECK(hipMemcpyAsync(flag, &st->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      TMHIP_CHECK(hipMemcpyAsync(err_host, &st->err, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
       TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
       done = *flag;
+      near = *err_host <= 1.0e3 * tgt;
     }
     TMHIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -579,14 +588,21 @@ static int rg_inner_loop(tmhip_ctx *ctx, int op, bool fp32, bool fused, RgFields
   int *flag = (int *)(ctx->result_host + 2);
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
   int done = 0, enq = 0;
+  double *err_host = ctx->result_host + 3;
+  const double t_rel = delta * *rho1, t_abs = eps_sq / 1.3;      // the two exits of rg_mixed_cg_her.c:122-145 (rhomax >= rho1)
+  const double tgt = t_rel > t_abs ? t_rel : t_abs;
+  bool near = false;                                             // as in tmhip_mixed_cg_her: poll every iteration close to the restart
   while (!done) {
-    for (int b = 0; b < batch; b++)
+    const int want = near ? 1 : batch;
+    for (int b = 0; b < want; b++)
       if (rg_enqueue_iteration(ctx, op, fp32, fused, f, st, N)) return 1;
-    enq += batch;
+    enq += want;
     TMHIP_CHECK(hipGetLastError());
     TMHIP_CHECK(hipMemcpyAsync(flag, &st->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    TMHIP_CHECK(hipMemcpyAsync(err_host, &st->err, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     done = *flag;
+    near = *err_host <= 1.0e3 * tgt;
     if (!done && enq > max_iter + batch) TMHIP_FAIL("rg_mixed_cg_her: inner loop did not terminate");
   }
   TMHIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
