@@ -234,4 +234,10 @@ def test_clover_cg_with_reductions_fused_into_the_stencils(fused):
                    lambda: lat.rg_mixed_cg_her(dp, dq, 5000, 1e-20, 1, N, delta=0.1, op="Qsw_pm_psi")[0]):
         assert solver() > 0
         assert rel_err(dp.download(), P[:N]) < 1e-8
+    lat.set_loopback(1)                      # split-phase path: reductions spread over boundary + interior kernels
+    dp.zero()
+    it2, _ = lat.cg_her(dp, dq, 2000, 1e-20, 1, N, op="Qsw_pm_psi")
+    assert abs(it2 - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9
+    assert lat.mixed_cg_her(dp, dq, 5000, 1e-20, 1, N, op="Qsw_pm_psi")[0] > 0 and rel_err(dp.download(), P[:N]) < 1e-8
+    lat.set_loopback(0)
     lat.close()

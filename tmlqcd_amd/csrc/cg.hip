@@ -365,8 +365,10 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
   const dim3 g = la_grid(N);
   const int nblk = g.x * g.y;
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
-  const bool fusable = ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && ctx->opt_block == 256 && ctx->Vh % 256 == 0;
-  const bool fused = fusable && op == TMHIP_OP_QTM_PM;                                      // scalar product in the last stencil (cg_fused_dot = 1)
+  const bool split = ctx->g.nproc_t > 1 || ctx->loopback;   // T-split rank (or its single-rank rehearsal): reductions fused into the interior + boundary kernels
+  const bool fusable = ctx->opt_cg_fused_dot && ctx->opt_block == 256 && ctx->Vh % 256 == 0 &&
+                       (!split || (ctx->face % 256 == 0 && !ctx->opt_fusedface && ctx->g.T >= 3));
+  const bool fused = fusable && !split && op == TMHIP_OP_QTM_PM;                            // scalar product in the last stencil (cg_fused_dot = 1)
   const bool fused_full = fusable && ctx->opt_cg_fused_dot >= 2 && (op == TMHIP_OP_QTM_PM || op == TMHIP_OP_QSW_PM);
   int enq = 0, done = 0;
   int *flag = (int *)(ctx->result_host + 2);
@@ -446,7 +448,8 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
   const int nblk = g.x * g.y;
   int *flag = (int *)(ctx->result_host + 2);
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
-  const bool fused = ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
+  const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
+  const bool fused = ctx->opt_cg_fused_dot && tmhip_fused_dot32_ok(ctx) && (!split || ctx->opt_cg_fused_dot >= 2);   // the older mode-0 fusion is unsplit only
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   int iter = 0;
   for (int i = 0; i < N_outer; i++) {
@@ -627,7 +630,8 @@ extern "C" int tmhip_rg_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field
   if (clover && tmhip_prepare_clover32(ctx)) return 1;
   if (!ctx->cg_state) TMHIP_CHECK(hipMalloc(&ctx->cg_state, sizeof(CgState)));
   if (!ctx->sf_extra && tmhip_field_alloc(ctx, TMHIP_FIELD_EO, &ctx->sf_extra)) return 1;
-  const bool fused = ctx->opt_cg_fused_dot && ctx->g.nproc_t == 1 && !ctx->loopback && tmhip_fused_dot32_ok(ctx);
+  const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
+  const bool fused = ctx->opt_cg_fused_dot && tmhip_fused_dot32_ok(ctx) && (!split || ctx->opt_cg_fused_dot >= 2);   // the older mode-0 fusion is unsplit only
   const float delta = (float)delta_in;                                /* :185 */
   int iter_in_sp = 0, iter_in_dp = 0, iter_out = 0, high_control = 0, j;
   double rho_dp, sourcesquarenorm, target_eps_sq;

@@ -116,7 +116,11 @@ int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in,
   if (fp32_pairs(ctx)) return hop32p::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw);
   return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw);
 }
-bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx) { return ctx->Vh % (fp32_pairs(ctx) ? 512 : 256) == 0; }
+bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx) {
+  const int spb = fp32_pairs(ctx) ? 512 : 256;
+  const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
+  return ctx->Vh % spb == 0 && (!split || (ctx->face % spb == 0 && !ctx->opt_fusedface && ctx->g.T >= 3));
+}
 
 // Single-process ring: n contexts (one per GPU, or several on one GPU for the self-test) that
 // together hold a T-split lattice; faces move by peer copies instead of RCCL.  Collective over
