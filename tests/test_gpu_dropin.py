@@ -122,21 +122,87 @@ def test_cg_her_drop_in_and_resident_benchmark(host):
     d.tmlqcd_hip_set_residency(0)
 
 
-def test_mixed_cg_her_drop_in(host):
-    """solver/mixed_cg_her.h signature: solver_params_t by value (opaque, >16 B => passed in memory), f32 on the stack."""
+class SolverParams(C.Structure):
+    """solver_params_t (solver/solver_params.h:46-109): 144 bytes, mcg_delta at offset 52."""
+    _fields_ = [("eigcg_i", C.c_int * 5), ("eigcg_d", C.c_double * 3), ("eigcg_rand_guess_opt", C.c_int), ("mcg_delta", C.c_float),
+                ("type", C.c_int), ("max_iter", C.c_int), ("rel_prec", C.c_int), ("no_shifts", C.c_int), ("sdim", C.c_int),
+                ("squared_solver_prec", C.c_double), ("M_psi", VP), ("M_psi32", VP), ("M_ndpsi", VP), ("M_ndpsi32", VP),
+                ("shifts", VP), ("solution_type", C.c_int), ("compression_type", C.c_int), ("sloppy_precision", C.c_int),
+                ("external_inverter", C.c_int)]
+
+
+def test_mixed_cg_her_and_rg_mixed_cg_her_drop_in(host):
+    """solver/mixed_cg_her.h, solver/rg_mixed_cg_her.h signatures: solver_params_t BY VALUE (>16 B => passed in memory),
+    f32 on the stack behind it."""
     stub, d, orc, g, (T, L, V) = host
     N = V // 2
+    assert C.sizeof(SolverParams) == 144 and SolverParams.mcg_delta.offset == 52
+    q = random_spinor(8, N)
+    for name, delta in (("mixed_cg_her", 0.0), ("rg_mixed_cg_her", 0.1)):
+        fn = getattr(d, name)
+        fn.restype = C.c_int
+        fn.argtypes = [VP, VP, SolverParams, C.c_int, C.c_double, C.c_int, C.c_int, VP, VP]
+        sp = SolverParams(); sp.mcg_delta = delta
+        P = np.full_like(q, 2.0)                                     # both solvers start from zero themselves
+        it = fn(_p(P), _p(q), sp, 5000, 1e-20, 1, N, C.cast(d.Qtm_pm_psi, VP), VP(0xdead0))
+        assert it > 0, name
+        full = orc.new_field(); full[:N] = P
+        chk = orc.new_field(); orc.op("Qtm_pm_psi", chk, full)
+        assert ((chk[:N] - q) ** 2).sum() / (q ** 2).sum() <= 1e-20, name
 
-    class Params(C.Structure):
-        _fields_ = [("opaque", C.c_double * 64)]
-    d.mixed_cg_her.restype = C.c_int
-    d.mixed_cg_her.argtypes = [VP, VP, Params, C.c_int, C.c_double, C.c_int, C.c_int, VP, VP]
-    q = random_spinor(8, N); P = np.zeros_like(q)
-    it = d.mixed_cg_her(_p(P), _p(q), Params(), 5000, 1e-20, 1, N, C.cast(d.Qtm_pm_psi, VP), None)
-    assert it > 0
-    full = orc.new_field(); full[:N] = P
-    chk = orc.new_field(); orc.op("Qtm_pm_psi", chk, full)
-    assert ((chk[:N] - q) ** 2).sum() / (q ** 2).sum() <= 1e-20
+
+def test_invert_eo_call_sequence_through_the_drop_in(host):
+    """The even/odd inversion of invert_eo.c:143-148,296-310 statement by statement through the reference-named
+    symbols on host arrays: coherent mode, then resident mode with one download at the end.  The result solves
+    M_full (Even_new, Odd_new) = (Even, Odd) and equals the oracle running the same statements."""
+    stub, d, orc, g, (T, L, V) = host
+    N = V // 2
+    d.assign_mul_one_pm_imu_inv.argtypes = [VP, VP, C.c_double, C.c_int]
+    d.mul_one_pm_imu_inv.argtypes = [VP, C.c_double, C.c_int]
+    d.assign_mul_add_r.argtypes = [VP, C.c_double, VP, C.c_int]
+    d.gamma5.argtypes = [VP, VP, C.c_int]
+    Even, Odd = random_spinor(61, N), random_spinor(62, N)
+    prec, max_iter = 1e-22, 1000
+
+    # the oracle, same statements
+    o_en, o_on, o_d = orc.new_field(), orc.new_field(), orc.new_field()
+    orc.assign_mul_one_pm_imu_inv(o_en, Even, +1., N)
+    orc.Hopping_Matrix(1, o_d, o_en)
+    orc.assign_mul_add_r(o_d, +1., Odd, N)
+    orc.gamma5(o_d, o_d, N)
+    it_ref, _ = orc.cg_her(o_on, o_d.copy(), max_iter, prec, 1, N)
+    orc.op("Qtm_minus_psi", o_on, o_on)
+    orc.Hopping_Matrix(0, o_d, o_on)
+    orc.mul_one_pm_imu_inv(o_d, +1., N)
+    orc.assign_add_mul_r(o_en, o_d, +1., N)
+
+    for resident in (0, 1):
+        en, on, dum = np.zeros_like(Even), np.zeros_like(Even), np.zeros_like(Even)
+        d.tmlqcd_hip_set_residency(resident)
+        if resident:
+            for a in (Even, Odd, en, on, dum):
+                d.tmlqcd_hip_host_modified(_p(a))
+        d.assign_mul_one_pm_imu_inv(_p(en), _p(Even), +1., N)                    # invert_eo.c:143
+        d.Hopping_Matrix(1, _p(dum), _p(en))                                     # :145  (OE)
+        d.assign_mul_add_r(_p(dum), +1., _p(Odd), N)                             # :148
+        d.gamma5(_p(dum), _p(dum), N)                                            # :296
+        it = d.cg_her(_p(on), _p(dum), max_iter, prec, 1, N, C.cast(d.Qtm_pm_psi, VP))   # :302
+        d.Qtm_minus_psi(_p(on), _p(on))                                          # :303
+        d.Hopping_Matrix(0, _p(dum), _p(on))                                     # :306  (EO)
+        d.mul_one_pm_imu_inv(_p(dum), +1., N)                                    # :307
+        d.assign_add_mul_r(_p(en), _p(dum), +1., N)                              # :310
+        if resident:
+            assert not en.any() and not on.any()                                 # nothing came back yet
+            d.tmlqcd_hip_sync_to_host(_p(en)); d.tmlqcd_hip_sync_to_host(_p(on))
+        d.tmlqcd_hip_set_residency(0)
+        assert abs(it - it_ref) <= 1
+        assert rel_err(en, o_en[:N]) < 1e-8 and rel_err(on, o_on[:N]) < 1e-8
+        # and it really is the solution of the full (unpreconditioned) system
+        re, ro = orc.new_field(), orc.new_field()
+        fe, fo = orc.new_field(), orc.new_field(); fe[:N] = en; fo[:N] = on
+        orc.M_full(re, ro, fe, fo)
+        res = ((re[:N] - Even) ** 2).sum() + ((ro[:N] - Odd) ** 2).sum()
+        assert res / ((Even ** 2).sum() + (Odd ** 2).sum()) < 1e-18
 
 
 def test_clover_drop_in(host):

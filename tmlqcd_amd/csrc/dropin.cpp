@@ -602,10 +602,7 @@ int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, 
     tmhip_field *fq = in(c, Q, TMHIP_FIELD_EO), *fp = in(c, P, TMHIP_FIELD_EO);
     int iters = -1;
     CK(tmhip_cg_her(c, fp, fq, max_iter, eps_sq, rel_prec, N, op, &iters, nullptr, 0));
-    Mirror &m = g_reg[P];
-    m.dev_valid = true; m.host_valid = false;
-    download(c, P, m);   // the solution is always handed back on the host
-    if (g_mode == TMLQCD_HIP_COHERENT) m.dev_valid = false;
+    done(c, P);          // coherent mode: the solution is on the host when we return; resident mode: after tmlqcd_hip_sync_to_host
     return iters;
   }
   // generic path: reference algorithm verbatim on host-visible fields
@@ -654,10 +651,7 @@ int mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params, const i
   tmhip_field *fq = in(c, Q, TMHIP_FIELD_EO), *fp = out(c, P, TMHIP_FIELD_EO);
   int iters = -1, outer = 0;
   CK(tmhip_mixed_cg_her(c, fp, fq, max_iter, eps_sq, rel_prec, N, op, innereps, max_inner, &iters, &outer));
-  Mirror &m = g_reg[P];
-  m.dev_valid = true; m.host_valid = false;
-  download(c, P, m);
-  if (g_mode == TMLQCD_HIP_COHERENT) m.dev_valid = false;
+  done(c, P);
   return iters;
 }
 
@@ -670,10 +664,7 @@ int rg_mixed_cg_her(spinor *const P, spinor *const Q, tmlqcd_solver_params solve
   tmhip_field *fq = in(c, Q, TMHIP_FIELD_EO), *fp = out(c, P, TMHIP_FIELD_EO);
   int iters = -1;
   CK(tmhip_rg_mixed_cg_her(c, fp, fq, max_iter, eps_sq, rel_prec, N, op, solver_params.mcg_delta, &iters, nullptr, nullptr, nullptr));
-  Mirror &m = g_reg[P];
-  m.dev_valid = true; m.host_valid = false;
-  download(c, P, m);
-  if (g_mode == TMLQCD_HIP_COHERENT) m.dev_valid = false;
+  done(c, P);
   return iters;
 }
 
