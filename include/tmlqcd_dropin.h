@@ -106,6 +106,17 @@ int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, 
 void tmlqcd_hip_update_clover(void);
 void Qsw_pm_psi(spinor *const l, spinor *const k);                                                  /* clovertm_operators.c:233 */
 void Msw_plus_psi(spinor *const l, spinor *const k);                                                /* :256 */
+void Qsw_psi(spinor *const l, spinor *const k);                                                     /* :201 */
+void Qsw_plus_psi(spinor *const l, spinor *const k);                                                /* :217 */
+void Qsw_minus_psi(spinor *const l, spinor *const k);                                               /* :209 (in place in invert_clover_eo.c:128) */
+void Qsw_sq_psi(spinor *const l, spinor *const k);                                                  /* :225 */
+void Msw_psi(spinor *const l, spinor *const k);                                                     /* :247 */
+void Msw_minus_psi(spinor *const l, spinor *const k);                                               /* :261 */
+void Msw_full(spinor *const Even_new, spinor *const Odd_new, spinor *const Even, spinor *const Odd); /* :96 */
+void assign_mul_one_sw_pm_imu(const int ieo, spinor *const k, spinor *const l, const double mu);     /* assign_mul_one_sw_pm_imu_inv_block_body.c:1 */
+void assign_mul_one_sw_pm_imu_inv(const int ieo, spinor *const k, spinor *const l, const double mu); /* :143 */
+void Mee_sw_psi(spinor *const k, spinor *const l, const double mu);                                 /* clovertm_operators.c:873 */
+void Mee_sw_inv_psi(spinor *const k, spinor *const l, const double mu);                             /* :1098 */
 void H_eo_sw_inv_psi(spinor *const l, spinor *const k, const int ieo, const int tau3sign, const double mu); /* :268 */
 void clover_inv(spinor *const l, const int tau3sign, const double mu);                              /* :287 */
 void clover_gamma5(const int ieo, spinor *const l, const spinor *const k, const spinor *const j, const double mu); /* :448 */

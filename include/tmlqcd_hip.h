@@ -162,6 +162,16 @@ int tmhip_clover(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, tmhip_
 int tmhip_H_eo_sw_inv_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int ieo, int tau3sign, double mu);     /* :268 */
 int tmhip_Qsw_pm_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);                                            /* :233 */
 int tmhip_Msw_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);                                          /* :256 */
+int tmhip_Qsw_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);        /* :201  Q-hat with mu = 0 in the diagonal term */
+int tmhip_Qsw_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);   /* :217 */
+int tmhip_Qsw_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);  /* :209; l may alias k (invert_clover_eo.c:128) */
+int tmhip_Qsw_sq_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);     /* :225 */
+int tmhip_Msw_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);        /* :247 */
+int tmhip_Msw_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);  /* :261 */
+int tmhip_Msw_full(tmhip_ctx *ctx, tmhip_field *Even_new, tmhip_field *Odd_new, tmhip_field *Even, tmhip_field *Odd);  /* :96-110 */
+/* k = (1 + T + i mu g5) l on parity ieo / k = sw_inv l   (operator/assign_mul_one_sw_pm_imu_inv_block_body.c:1-72, 143-196) */
+int tmhip_assign_mul_one_sw_pm_imu(tmhip_ctx *ctx, int ieo, tmhip_field *k, tmhip_field *l, double mu);
+int tmhip_assign_mul_one_sw_pm_imu_inv(tmhip_ctx *ctx, int ieo, tmhip_field *k, tmhip_field *l, double mu);
 int tmhip_Qsw_pm_psi_32(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k);                                         /* clovertm_operators_32.c */
 
 /* ---- mixed precision -------------------------------------

@@ -58,6 +58,11 @@ def _lib():
         lib.tmo_clover.argtypes = [vp, i, vp, vp, vp, d]
         lib.tmo_Qsw_pm_psi.argtypes = [vp, vp, vp]
         lib.tmo_Msw_plus_psi.argtypes = [vp, vp, vp]
+        for n in ("Qsw_psi", "Qsw_plus_psi", "Qsw_minus_psi", "Qsw_sq_psi", "Msw_psi", "Msw_minus_psi"):
+            getattr(lib, "tmo_" + n).argtypes = [vp, vp, vp]
+        lib.tmo_assign_mul_one_sw_pm_imu.argtypes = [vp, i, vp, vp, d]
+        lib.tmo_assign_mul_one_sw_pm_imu_inv.argtypes = [vp, i, vp, vp, d]
+        lib.tmo_Msw_full.argtypes = [vp] * 5
         lib.tmo_square_norm.restype = d
         lib.tmo_square_norm.argtypes = [vp, i]
         lib.tmo_scalar_prod_r.restype = d
@@ -165,6 +170,15 @@ class Oracle:
         sw = np.ascontiguousarray(sw, dtype=np.float64)
         fails = self.lib.tmo_sw_invert(self.h, _p(swi), _p(sw), ieo, mu)
         return swi, fails
+
+    def assign_mul_one_sw_pm_imu(self, ieo, k, l, mu):
+        self.lib.tmo_assign_mul_one_sw_pm_imu(self.h, ieo, _p(k), _p(l), mu)
+
+    def assign_mul_one_sw_pm_imu_inv(self, ieo, k, l, mu):
+        self.lib.tmo_assign_mul_one_sw_pm_imu_inv(self.h, ieo, _p(k), _p(l), mu)
+
+    def Msw_full(self, en, on, e, o):
+        self.lib.tmo_Msw_full(self.h, _p(en), _p(on), _p(e), _p(o))
 
     def clover_inv(self, l, tau3sign, mu):
         self.lib.tmo_clover_inv(self.h, _p(l), tau3sign, mu)

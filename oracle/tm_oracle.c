@@ -632,6 +632,78 @@ void tmo_Qsw_pm_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
   tmo_Hopping_Matrix(lat, OE, lat->scratch[1], l);
   tmo_clover_gamma5(lat, OE, l, lat->scratch[0], lat->scratch[1], +lat->mu);
 }
+/* the rest of the e/o clover family, operator/clovertm_operators.c:201-268 (g_mu3 = 0): which = 0 Qsw_psi (mu = 0 in the
+ * diagonal term), +1 Qsw_plus_psi / Msw_plus_psi, -1 Qsw_minus_psi / Msw_minus_psi; g5 selects clover_gamma5 vs clover */
+static void tmo_sw_hat(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k, int which, int g5) {
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
+  tmo_clover_inv(lat, lat->scratch[1], which < 0 ? -1 : +1, lat->mu);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
+  tmo_clover_generic(lat, OE, l, k, lat->scratch[0], which * lat->mu, g5);
+}
+void tmo_Qsw_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) { tmo_sw_hat(lat, l, k, 0, 1); }          /* :201-206 */
+void tmo_Qsw_minus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) { tmo_sw_hat(lat, l, k, -1, 1); }   /* :209-214 */
+void tmo_Qsw_plus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) { tmo_sw_hat(lat, l, k, +1, 1); }    /* :217-222 */
+void tmo_Msw_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) { tmo_sw_hat(lat, l, k, 0, 0); }          /* :247-252 */
+void tmo_Msw_minus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) { tmo_sw_hat(lat, l, k, -1, 0); }   /* :261-266 */
+/* :225-237 */
+void tmo_Qsw_sq_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
+  tmo_clover_inv(lat, lat->scratch[1], +1, lat->mu);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
+  tmo_clover_gamma5(lat, OE, lat->scratch[0], k, lat->scratch[0], 0.);
+  tmo_Hopping_Matrix(lat, EO, l, lat->scratch[0]);
+  tmo_clover_inv(lat, l, +1, lat->mu);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[1], l);
+  tmo_clover_gamma5(lat, OE, l, lat->scratch[0], lat->scratch[1], 0.);
+}
+/* operator/assign_mul_one_sw_pm_imu_inv_block_body.c:1-72: k = (1 + T + i mu g5) l on parity ieo */
+void tmo_assign_mul_one_sw_pm_imu(tmo_lattice *lat, int ieo, tmo_spinor *k, const tmo_spinor *l, double mu) {
+  const int ioff = ieo == 0 ? 0 : lat->VPR / 2, Vh = lat->V / 2;
+#pragma omp parallel for
+  for (int icx = ioff; icx < Vh + ioff; icx++) {
+    const tmo_su3 *w = lat->sw + 6 * (size_t)lat->eo2lexic[icx];
+    const tmo_spinor *s = l + (icx - ioff);
+    tmo_spinor o;
+    tmo_su3_vector chi, psi1, psi2;
+    psi1 = su3_mul(&w[0], s->s0); chi = su3_mul(&w[2], s->s1); V_ADD_ASSIGN(psi1, chi);
+    psi2 = su3_inv_mul(&w[2], s->s0); chi = su3_mul(&w[4], s->s1); V_ADD_ASSIGN(psi2, chi);
+    V_ADD_I_MUL(psi1, mu, s->s0); V_ADD_I_MUL(psi2, mu, s->s1);
+    o.s0 = psi1; o.s1 = psi2;
+    psi1 = su3_mul(&w[1], s->s2); chi = su3_mul(&w[3], s->s3); V_ADD_ASSIGN(psi1, chi);
+    psi2 = su3_inv_mul(&w[3], s->s2); chi = su3_mul(&w[5], s->s3); V_ADD_ASSIGN(psi2, chi);
+    V_ADD_I_MUL(psi1, -mu, s->s2); V_ADD_I_MUL(psi2, -mu, s->s3);
+    o.s2 = psi1; o.s3 = psi2;
+    k[icx - ioff] = o;
+  }
+}
+/* operator/assign_mul_one_sw_pm_imu_inv_block_body.c:143-196: k = sw_inv(+mu set) l; like the reference, ieo and mu are not
+ * looked at (the array holds the inverse for the parity / mu sw_invert was last called with) */
+void tmo_assign_mul_one_sw_pm_imu_inv(tmo_lattice *lat, int ieo, tmo_spinor *k, const tmo_spinor *l, double mu) {
+  (void)ieo; (void)mu;
+  const int Vh = lat->V / 2;
+#pragma omp parallel for
+  for (int icx = 0; icx < Vh; icx++) {
+    const tmo_su3 *w = lat->sw_inv + 8 * (size_t)icx;
+    const tmo_spinor *rn = l + icx;
+    tmo_spinor o;
+    tmo_su3_vector psi, chi, phi1 = rn->s0, phi3 = rn->s2;
+    psi = su3_mul(&w[0], phi1); chi = su3_mul(&w[2], rn->s1); o.s0 = v_add(psi, chi);
+    psi = su3_mul(&w[6], phi1); chi = su3_mul(&w[4], rn->s1); o.s1 = v_add(psi, chi);
+    psi = su3_mul(&w[1], phi3); chi = su3_mul(&w[3], rn->s3); o.s2 = v_add(psi, chi);
+    psi = su3_mul(&w[7], phi3); chi = su3_mul(&w[5], rn->s3); o.s3 = v_add(psi, chi);
+    k[icx] = o;
+  }
+}
+/* operator/clovertm_operators.c:96-110 */
+void tmo_Msw_full(tmo_lattice *lat, tmo_spinor *Even_new, tmo_spinor *Odd_new, const tmo_spinor *Even, const tmo_spinor *Odd) {
+  const int N = lat->V / 2;
+  tmo_Hopping_Matrix(lat, EO, lat->scratch[0], Odd);
+  tmo_assign_mul_one_sw_pm_imu(lat, EO, Even_new, Even, +lat->mu);
+  tmo_assign_add_mul_r(Even_new, lat->scratch[0], -1., N);
+  tmo_Hopping_Matrix(lat, OE, lat->scratch[0], Even);
+  tmo_assign_mul_one_sw_pm_imu(lat, OE, Odd_new, Odd, +lat->mu);
+  tmo_assign_add_mul_r(Odd_new, lat->scratch[0], -1., N);
+}
 /* operator/clovertm_operators.c:256-261 */
 void tmo_Msw_plus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
   tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);

@@ -42,7 +42,8 @@ def test_dropin_library_exports_reference_symbols():
                  "assign_mul_add_r_and_square", "diff", "assign", "cg_her", "gamma5", "Qtm_plus_sym_psi",
                  "Qtm_minus_sym_psi", "Mtm_plus_sym_psi", "Mtm_minus_sym_psi", "Mtm_plus_sym_dagg_psi", "Qtm_pm_sym_psi",
                  "Mtm_plus_sym_psi_nocom", "Mtm_minus_sym_psi_nocom", "Qtm_plus_sym_psi_nocom", "mixed_cg_her",
-                 "Qsw_pm_psi", "clover_inv", "clover_gamma5"):
+                 "Qsw_pm_psi", "clover_inv", "clover_gamma5", "Qsw_minus_psi", "Qsw_plus_psi", "Msw_full",
+                 "assign_mul_one_sw_pm_imu_inv", "rg_mixed_cg_her", "deriv_Sb"):
         assert must in names, must
     exp = exported(os.path.join(LIB, "libtmlqcd_dropin.so"))
     missing = [n for n in names if n not in exp]

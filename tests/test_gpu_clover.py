@@ -84,6 +84,22 @@ def test_clover_site_ops_and_fused_operator(setup8):
     assert rel_err(dl.download(), ref[:N]) < TOL
     orc.op("Msw_plus_psi", ref, k.copy()); lat.op("Msw_plus_psi", dl, dk)
     assert rel_err(dl.download(), ref[:N]) < TOL
+    # the rest of the e/o family (clovertm_operators.c:201-268) and the site operators behind Msw_full / invert_clover_eo
+    for name in ("Qsw_psi", "Qsw_plus_psi", "Qsw_minus_psi", "Qsw_sq_psi", "Msw_psi", "Msw_minus_psi"):
+        orc.op(name, ref, k.copy()); lat.op(name, dl, dk)
+        assert rel_err(dl.download(), ref[:N]) < TOL, name
+    ref[:N] = k; orc.op("Qsw_minus_psi", ref, ref)
+    dl.upload(k); lat.op("Qsw_minus_psi", dl, dl)                      # in place, invert_clover_eo.c:128
+    assert rel_err(dl.download(), ref[:N]) < TOL
+    for ieo in (0, 1):
+        orc.assign_mul_one_sw_pm_imu(ieo, ref, k, mu); lat.assign_mul_one_sw_pm_imu(ieo, dl, dk, mu)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+    orc.assign_mul_one_sw_pm_imu_inv(0, ref, k, mu); lat.assign_mul_one_sw_pm_imu_inv(0, dl, dk, mu)
+    assert rel_err(dl.download(), ref[:N]) < TOL
+    ro = orc.new_field(); do = lat.field()
+    orc.Msw_full(ref, ro, k, j); lat.Msw_full(dl, do, dk, dj)
+    assert rel_err(dl.download(), ref[:N]) < TOL and rel_err(do.download(), ro[:N]) < TOL
+    do.free()
     for f in (dk, dj, dl):
         f.free()
 

@@ -234,3 +234,71 @@ def test_clover_drop_in(host):
     it = d.cg_her(_p(P), _p(q), 2000, 1e-18, 1, N, C.cast(d.Qsw_pm_psi, VP))
     Pref = orc.new_field(); it_ref, _ = orc.cg_her(Pref, q.copy(), 2000, 1e-18, 1, N, "Qsw_pm_psi")
     assert abs(it - it_ref) <= max(1, it_ref // 100) and rel_err(P, Pref[:N]) < 1e-7
+
+
+def test_invert_clover_eo_call_sequence_through_the_drop_in(host):
+    """invert_clover_eo.c:101-160 (BASELINE configs[4] call stack) statement by statement through the drop-in:
+    sw_term / sw_invert computed on the device into the host program's sw / sw_inv arrays, then the even/odd inversion with
+    cg_her, mixed_cg_her and rg_mixed_cg_her on Qsw_pm_psi and Qm = Qsw_minus_psi in place.  The result solves
+    Msw_full (Even_new, Odd_new) = (Even, Odd)."""
+    stub, d, orc, g, (T, L, V) = host
+    N = V // 2
+    kappa, mu, c_sw = 0.129, 0.013, 1.4
+    stub.stub_boundary(kappa, 1.0, 0.0, 0.0, 0.0); stub.stub_set_mu(mu)
+    orc.set_kappa_theta(kappa, (1.0, 0.0, 0.0, 0.0)); orc.set_mu(mu)
+    gptr = stub.stub_init(T, L, L, L)            # fresh links: also exercises the re-upload
+    C.memmove(gptr, _p(g), g.nbytes)
+    orc.set_gauge(g)
+    stub.stub_init_clover.restype = C.c_void_p
+    stub.stub_init_clover.argtypes = [C.c_int]
+    sw_host = np.frombuffer((C.c_double * (V * 6 * 18)).from_address(stub.stub_init_clover(0)), dtype=np.float64).reshape(V, 3, 2, 3, 3, 2)
+    swi_host = np.frombuffer((C.c_double * (V * 8 * 18)).from_address(stub.stub_init_clover(1)), dtype=np.float64).reshape(V, 4, 2, 3, 3, 2)
+    d.tmlqcd_hip_sw_term.argtypes = [C.c_double, C.c_double]
+    d.tmlqcd_hip_sw_invert.argtypes = [C.c_int, C.c_double]
+    d.tmlqcd_hip_sw_term(kappa, c_sw)                                  # operator.c:329-330
+    d.tmlqcd_hip_sw_invert(0, mu)                                      # operator.c:364  sw_invert(EE, mu)
+    sw = orc.sw_term(kappa, c_sw); swi, _ = orc.sw_invert(sw, 0, mu)
+    assert rel_err(sw_host, sw) < TOL and rel_err(swi_host, swi) < TOL  # the host program's arrays received the copies
+    orc.set_clover(sw, swi)
+    for n in ("assign_mul_one_sw_pm_imu_inv", "assign_mul_one_sw_pm_imu"):
+        getattr(d, n).argtypes = [C.c_int, VP, VP, C.c_double]
+    d.assign_mul_add_r.argtypes = [VP, C.c_double, VP, C.c_int]
+    d.gamma5.argtypes = [VP, VP, C.c_int]
+    d.clover_inv.argtypes = [VP, C.c_int, C.c_double]
+    d.Qsw_minus_psi.argtypes = [VP, VP]
+    for n in ("mixed_cg_her", "rg_mixed_cg_her"):
+        getattr(d, n).restype = C.c_int
+        getattr(d, n).argtypes = [VP, VP, SolverParams, C.c_int, C.c_double, C.c_int, C.c_int, VP, VP]
+    Even, Odd = random_spinor(71, N), random_spinor(72, N)
+    prec, max_iter = 1e-22, 2000
+    Qsq = C.cast(d.Qsw_pm_psi, VP)
+    for solver in ("CG", "MIXEDCG", "RGMIXEDCG"):
+        en, on, dum = np.zeros_like(Even), np.zeros_like(Even), np.zeros_like(Even)
+        d.assign_mul_one_sw_pm_imu_inv(0, _p(en), _p(Even), +mu)                 # invert_clover_eo.c:101
+        d.Hopping_Matrix(1, _p(dum), _p(en))                                     # :103
+        d.assign_mul_add_r(_p(dum), +1., _p(Odd), N)                             # :106
+        d.gamma5(_p(dum), _p(dum), N)                                            # :125 / :141 / :148
+        sp = SolverParams(); sp.mcg_delta = 0.1
+        if solver == "CG":
+            it = d.cg_her(_p(on), _p(dum), max_iter, prec, 1, N, Qsq)            # :126-128
+        elif solver == "MIXEDCG":
+            it = d.mixed_cg_her(_p(on), _p(dum), sp, max_iter, prec, 1, N, Qsq, None)        # :142-144
+        else:
+            it = d.rg_mixed_cg_her(_p(on), _p(dum), sp, max_iter, prec, 1, N, Qsq, None)     # :149-150
+        assert it > 0, solver
+        d.Qsw_minus_psi(_p(on), _p(on))                                          # Qm(Odd_new, Odd_new)
+        d.Hopping_Matrix(0, _p(dum), _p(on))                                     # :159
+        d.clover_inv(_p(dum), +1, mu)                                            # :160
+        d.assign_add_mul_r(_p(en), _p(dum), +1., N)                              # :163
+        fe, fo, re, ro = orc.new_field(), orc.new_field(), orc.new_field(), orc.new_field()
+        fe[:N] = en; fo[:N] = on
+        orc.Msw_full(re, ro, fe, fo)
+        res = ((re[:N] - Even) ** 2).sum() + ((ro[:N] - Odd) ** 2).sum()
+        assert res / ((Even ** 2).sum() + (Odd ** 2).sum()) < 1e-18, solver
+    # Msw_full through the drop-in as well
+    d.Msw_full.argtypes = [VP] * 4
+    a, b = np.zeros_like(Even), np.zeros_like(Even)
+    d.Msw_full(_p(a), _p(b), _p(Even), _p(Odd))
+    ra, rb = orc.new_field(), orc.new_field()
+    orc.Msw_full(ra, rb, Even, Odd)
+    assert rel_err(a, ra[:N]) < TOL and rel_err(b, rb[:N]) < TOL

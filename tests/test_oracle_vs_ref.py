@@ -85,6 +85,22 @@ sw = o.sw_term(kappa, 1.37)
 assert np.array_equal(sw, sw_ref), "sw_term"
 swi, fails = o.sw_invert(sw, 0, 0.02)
 assert fails == 0 and np.array_equal(swi, swi_ref), "sw_invert"
+# the e/o clover operator family on those blocks (operator/clovertm_operators.c:96-268, assign_mul_one_sw_pm_imu_inv_block_body.c)
+import ctypes as C
+o.set_clover(sw, swi); o.set_mu(0.02)          # tmref_clover left g_mu = 0.02 in the reference
+for name in ("Qsw_pm_psi", "Qsw_psi", "Qsw_plus_psi", "Qsw_minus_psi", "Qsw_sq_psi", "Msw_psi", "Msw_plus_psi", "Msw_minus_psi"):
+    fn = getattr(lib, name); fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = None
+    o.op(name, q, k); fn(sp(3), sp(0)); same(q, 3, name)
+b = o.new_field(); b[:N] = k
+o.op("Qsw_minus_psi", b, b); lib.assign(sp(4), sp(0), N); lib.Qsw_minus_psi(sp(4), sp(4)); same(b, 4, "Qsw_minus_psi in place (invert_clover_eo.c:128)")
+for name in ("assign_mul_one_sw_pm_imu", "assign_mul_one_sw_pm_imu_inv"):
+    fn = getattr(lib, name); fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double]; fn.restype = None
+for ieo in (0, 1):
+    o.assign_mul_one_sw_pm_imu(ieo, q, k, 0.02); lib.assign_mul_one_sw_pm_imu(ieo, sp(3), sp(0), 0.02); same(q, 3, "assign_mul_one_sw_pm_imu")
+o.assign_mul_one_sw_pm_imu_inv(0, q, k, 0.02); lib.assign_mul_one_sw_pm_imu_inv(0, sp(3), sp(0), 0.02); same(q, 3, "assign_mul_one_sw_pm_imu_inv")
+lib.Msw_full.argtypes = [C.c_void_p] * 4; lib.Msw_full.restype = None
+en, on = o.new_field(), o.new_field()
+o.Msw_full(en, on, k, l); lib.Msw_full(sp(6), sp(7), sp(0), sp(1)); same(en, 6, "Msw_full even"); same(on, 7, "Msw_full odd")
 print("OK", T, LX, LY, LZ, "cg iters", it)
 '''
 

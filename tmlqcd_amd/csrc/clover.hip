@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void clover_site_kernel(v2d *L, const v2d *K, 
       for (int c = 0; c < 3; c++) {
         r1[c] = v2d{r1[c].x - m * sa[c].y, r1[c].y + m * sa[c].x};
         r2[c] = v2d{r2[c].x - m * sb[c].y, r2[c].y + m * sb[c].x};
-        const v2d j1 = J[(size_t)(6 * b + c) * ns + i], j2 = J[(size_t)(6 * b + 3 + c) * ns + i];
+        const v2d zero = v2d{0.0, 0.0};
+        const v2d j1 = J ? J[(size_t)(6 * b + c) * ns + i] : zero, j2 = J ? J[(size_t)(6 * b + 3 + c) * ns + i] : zero;
         const bool flip = MODE == 1 && b == 1;
         L[(size_t)(6 * b + c) * ns + i] = flip ? j1 - r1[c] : r1[c] - j1;
         L[(size_t)(6 * b + 3 + c) * ns + i] = flip ? j2 - r2[c] : r2[c] - j2;
@@ -521,6 +522,52 @@ int tmhip_Msw_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
   v2d *s1 = ctx->scratch[1]->d;
   return tmhip_launch_hopping(ctx, TMHIP_EO, s1, k->d, nullptr, EPI_CLOVER_INV, 0, 0, true, swinv(ctx, +1, mu)) ||
          tmhip_launch_hopping(ctx, TMHIP_OE, l->d, s1, k->d, EPI_CLOVER, 0, +mu, true, swpar(ctx, TMHIP_OE));
+}
+/* The rest of the e/o clover family (clovertm_operators.c:201-268, g_mu3 = 0), two launches each, clover blocks in the epilogues:
+ * which = 0: mu = 0 in the diagonal term (Qsw_psi / Msw_psi), +-1: Qsw_plus/minus_psi, Msw_plus/minus_psi.  l may alias k
+ * (invert_clover_eo.c:128 calls Qm(Odd_new, Odd_new)): k enters the last launch only through the element-wise epilogue. */
+static int sw_hat(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int which, int epi, const char *who) {
+  if (need64(l, who) || need64(k, who)) return 1;
+  if (!ctx->clover_set) TMHIP_FAIL("%s called before tmhip_set_clover / tmhip_sw_invert", who);
+  const double mu = ctx->mu;
+  v2d *s1 = ctx->scratch[1]->d;
+  return tmhip_launch_hopping(ctx, TMHIP_EO, s1, k->d, nullptr, EPI_CLOVER_INV, 0, 0, true, swinv(ctx, which < 0 ? -1 : +1, mu)) ||
+         tmhip_launch_hopping(ctx, TMHIP_OE, l->d, s1, k->d, epi, 0, which * mu, true, swpar(ctx, TMHIP_OE));
+}
+int tmhip_Qsw_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) { return sw_hat(ctx, l, k, 0, EPI_CLOVER_G5, "Qsw_psi"); }               /* :201-206 */
+int tmhip_Qsw_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) { return sw_hat(ctx, l, k, -1, EPI_CLOVER_G5, "Qsw_minus_psi"); }  /* :209-214 */
+int tmhip_Qsw_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) { return sw_hat(ctx, l, k, +1, EPI_CLOVER_G5, "Qsw_plus_psi"); }    /* :217-222 */
+int tmhip_Msw_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) { return sw_hat(ctx, l, k, 0, EPI_CLOVER, "Msw_psi"); }                  /* :247-252 */
+int tmhip_Msw_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) { return sw_hat(ctx, l, k, -1, EPI_CLOVER, "Msw_minus_psi"); }     /* :261-266 */
+/* :225-237 : (Qsw_psi)^2 */
+int tmhip_Qsw_sq_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  return sw_hat(ctx, ctx->scratch[0], k, 0, EPI_CLOVER_G5, "Qsw_sq_psi") || sw_hat(ctx, l, ctx->scratch[0], 0, EPI_CLOVER_G5, "Qsw_sq_psi");
+}
+/* assign_mul_one_sw_pm_imu_inv_block_body.c:1-72 : k = (1 + T + i mu g5) l on the sites of parity ieo */
+int tmhip_assign_mul_one_sw_pm_imu(tmhip_ctx *ctx, int ieo, tmhip_field *k, tmhip_field *l, double mu) {
+  if (need64(k, "assign_mul_one_sw_pm_imu") || need64(l, "assign_mul_one_sw_pm_imu")) return 1;
+  if (!ctx->sw_set) TMHIP_FAIL("assign_mul_one_sw_pm_imu called before tmhip_sw_term / tmhip_set_clover");
+  hipLaunchKernelGGL(clover_site_kernel<2>, dim3((ctx->Vh + 255) / 256), dim3(256), 0, ctx->stream, k->d, (const v2d *)l->d, (const v2d *)nullptr,
+                     swpar(ctx, ieo), k->ns, ctx->gs, ctx->Vh, mu);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+/* assign_mul_one_sw_pm_imu_inv_block_body.c:143-196 : k = sw_inv(+mu set) l; ieo and mu are ignored exactly as in the reference */
+int tmhip_assign_mul_one_sw_pm_imu_inv(tmhip_ctx *ctx, int ieo, tmhip_field *k, tmhip_field *l, double mu) {
+  (void)ieo; (void)mu;
+  if (need64(k, "assign_mul_one_sw_pm_imu_inv") || need64(l, "assign_mul_one_sw_pm_imu_inv")) return 1;
+  if (!ctx->clover_set) TMHIP_FAIL("assign_mul_one_sw_pm_imu_inv called before tmhip_set_clover / tmhip_sw_invert");
+  hipLaunchKernelGGL(clover_site_kernel<0>, dim3((ctx->Vh + 255) / 256), dim3(256), 0, ctx->stream, k->d, (const v2d *)l->d, (const v2d *)nullptr,
+                     (const v2d *)ctx->sw_inv, k->ns, ctx->gs, ctx->Vh, 0.0);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+/* clovertm_operators.c:96-110 : X_new = (1 + T + i mu g5) X - H Y on both parities, clover blocks in the stencil epilogue */
+int tmhip_Msw_full(tmhip_ctx *ctx, tmhip_field *En, tmhip_field *On, tmhip_field *E, tmhip_field *O) {
+  if (need64(En, "Msw_full") || need64(On, "Msw_full") || need64(E, "Msw_full") || need64(O, "Msw_full")) return 1;
+  if (!ctx->sw_set) TMHIP_FAIL("Msw_full called before tmhip_sw_term / tmhip_set_clover");
+  return tmhip_launch_hopping(ctx, TMHIP_EO, En->d, O->d, E->d, EPI_CLOVER, 0, +ctx->mu, true, swpar(ctx, TMHIP_EO)) ||
+         tmhip_launch_hopping(ctx, TMHIP_OE, On->d, E->d, O->d, EPI_CLOVER, 0, +ctx->mu, true, swpar(ctx, TMHIP_OE));
 }
 /* clovertm_operators_32.c Qsw_pm_psi_32 */
 int tmhip_Qsw_pm_psi_32(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {

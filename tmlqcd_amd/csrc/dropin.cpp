@@ -325,6 +325,37 @@ void tmlqcd_hip_sw_invert(const int ieo, const double mu) {
 }
 EO_OP_CLOVER(Qsw_pm_psi, tmhip_Qsw_pm_psi)      /* clovertm_operators.c:233-245 */
 EO_OP_CLOVER(Msw_plus_psi, tmhip_Msw_plus_psi)  /* clovertm_operators.c:256-261 */
+EO_OP_CLOVER(Qsw_psi, tmhip_Qsw_psi)              /* :201-206 */
+EO_OP_CLOVER(Qsw_minus_psi, tmhip_Qsw_minus_psi)  /* :209-214 */
+EO_OP_CLOVER(Qsw_plus_psi, tmhip_Qsw_plus_psi)    /* :217-222 */
+EO_OP_CLOVER(Qsw_sq_psi, tmhip_Qsw_sq_psi)        /* :225-237 */
+EO_OP_CLOVER(Msw_psi, tmhip_Msw_psi)              /* :247-252 */
+EO_OP_CLOVER(Msw_minus_psi, tmhip_Msw_minus_psi)  /* :261-266 */
+/* clovertm_operators.c:96-110 */
+void Msw_full(spinor *const En, spinor *const On, spinor *const E, spinor *const O) {
+  tmhip_ctx *c = refresh_clover();
+  tmhip_field *fe = in(c, E, TMHIP_FIELD_EO), *fo = in(c, O, TMHIP_FIELD_EO);
+  tmhip_field *fen = out(c, En, TMHIP_FIELD_EO), *fon = out(c, On, TMHIP_FIELD_EO);
+  CK(tmhip_Msw_full(c, fen, fon, fe, fo));
+  done(c, En); done(c, On);
+}
+/* operator/assign_mul_one_sw_pm_imu_inv_block_body.c:1-72 */
+void assign_mul_one_sw_pm_imu(const int ieo, spinor *const k, spinor *const l, const double mu) {
+  tmhip_ctx *c = refresh_clover();
+  tmhip_field *fl = in(c, l, TMHIP_FIELD_EO), *fk = out(c, k, TMHIP_FIELD_EO);
+  CK(tmhip_assign_mul_one_sw_pm_imu(c, ieo, fk, fl, mu));
+  done(c, k);
+}
+/* operator/assign_mul_one_sw_pm_imu_inv_block_body.c:143-196 (ieo and mu are not looked at, as in the reference) */
+void assign_mul_one_sw_pm_imu_inv(const int ieo, spinor *const k, spinor *const l, const double mu) {
+  tmhip_ctx *c = refresh_clover();
+  tmhip_field *fl = in(c, l, TMHIP_FIELD_EO), *fk = out(c, k, TMHIP_FIELD_EO);
+  CK(tmhip_assign_mul_one_sw_pm_imu_inv(c, ieo, fk, fl, mu));
+  done(c, k);
+}
+/* clovertm_operators.c:873-940, 1098-1140: the even-site forms of the two above */
+void Mee_sw_psi(spinor *const k, spinor *const l, const double mu) { assign_mul_one_sw_pm_imu(0, k, l, mu); }
+void Mee_sw_inv_psi(spinor *const k, spinor *const l, const double mu) { assign_mul_one_sw_pm_imu_inv(0, k, l, mu); }
 /* clovertm_operators.c:268-272 */
 void H_eo_sw_inv_psi(spinor *const l, spinor *const k, const int ieo, const int tau3sign, const double mu) {
   tmhip_ctx *c = refresh_clover();

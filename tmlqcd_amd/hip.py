@@ -94,6 +94,10 @@ def load_library():
         "tmhip_H_eo_sw_inv_psi": [vp, vp, vp, i, i, d],
         "tmhip_Qsw_pm_psi": [vp, vp, vp],
         "tmhip_Msw_plus_psi": [vp, vp, vp],
+        "tmhip_Qsw_psi": [vp, vp, vp], "tmhip_Qsw_plus_psi": [vp, vp, vp], "tmhip_Qsw_minus_psi": [vp, vp, vp],
+        "tmhip_Qsw_sq_psi": [vp, vp, vp], "tmhip_Msw_psi": [vp, vp, vp], "tmhip_Msw_minus_psi": [vp, vp, vp],
+        "tmhip_Msw_full": [vp, vp, vp, vp, vp],
+        "tmhip_assign_mul_one_sw_pm_imu": [vp, i, vp, vp, d], "tmhip_assign_mul_one_sw_pm_imu_inv": [vp, i, vp, vp, d],
         "tmhip_Qsw_pm_psi_32": [vp, vp, vp],
         "tmhip_field_alloc32": [vp, C.POINTER(vp)],
         "tmhip_field_upload32": [vp, vp, vp, i],
@@ -308,6 +312,15 @@ class Lattice:
         swi = np.zeros((self.V, 4, 2, 3, 3, 2)) if want_sw_inv else None
         _ck(self.lib.tmhip_get_clover(self.h, _hp(sw) if want_sw else None, _hp(swi) if want_sw_inv else None), "tmhip_get_clover")
         return sw, swi
+
+    def assign_mul_one_sw_pm_imu(self, ieo, k, l, mu):
+        _ck(self.lib.tmhip_assign_mul_one_sw_pm_imu(self.h, ieo, k.h, l.h, mu), "assign_mul_one_sw_pm_imu")
+
+    def assign_mul_one_sw_pm_imu_inv(self, ieo, k, l, mu):
+        _ck(self.lib.tmhip_assign_mul_one_sw_pm_imu_inv(self.h, ieo, k.h, l.h, mu), "assign_mul_one_sw_pm_imu_inv")
+
+    def Msw_full(self, en, on, e, o):
+        _ck(self.lib.tmhip_Msw_full(self.h, en.h, on.h, e.h, o.h), "Msw_full")
 
     def clover_inv(self, l, tau3sign, mu):
         _ck(self.lib.tmhip_clover_inv(self.h, l.h, tau3sign, mu), "clover_inv")
