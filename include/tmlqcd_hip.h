@@ -222,8 +222,18 @@ int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_
 /* generic event slots (0..15) recorded on the context's compute stream */
 int tmhip_event_record(tmhip_ctx *ctx, int slot);
 int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double *ms);
-/* kernel variant selection for A/B measurements (0 = default).  One option changes what is read from memory:
- * "gauge_recon" = 12 makes the fp64 twisted-mass stencil launches fetch only the first two rows of every link and
+/* Kernel variant selection for A/B measurements; the defaults are the measured best.
+ *   "block" 256|64 threads per block          "nt" 1|0 non-temporal link loads / output stores
+ *   "xcd"   block order: 2 automatic (default; tile order up to L = 32, slab order above), 0 none, 1 one chunk per XCD,
+ *           3 slab, 4 tile;  "tgrp" time-slices per tile group (0 = automatic)
+ *   "occ" / "occ32"  waves per SIMD allowed by a dynamic-LDS cap for the fp64 / fp32 stencil (3 / 0 = no cap)
+ *   "minw" 4: __launch_bounds__(BS, 4);  "shape" n: compact n-x-plane block shape;  "fp32_pairs" 1: two sites per thread in fp32
+ *   "flagsync" 1|0 flag kernels vs HIP events on the split path;  "fusedface" 1: faces in the same launch as the interior
+ *   "cg_fused_dot" 2 (default: alpha / residual / norm in the stencil epilogues), 1 scalar product only, 0 plain linalg kernels
+ *   "cg_sync" 1: host-side scalars as in the reference loop;  "cg_batch" n: iterations enqueued between two polls of `done`
+ *   "gaux" / "gdrop": diagnostics (gauge links through a buffer descriptor / dropped), profiles/r01_diagnostics.md
+ * One option changes what is read from memory:
+ * "gauge_recon" = 12 makes the twisted-mass stencil launches (fp64 and fp32) fetch only the first two rows of every link and
  * rebuild the third as conj(row0 x row1) in registers (the 12-real compression the reference exposes for its external
  * inverters, misc_types.h:29-33 COMPRESSION_12) -- 25 % fewer bytes per site.  It is opt-in and guarded: the links
  * of the resident gauge field must be SU(3) to 1e-13 (measured on the device at set_gauge / when the option is set),
