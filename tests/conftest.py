@@ -38,3 +38,22 @@ def host_stub():
     tmlqcd_amd.load_library()
     dropin = C.CDLL(os.path.join(ROOT, "tmlqcd_amd", "lib", "libtmlqcd_dropin.so"), mode=C.RTLD_GLOBAL)
     return stub, dropin
+
+
+@pytest.fixture(scope="session")
+def c_host_program():
+    """tests/c_host/mini_benchmark: a C main in the shape of benchmark.c, linked at LINK TIME (not dlopen) against
+    libtmlqcd_dropin.so + libtmlqcd_hip.so the way INTEGRATION.md §2 puts them on tmLQCD's link line."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "c_host")
+    exe = os.path.join(d, "mini_benchmark")
+    srcs = [os.path.join(d, "mini_benchmark.c"), os.path.join(ROOT, "tests", "host_stub", "globals.c")]
+    libs = [os.path.join(ROOT, "tmlqcd_amd", "lib", "libtmlqcd_dropin.so"), os.path.join(ROOT, "oracle", "libtmoracle.so")]
+    newest = max(os.path.getmtime(p) for p in srcs + libs)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
+        subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-Wall", "-o", exe] + srcs +
+                              ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"),
+                               "-L" + os.path.join(ROOT, "tmlqcd_amd", "lib"), "-ltmlqcd_dropin", "-ltmlqcd_hip",
+                               "-L" + os.path.join(ROOT, "oracle"), "-ltmoracle", "-lm",
+                               "-Wl,-rpath,$ORIGIN/../../tmlqcd_amd/lib", "-Wl,-rpath,$ORIGIN/../../oracle", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe

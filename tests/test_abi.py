@@ -97,3 +97,16 @@ def test_reference_caller_host_program_links_against_the_drop_in():
     und = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
     for sym in ("square_norm", "scalar_prod_r", "assign_add_mul_r", "assign_mul_add_r_and_square", "diff", "assign"):
         assert (" U " + sym) in und, sym                       # really taken from the drop-in, not from reference objects
+
+
+def test_c_host_program_links_against_the_drop_in_at_link_time(c_host_program):
+    """A C main (tests/c_host/mini_benchmark.c, the shape of benchmark.c) with `-ltmlqcd_dropin -ltmlqcd_hip` on its link line:
+    every reference-named symbol it calls is bound to the drop-in library, the globals to the program itself."""
+    out = subprocess.run(["nm", "-D", "--undefined-only", c_host_program], capture_output=True, text=True, check=True).stdout
+    und = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert {"Hopping_Matrix", "square_norm", "tmlqcd_hip_benchmark_loop", "tmlqcd_hip_finalize"} <= und
+    ldd = subprocess.run(["ldd", c_host_program], capture_output=True, text=True, check=True).stdout
+    assert "libtmlqcd_dropin.so" in ldd and "libtmlqcd_hip.so" in ldd and "not found" not in ldd
+    defined = subprocess.run(["nm", "-D", "--defined-only", c_host_program], capture_output=True, text=True, check=True).stdout
+    for g in ("g_gauge_field", "g_update_gauge_copy", "ka0", "VOLUME"):       # exported by the executable for the library to read
+        assert g in defined, g

@@ -78,3 +78,12 @@ def test_reference_cg_her_object_code_drives_the_drop_in():
     rg = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_rg_scalars_8x8.json")))["runs"][0]
     assert rg["delta"] == 0.1 and abs(d["iters_rg"] - rg["iters"]) <= 6      # 59 in the all-reference run
     assert d["sol_err_rg"] < 1e-8
+
+
+def test_c_main_linked_at_link_time_runs_the_benchmark_loop(c_host_program):
+    """tests/c_host/mini_benchmark (C main + tmLQCD globals, `-ltmlqcd_dropin -ltmlqcd_hip` at link time): benchmark.c's loop on host
+    arrays in coherent mode and resident in HBM, checked inside the program against the oracle."""
+    r = subprocess.run([c_host_program, "8", "8", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["max_rel_err_vs_oracle"] < 1e-13 and d["mflops_resident"] > d["mflops_coherent"] > 0
