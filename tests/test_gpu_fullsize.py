@@ -1,0 +1,143 @@
+"""GPU: the BASELINE.json lattice sizes themselves.
+
+configs[1] 32^4 and the unsplit configs[3] volume 32^3 x 64: the oracle is fast enough on the GPU box's host cores for a
+full site-by-site comparison of the stencil and the fused operator; configs[4] 48^3 x 96 clover is checked through
+size-independent properties (exact inverse of the clover block, hermiticity, Q_+ = Q_-^dagger, positivity, CG true residual,
+fp32 vs fp64, 12-real gauge read vs full read)."""
+import numpy as np
+import pytest
+
+from tests.util import TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _mem_gb():
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            return int(line.split()[1]) / 1048576.0
+    return 0.0
+
+
+@pytest.mark.parametrize("T,L", [(32, 32), (64, 32)])
+def test_full_size_site_by_site_against_oracle(T, L):
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    if _mem_gb() < 24:
+        pytest.skip("needs ~20 GB of host memory for the oracle's gauge copy")
+    kappa, mu, theta = 0.125, 0.01, (1.0, 0.0, 0.0, 0.0)
+    orc = Oracle(T, L, L, L, kappa=kappa, mu=mu, theta=theta, threads=16)
+    lat = Lattice(T, L, L, L, kappa=kappa, mu=mu, theta=theta)
+    g = syn.gauge_field(31, T, L, L, L)
+    orc.set_gauge(g); lat.set_gauge(g)
+    del g
+    N = orc.Vh
+    k = syn.spinor_field_eo(32, 1, T, L, L, L)
+    dk, dl = lat.field(k), lat.field()
+    ref = orc.new_field()
+    for ieo in (0, 1):
+        orc.Hopping_Matrix(ieo, ref, k); lat.Hopping_Matrix(ieo, dl, dk)
+        assert rel_err(dl.download(), ref[:N]) < TOL, ieo
+    orc.op("Qtm_pm_psi", ref, k.copy()); lat.op("Qtm_pm_psi", dl, dk)
+    out = dl.download()
+    assert rel_err(out, ref[:N]) < TOL
+    assert abs(lat.square_norm(dl, N) - orc.square_norm(ref, N)) <= 1e-13 * orc.square_norm(ref, N)
+    # the opt-in 12-real gauge read and the fp32 twin at this size
+    lat.set_option("gauge_recon", 12)
+    lat.op("Qtm_pm_psi", dl, dk)
+    lat.set_option("gauge_recon", 18)
+    assert rel_err(dl.download(), ref[:N]) < TOL
+    k32 = lat.field32(k.astype(np.float32)); l32 = lat.field32()
+    lat.Qtm_pm_psi_32(l32, k32)
+    assert rel_err(l32.download().astype(np.float64), ref[:N]) < 2e-5
+    # solve to the BASELINE tolerance (|r|/|b| = 1e-10) and check the true residual on the CPU
+    it, _ = lat.cg_her(dl, dk, 5000, 1e-20, 1, N)
+    full = orc.new_field(); full[:N] = dl.download()
+    orc.op("Qtm_pm_psi", ref, full)
+    assert it > 0 and ((ref[:N] - k) ** 2).sum() / (k ** 2).sum() <= 1e-20
+    lat.close()
+
+
+def test_clover_48x96_properties():
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    if _mem_gb() < 40:
+        pytest.skip("needs ~30 GB of host memory for the 48^3 x 96 gauge field and its temporaries")
+    T, L = 96, 48
+    kappa, mu, c_sw = 0.1394265, 0.0002, 1.69
+    lat = Lattice(T, L, L, L, kappa=kappa, mu=mu)
+    g = syn.gauge_field(41, T, L, L, L)
+    lat.set_gauge(g)
+    lat.sw_term(g, kappa, c_sw)
+    lat.sw_invert(0, mu)
+    del g
+    N = lat.Vh
+    x, y = lat.field(syn.spinor_field_eo(42, 1, T, L, L, L)), lat.field(syn.spinor_field_eo(43, 1, T, L, L, L))
+    a, b, c = lat.field(), lat.field(), lat.field()
+
+    def close(u, v, tol):
+        lat.diff(c, u, v, N)
+        return lat.square_norm(c, N) <= tol ** 2 * lat.square_norm(v, N)
+
+    # (1 + T + i mu g5) sw_inv = 1 on the even sites: the device-computed inverse really inverts the device-computed term
+    lat.assign_mul_one_sw_pm_imu_inv(0, a, x, mu); lat.assign_mul_one_sw_pm_imu(0, b, a, mu)
+    assert close(b, x, 1e-12)
+    # Q_+ = Q_-^dagger, Qsw_pm = Q_+ Q_- hermitian and positive
+    lat.op("Qsw_plus_psi", a, x); lat.op("Qsw_minus_psi", b, y)
+    s1, s2 = lat.scalar_prod_r(y, a, N), lat.scalar_prod_r(b, x, N)
+    assert abs(s1 - s2) <= 1e-11 * max(abs(s1), np.sqrt(lat.square_norm(a, N) * lat.square_norm(y, N)) * 1e-3)
+    lat.op("Qsw_pm_psi", a, x); lat.op("Qsw_pm_psi", b, y)
+    h1, h2 = lat.scalar_prod_r(y, a, N), lat.scalar_prod_r(b, x, N)
+    assert abs(h1 - h2) <= 1e-11 * abs(h1) and lat.scalar_prod_r(x, a, N) > 0
+    # Q_+ Q_- composed from its halves
+    lat.op("Qsw_minus_psi", b, x); lat.op("Qsw_plus_psi", c, b)
+    lat.assign(b, c, N)
+    assert close(b, a, 1e-12)
+    # fp32 twin
+    x32, a32 = lat.field32(x.download().astype(np.float32)), lat.field32()
+    lat.Qsw_pm_psi_32(a32, x32)
+    lat.assign_to_64(b, a32, N)
+    assert close(b, a, 2e-5)
+    # solvers: true residual in fp64 on the device
+    for name, run in (("cg_her", lambda: (y.zero(), lat.cg_her(y, x, 20000, 1e-20, 1, N, op="Qsw_pm_psi")[0])[1]),
+                      ("mixed_cg_her", lambda: lat.mixed_cg_her(y, x, 20000, 1e-20, 1, N, op="Qsw_pm_psi")[0]),
+                      ("rg_mixed_cg_her", lambda: lat.rg_mixed_cg_her(y, x, 20000, 1e-20, 1, N, op="Qsw_pm_psi")[0])):
+        assert run() > 0, name
+        lat.op("Qsw_pm_psi", b, y); lat.diff(b, x, b, N)
+        assert lat.square_norm(b, N) <= 1e-20 * lat.square_norm(x, N), name
+    lat.close()
+
+
+def test_t_split_32x64_over_two_contexts_full_size():
+    """configs[3] volume (32^3 x 64) cut in T over two contexts of this process (32 time-slices each: halo gauge links, global
+    parity offset, face pack -> peer copy -> boundary kernels, slab/tile block order on the 30 interior slices) == the unsplit
+    lattice on the oracle, site by site."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    from tmlqcd_amd.hip import multi_Hopping_Matrix
+    if _mem_gb() < 24:
+        pytest.skip("needs ~20 GB of host memory for the oracle's gauge copy")
+    T, L, world = 32, 32, 2
+    Tg = T * world
+    kappa, theta = 0.125, (1.0, 0.0, 0.0, 0.0)
+    g = Oracle(Tg, L, L, L, kappa=kappa, theta=theta, threads=16)
+    g.set_gauge(syn.gauge_field(51, Tg, L, L, L))
+    lats = [Lattice(T, L, L, L, kappa=kappa, theta=theta, nproc_t=world, proc_t=r) for r in range(world)]
+    for r, lat in enumerate(lats):
+        lat.set_gauge(syn.gauge_field(51, T, L, L, L, world, r))
+    Vh = lats[0].Vh
+    for ieo in (0, 1):
+        kg = g.new_field(); kg[:g.Vh] = syn.spinor_field_eo(52, 1 - ieo, Tg, L, L, L)
+        ref = g.new_field()
+        g.Hopping_Matrix(ieo, ref, kg)
+        ks = [lat.field(syn.spinor_field_eo(52, 1 - ieo, T, L, L, L, world, r)) for r, lat in enumerate(lats)]
+        ls = [lat.field() for lat in lats]
+        multi_Hopping_Matrix(lats, ieo, ls, ks)
+        for r in range(world):
+            assert rel_err(ls[r].download(), ref[r * Vh:(r + 1) * Vh]) < TOL, (ieo, r)
+        for f in ks + ls:
+            f.free()
+    for lat in lats:
+        lat.close()
