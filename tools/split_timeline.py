@@ -1,0 +1,17 @@
+"""Run a few split-phase (loopback) stencils for a rocprofv3 kernel trace.  Usage: split_timeline.py L T"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tmlqcd_amd import Lattice  # noqa: E402
+from tmlqcd_amd import synthetic as syn  # noqa: E402
+
+L, T = int(sys.argv[1]), int(sys.argv[2])
+lat = Lattice(T, L, L, L, kappa=0.125, mu=0.01)
+lat.set_gauge(syn.gauge_field(1, T, L, L, L))
+f0 = lat.field(syn.spinor_field_eo(2, 0, T, L, L, L))
+f1, f2 = lat.field(), lat.field()
+lat.set_loopback(1)
+lat.bench_hopping(f0, f1, f2, 20)
+lat.sync()
+lat.close()
