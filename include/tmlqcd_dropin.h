@@ -175,6 +175,10 @@ enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1 };
 void tmlqcd_hip_sw_term(const double kappa, const double c_sw);
 void tmlqcd_hip_sw_invert(const int ieo, const double mu);
 void tmlqcd_hip_set_residency(int mode);
+/* Upper bound on the number of device mirrors kept for host arrays (default 64, also TMLQCD_HIP_MAX_MIRRORS): beyond it the
+ * least recently used mirror whose host copy is current is freed.  Host programs that allocate work fields per solve
+ * (solver/solver_field.c) hand in ever new addresses; mirrors holding device-only data (resident mode) are never dropped. */
+void tmlqcd_hip_set_max_mirrors(int n);
 void tmlqcd_hip_sync_to_host(spinor *field);       /* download the device mirror of `field` if it is newer */
 void tmlqcd_hip_sync_all_to_host(void);
 void tmlqcd_hip_host_modified(spinor *field);      /* the host wrote `field`: drop its device mirror */

@@ -69,6 +69,26 @@ def test_coherent_mode_is_a_plain_drop_in(host):
     assert rel_err(kk, ref2[:N]) < TOL
 
 
+def test_mirror_registry_is_bounded(host):
+    """Ever new host addresses (work fields allocated per solve, solver/solver_field.c): the registry drops the least recently
+    used mirrors whose host copy is current instead of growing; results are unaffected."""
+    stub, d, orc, g, (T, L, V) = host
+    N = V // 2
+    d.tmlqcd_hip_set_max_mirrors.argtypes = [C.c_int]
+    d.tmlqcd_hip_set_max_mirrors(8)
+    ref = orc.new_field()
+    keep = []
+    for i in range(30):
+        k = random_spinor(100 + i, N); l = np.zeros_like(k)
+        keep.append((k, l))                                   # distinct live addresses
+        d.Hopping_Matrix(i & 1, _p(l), _p(k)); orc.Hopping_Matrix(i & 1, ref, k)
+        assert rel_err(l, ref[:N]) < TOL, i
+    k0, l0 = keep[0]                                          # its mirror is long gone: transparently re-created
+    d.Hopping_Matrix(0, _p(l0), _p(k0)); orc.Hopping_Matrix(0, ref, k0)
+    assert rel_err(l0, ref[:N]) < TOL
+    d.tmlqcd_hip_set_max_mirrors(64)
+
+
 def test_globals_are_reread_at_call_time(host):
     stub, d, orc, g, (T, L, V) = host
     N = V // 2

@@ -38,7 +38,11 @@ struct Mirror {
   int kind = TMHIP_FIELD_EO;
   bool dev_valid = false;   // device copy holds the current data
   bool host_valid = true;   // host copy holds the current data
+  unsigned long long last_use = 0;
 };
+unsigned long long g_tick = 0;
+size_t g_mirror_cap = 64;   // TMLQCD_HIP_MAX_MIRRORS: host programs that allocate work fields per solve (solver_field.c) would otherwise
+                            // grow the registry without bound; mirrors whose host copy is current can be dropped at any time
 
 tmhip_ctx *g_ctx = nullptr;
 int g_device = -1;
@@ -101,8 +105,25 @@ void download(tmhip_ctx *c, const void *host, Mirror &m) {
   m.host_valid = true;
 }
 
+// drop the least recently used mirrors that hold nothing the host does not have
+void evict_if_crowded(tmhip_ctx *c, const void *keep) {
+  static bool read_env = false;
+  if (!read_env) { const char *e = getenv("TMLQCD_HIP_MAX_MIRRORS"); if (e && atoi(e) > 8) g_mirror_cap = (size_t)atoi(e); read_env = true; }
+  while (g_reg.size() > g_mirror_cap) {
+    const void *victim = nullptr;
+    unsigned long long oldest = ~0ull;
+    for (auto &kv : g_reg)
+      if (kv.first != keep && kv.second.host_valid && kv.second.last_use < oldest) { oldest = kv.second.last_use; victim = kv.first; }
+    if (!victim) return;   // everything else is device-only data (resident mode): keep it
+    if (g_reg[victim].f) tmhip_field_free(c, g_reg[victim].f);
+    g_reg.erase(victim);
+  }
+}
+
 Mirror &mirror(tmhip_ctx *c, const void *host, int kind) {
+  if (g_reg.find(host) == g_reg.end()) evict_if_crowded(c, host);
   Mirror &m = g_reg[host];
+  m.last_use = ++g_tick;
   if (m.f && m.kind != kind) {   // same host buffer re-used with another shape
     if (m.dev_valid && !m.host_valid) download(c, host, m);
     tmhip_field_free(c, m.f);
@@ -308,6 +329,7 @@ static tmhip_ctx *refresh_clover() {
   return c;
 }
 void tmlqcd_hip_update_clover(void) { g_clover_uploaded = false; }
+void tmlqcd_hip_set_max_mirrors(int n) { if (n >= 8) g_mirror_cap = (size_t)n; }
 /* sw_term(g_gauge_field, kappa, c_sw) (operator/clover_term.c:88) computed in HBM; the host's sw array, if the program
  * has one (init_sw_fields), receives a copy so that host-side consumers (sw_trace, sw_deriv ...) keep working. */
 void tmlqcd_hip_sw_term(const double kappa, const double c_sw) {
