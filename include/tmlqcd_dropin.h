@@ -165,6 +165,13 @@ typedef struct {                                                             /* 
  * after the last deriv_Sb of a force computation, e.g. at the end of det_derivative, monomial/det_monomial.c:56-117). */
 void deriv_Sb(const int ieo, spinor *const l, spinor *const k, hamiltonian_field_t *const hf, const double factor);
 void tmlqcd_hip_flush_derivative(hamiltonian_field_t *const hf);
+/* the clover part of cloverdet_derivative (monomial/cloverdet_monomial.c:67-72,125-147) with swm / swp resident in HBM: replace the
+ * zeroing loop, sw_spinor_eo (operator/clover_deriv.c:252), sw_deriv (:72) and sw_all (operator/clover_accumulate_deriv.c:58) calls;
+ * the derivative follows the same coherent / resident rule as deriv_Sb */
+void tmlqcd_hip_swpm_zero(void);
+void tmlqcd_hip_sw_spinor_eo(const int ieo, const spinor *const kk, const spinor *const ll, const double fac);
+void tmlqcd_hip_sw_deriv(const int ieo, const double mu);
+void tmlqcd_hip_sw_all(hamiltonian_field_t *const hf, const double kappa, const double c_sw);
 
 /* ---- residency control (additions; not in the reference) ------------------- */
 enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1 };

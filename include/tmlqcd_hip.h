@@ -144,6 +144,17 @@ int tmhip_deriv_Sb(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, doub
 int tmhip_derivative_download(tmhip_ctx *ctx, void *df, int accumulate);
 int tmhip_multi_deriv_Sb(int n, tmhip_ctx **ctxs, int ieo, tmhip_field **l, tmhip_field **k, double factor);
 
+/* Clover part of the force (monomial/cloverdet_monomial.c:110-147): the insertion matrices swm / swp (clover_leaf.c:141) are
+ * device-resident; zero them, accumulate the spinor outer products (operator/clover_deriv.c:252) and the tr-log term
+ * (clover_deriv.c:72; needs sw_inv of that parity), then tmhip_sw_all (operator/clover_accumulate_deriv.c:58) adds the sixteen
+ * link derivatives per plane and site to the SAME derivative accumulator tmhip_deriv_Sb uses.  gauge_field = NULL reuses the
+ * lexicographic copy kept by the last tmhip_sw_term.  tmhip_get_swpm returns su3 swm[VOLUME][4] / swp[VOLUME][4].  Single rank. */
+int tmhip_swpm_zero(tmhip_ctx *ctx);
+int tmhip_sw_spinor_eo(tmhip_ctx *ctx, int ieo, tmhip_field *kk, tmhip_field *ll, double fac);
+int tmhip_sw_deriv(tmhip_ctx *ctx, int ieo, double mu);
+int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_field, double kappa, double c_sw);
+int tmhip_get_swpm(tmhip_ctx *ctx, void *swm, void *swp);
+
 /* ---- clover twisted mass (invert_clover_eo.c:63-165) ------
  * The 6x6 site blocks are inputs like the gauge field: `sw` = su3 sw[VOLUME][3][2] from sw_term
  * (operator/clover_term.c:88), `sw_inv` = su3 sw_inv[VOLUME][4][2] from sw_invert(EE, mu)

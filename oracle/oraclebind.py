@@ -51,6 +51,9 @@ def _lib():
         lib.tmo_set_clover.argtypes = [vp, vp, vp]
         lib.tmo_sw_term.argtypes = [vp, vp, d, d]
         lib.tmo_deriv_Sb.argtypes = [vp, i, vp, vp, vp, d]
+        lib.tmo_sw_spinor_eo.argtypes = [vp, i, vp, vp, vp, vp, d]
+        lib.tmo_sw_deriv.argtypes = [vp, i, vp, vp, d]
+        lib.tmo_sw_all.argtypes = [vp, vp, vp, vp, d, d]
         lib.tmo_sw_invert.argtypes = [vp, vp, vp, i, d]
         lib.tmo_sw_invert.restype = i
         lib.tmo_clover_inv.argtypes = [vp, vp, i, d]
@@ -157,6 +160,17 @@ class Oracle:
         """deriv_Sb.c:401: accumulates the hopping part of the fermion force into df [VPR][4][8] (su3adj)."""
         assert df.shape == (self.VPR, 4, 8) and df.flags.c_contiguous
         self.lib.tmo_deriv_Sb(self.h, ieo, _p(l), _p(k), _p(df), factor)
+
+    def sw_spinor_eo(self, ieo, swm, swp, kk, ll, fac):
+        """operator/clover_deriv.c:252; swm / swp: [V][4][3][3][2], accumulated."""
+        self.lib.tmo_sw_spinor_eo(self.h, ieo, _p(swm), _p(swp), _p(kk), _p(ll), fac)
+
+    def sw_deriv(self, ieo, swm, swp, mu):
+        self.lib.tmo_sw_deriv(self.h, ieo, _p(swm), _p(swp), mu)
+
+    def sw_all(self, df, swm, swp, kappa, c_sw):
+        assert df.shape == (self.VPR, 4, 8) and df.flags.c_contiguous
+        self.lib.tmo_sw_all(self.h, _p(df), _p(swm), _p(swp), kappa, c_sw)
 
     def sw_term(self, kappa, c_sw):
         """operator/clover_term.c:88 on the current gauge field -> sw [V][3][2][3][3][2]."""

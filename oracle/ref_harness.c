@@ -129,6 +129,24 @@ double *tmref_derivative(void) {
   }
   return (double *)tmref_df;
 }
+/* Clover part of the force (cloverdet_monomial.c:110-147): swm / swp accumulators (init_swpm, clover_leaf.c:141) and sw_all */
+#ifndef TMREF_NO_CLOVER
+su3 *tmref_swpm(int which) {       /* 0: swm base, 1: swp base; both [VOLUME][4] su3; allocated (zeroed) on first use */
+  init_swpm(VOLUME);
+  return which ? &swp[0][0] : &swm[0][0];
+}
+void tmref_swpm_zero(void) {
+  init_swpm(VOLUME);
+  memset(&swp[0][0], 0, (size_t)4 * VOLUME * sizeof(su3));
+  memset(&swm[0][0], 0, (size_t)4 * VOLUME * sizeof(su3));
+}
+void tmref_sw_all(double kappa, double c_sw) {
+  hamiltonian_field_t hf;
+  (void)tmref_derivative();
+  hf.gaugefield = g_gauge_field; hf.momenta = NULL; hf.derivative = tmref_dfp; hf.update_gauge_copy = 0; hf.traj_counter = 0;
+  sw_all(&hf, kappa, c_sw);
+}
+#endif
 void tmref_deriv_Sb(int ieo, spinor *l, spinor *k, double factor) {
   hamiltonian_field_t hf;
   (void)tmref_derivative();

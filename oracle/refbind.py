@@ -107,6 +107,14 @@ class RefLattice:
         n = self.V * 4 * 8
         return np.frombuffer((C.c_double * n).from_address(self.lib.tmref_derivative()), dtype=np.float64).reshape(self.V, 4, 8)
 
+    def swpm(self):
+        """Views (swm, swp) of the clover-force accumulators, su3 [V][4] as float64 [V][4][3][3][2] (clover_leaf.c:141-172)."""
+        self.lib.tmref_swpm.restype = C.c_void_p
+        self.lib.tmref_swpm.argtypes = [C.c_int]
+        n = self.V * 4 * 18
+        mk = lambda w: np.frombuffer((C.c_double * n).from_address(self.lib.tmref_swpm(w)), dtype=np.float64).reshape(self.V, 4, 3, 3, 2)
+        return mk(0), mk(1)
+
     def rg_mixed_cg_her(self, iP, iQ, delta, max_iter, eps_sq, rel_prec, debug=0):
         """solver/rg_mixed_cg_her.c:180 on g_spinor_field[iP], [iQ] (half-spinor build only)."""
         return self.lib.tmref_rg_mixed_cg_her(self.sp(iP), self.sp(iQ), delta, max_iter, eps_sq, rel_prec, self.V // 2, debug)

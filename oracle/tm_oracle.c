@@ -929,6 +929,126 @@ void tmo_deriv_Sb(tmo_lattice *lat, int ieo, const tmo_spinor *l, const tmo_spin
   }
 }
 
+/* ---------------------------------------------------------------- clover part of the fermion force
+ * (monomial/cloverdet_monomial.c:110-147 calls, after the solves: sw_spinor_eo x2, sw_deriv, sw_all).
+ * swm / swp: su3 [V][4] each, lexicographic site (operator/clover_leaf.c:141-172). */
+/* operator/clover_deriv.c:252-318: insertion matrices from the spinor outer products on the sites of parity ieo */
+void tmo_sw_spinor_eo(tmo_lattice *lat, int ieo, tmo_su3 *swm, tmo_su3 *swp, const tmo_spinor *kk, const tmo_spinor *ll, double fac) {
+  const int ioff = ieo == 0 ? 0 : lat->VPR / 2, Vh = lat->V / 2;
+#pragma omp parallel for
+  for (int icx = ioff; icx < Vh + ioff; icx++) {
+    const int x = lat->eo2lexic[icx];
+    const tmo_spinor *r = kk + (icx - ioff), *s = ll + (icx - ioff);
+    const tmo_su3_vector *ra[4] = {&r->s0, &r->s0, &r->s1, &r->s1}, *sa[4] = {&s->s0, &s->s1, &s->s1, &s->s0};   /* v0..v3 */
+    const tmo_su3_vector *rb[4] = {&r->s2, &r->s2, &r->s3, &r->s3}, *sb[4] = {&s->s2, &s->s3, &s->s3, &s->s2};   /* u0..u3 */
+    for (int n = 0; n < 4; n++) {
+      const double _Complex *pr = &ra[n]->c0, *ps = &sa[n]->c0, *qr = &rb[n]->c0, *qs = &sb[n]->c0;
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+          const double _Complex v = pr[a] * conj(ps[b]), u = -qr[a] * conj(qs[b]);   /* su3.h:683-703 (u carries the gamma5 sign) */
+          M33(&swm[4 * (size_t)x + n])[a][b] += fac * (u - v);
+          M33(&swp[4 * (size_t)x + n])[a][b] += fac * (u + v);
+        }
+    }
+  }
+}
+/* operator/clover_deriv.c:72-153: the tr log part, from sw_inv of the sites of parity ieo */
+void tmo_sw_deriv(tmo_lattice *lat, int ieo, tmo_su3 *swm, tmo_su3 *swp, double mu) {
+  const int ioff = ieo == 0 ? 0 : lat->VPR / 2, Vh = lat->V / 2;
+  const double fac = fabs(mu) > 0. ? 0.5 : 1.0;
+#pragma omp parallel for
+  for (int icy = 0; icy < Vh; icy++) {
+    const int x = lat->eo2lexic[icy + ioff];
+    for (int set = 0; set < (fabs(mu) > 0. ? 2 : 1); set++) {
+      const tmo_su3 *w = lat->sw_inv + 8 * (size_t)(icy + set * Vh);
+      for (int n = 0; n < 4; n++)
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) {
+            const double _Complex lp = M33(&w[2 * n + 1])[a][b] + M33(&w[2 * n])[a][b], lm = M33(&w[2 * n + 1])[a][b] - M33(&w[2 * n])[a][b];
+            M33(&swm[4 * (size_t)x + n])[a][b] += fac * lm;
+            M33(&swp[4 * (size_t)x + n])[a][b] += fac * lp;
+          }
+    }
+  }
+}
+/* su3adj.h:164-172 */
+static inline void tmo_trace_lambda_add(double *d, double c, const tmo_su3 *a) {
+  d[0] += c * (-cimag(a->c10) - cimag(a->c01));
+  d[1] += c * (+creal(a->c10) - creal(a->c01));
+  d[2] += c * (-cimag(a->c00) + cimag(a->c11));
+  d[3] += c * (-cimag(a->c20) - cimag(a->c02));
+  d[4] += c * (+creal(a->c20) - creal(a->c02));
+  d[5] += c * (-cimag(a->c21) - cimag(a->c12));
+  d[6] += c * (+creal(a->c21) - creal(a->c12));
+  d[7] += c * ((-cimag(a->c00) - cimag(a->c11) + 2.0 * cimag(a->c22)) * 0.577350269189625);
+}
+static inline void m33_dag(tmo_su3 *u, const tmo_su3 *v) {
+  tmo_su3 r;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M33(&r)[i][j] = conj(M33(v)[j][i]);
+  *u = r;
+}
+/* operator/clover_accumulate_deriv.c:58-205: sixteen link derivatives per plane and site from the four clover leaves with the
+ * insertion matrix vis[k][l] built from swm / swp.  The site loop scatters to neighbouring links, so it runs serially here
+ * (the reference uses atomic updates under OpenMP); df is su3adj [VPR][4] as 8 doubles per link. */
+void tmo_sw_all(tmo_lattice *lat, double *df, const tmo_su3 *swm, const tmo_su3 *swp, double kappa, double c_sw) {
+  const double c = -2. * (kappa * c_sw / 8.);
+  const int *iup = lat->iup, *idn = lat->idn;
+#define DF(ix, mu) (df + ((size_t)4 * (ix) + (mu)) * 8)
+  for (int x = 0; x < lat->V; x++) {
+    tmo_su3 vis[4][4], v1, v2, vv1, vv2, plaq;
+    const tmo_su3 *m = swm + 4 * (size_t)x, *p = swp + 4 * (size_t)x;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        M33(&vis[0][1])[a][b] = -I * (M33(&m[1])[a][b] + M33(&m[3])[a][b]);
+        M33(&vis[0][2])[a][b] = M33(&m[1])[a][b] - M33(&m[3])[a][b];
+        M33(&vis[0][3])[a][b] = I * (M33(&m[2])[a][b] - M33(&m[0])[a][b]);
+        M33(&vis[2][3])[a][b] = -I * (M33(&p[1])[a][b] + M33(&p[3])[a][b]);
+        M33(&vis[1][3])[a][b] = M33(&p[3])[a][b] - M33(&p[1])[a][b];
+        M33(&vis[1][2])[a][b] = I * (M33(&p[2])[a][b] - M33(&p[0])[a][b]);
+      }
+    for (int k = 0; k < 4; k++)
+      for (int l = k + 1; l < 4; l++) {   /* anti-hermitian part, clover_accumulate_deriv.c:84-96 */
+        m33_dag(&v1, &vis[k][l]);
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) M33(&vis[k][l])[a][b] -= M33(&v1)[a][b];
+      }
+    for (int k = 0; k < 4; k++)
+      for (int l = k + 1; l < 4; l++) {
+        const int xpk = iup[4 * x + k], xpl = iup[4 * x + l], xmk = idn[4 * x + k], xml = idn[4 * x + l];
+        const int xpkml = idn[4 * xpk + l], xplmk = idn[4 * xpl + k], xmkml = idn[4 * xml + k];
+        const tmo_su3 *V = &vis[k][l], *w1, *w2, *w3, *w4;
+        /* leaf 1 */
+        w1 = glink(lat, x, k); w2 = glink(lat, xpk, l); w3 = glink(lat, xpl, k); w4 = glink(lat, x, l);
+        m33_mul(&v1, w1, 0, w2, 0, 0); m33_mul(&v2, w4, 0, w3, 0, 0); m33_mul(&plaq, &v1, 0, &v2, 1, 0);
+        m33_mul(&vv1, &plaq, 0, V, 0, 0);                              tmo_trace_lambda_add(DF(x, k), c, &vv1);
+        m33_mul(&vv2, w1, 1, &vv1, 0, 0); m33_mul(&vv1, &vv2, 0, w1, 0, 0);  tmo_trace_lambda_add(DF(xpk, l), c, &vv1);
+        m33_mul(&vv2, V, 0, &plaq, 0, 0); m33_dag(&vv1, &vv2);         tmo_trace_lambda_add(DF(x, l), c, &vv1);
+        m33_mul(&vv2, w4, 1, &vv1, 0, 0); m33_mul(&vv1, &vv2, 0, w4, 0, 0);  tmo_trace_lambda_add(DF(xpl, k), c, &vv1);
+        /* leaf 2 */
+        w1 = glink(lat, x, l); w2 = glink(lat, xplmk, k); w3 = glink(lat, xmk, l); w4 = glink(lat, xmk, k);
+        m33_mul(&v1, w1, 0, w2, 1, 0); m33_mul(&v2, w3, 1, w4, 0, 0); m33_mul(&plaq, &v1, 0, &v2, 0, 0);
+        m33_mul(&vv1, &plaq, 0, V, 0, 0);                              tmo_trace_lambda_add(DF(x, l), c, &vv1);
+        m33_dag(&vv1, &v1); m33_mul(&vv2, &vv1, 0, V, 1, 0); m33_mul(&vv1, &vv2, 0, &v2, 1, 0);  tmo_trace_lambda_add(DF(xplmk, k), c, &vv1);
+        m33_mul(&vv2, w3, 0, &vv1, 0, 0); m33_mul(&vv1, &vv2, 0, w3, 1, 0);  tmo_trace_lambda_add(DF(xmk, l), c, &vv1);
+        m33_dag(&vv2, &vv1);                                           tmo_trace_lambda_add(DF(xmk, k), c, &vv2);
+        /* leaf 3 */
+        w1 = glink(lat, xmk, k); w2 = glink(lat, xmkml, l); w3 = glink(lat, xmkml, k); w4 = glink(lat, xml, l);
+        m33_mul(&v1, w2, 0, w1, 0, 0); m33_mul(&v2, w3, 0, w4, 0, 0);
+        m33_mul(&vv1, w1, 0, V, 1, 0); m33_mul(&vv2, &vv1, 0, &v2, 1, 0); m33_mul(&vv1, &vv2, 0, w2, 0, 0);  tmo_trace_lambda_add(DF(xmk, k), c, &vv1);
+        m33_mul(&vv2, w2, 0, &vv1, 0, 0); m33_mul(&vv1, &vv2, 0, w2, 1, 0);  tmo_trace_lambda_add(DF(xmkml, l), c, &vv1);
+        m33_dag(&vv2, &vv1);                                           tmo_trace_lambda_add(DF(xmkml, k), c, &vv2);
+        m33_mul(&vv1, w3, 1, &vv2, 0, 0); m33_mul(&vv2, &vv1, 0, w3, 0, 0);  tmo_trace_lambda_add(DF(xml, l), c, &vv2);
+        /* leaf 4 */
+        w1 = glink(lat, xml, l); w2 = glink(lat, xml, k); w3 = glink(lat, xpkml, l); w4 = glink(lat, x, k);
+        m33_mul(&v1, w1, 1, w2, 0, 0); m33_mul(&v2, w3, 0, w4, 1, 0);
+        m33_mul(&vv1, w1, 0, V, 1, 0); m33_mul(&vv2, &vv1, 0, &v2, 1, 0); m33_mul(&vv1, &vv2, 0, w2, 1, 0);  tmo_trace_lambda_add(DF(xml, l), c, &vv1);
+        m33_dag(&vv2, &vv1);                                           tmo_trace_lambda_add(DF(xml, k), c, &vv2);
+        m33_mul(&vv1, w2, 1, &vv2, 0, 0); m33_mul(&vv2, &vv1, 0, w2, 0, 0);  tmo_trace_lambda_add(DF(xpkml, l), c, &vv2);
+        m33_dag(&vv2, &v2); m33_mul(&vv1, &vv2, 0, &v1, 1, 0); m33_mul(&vv2, &vv1, 0, V, 1, 0);  tmo_trace_lambda_add(DF(x, k), c, &vv2);
+      }
+  }
+#undef DF
+}
+
 /* ---------------------------------------------------------------- linalg */
 /* Per-thread Kahan partials summed in thread order, as the reference does with
    g_omp_acc_re (linalg/square_norm.c:299-304). */

@@ -147,3 +147,108 @@ def test_deriv_Sb_drop_in_symbol(host_stub):
     assert rel_err(df_host, start + ref[:V]) < TOL
     d.tmlqcd_hip_set_residency(0)
     d.tmlqcd_hip_finalize()
+
+
+@pytest.mark.parametrize("dims,mu", [((4, 4, 6, 4), 0.02), ((2, 2, 2, 2), 0.0), ((8, 6, 4, 12), 0.3)])
+def test_clover_force_chain_against_oracle(dims, mu):
+    """The clover part of cloverdet_derivative (monomial/cloverdet_monomial.c:110-147) on the device: sw_spinor_eo on both
+    parities, sw_deriv(EE, mu), then sw_all adding into the same derivative field deriv_Sb uses -- against the oracle, which
+    is bit-exact against operator/clover_deriv.c and operator/clover_accumulate_deriv.c (tests/test_oracle_vs_ref.py)."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T, LX, LY, LZ = dims
+    kappa, c_sw, theta = 0.131, 1.37, (1.0, 0.5, -0.25, 0.125)
+    orc = Oracle(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta, threads=8)
+    lat = Lattice(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta)
+    g = random_gauge(201, orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    sw = orc.sw_term(kappa, c_sw); swi, _ = orc.sw_invert(sw, 0, mu)
+    orc.set_clover(sw, swi)
+    lat.sw_term(g, kappa, c_sw); lat.sw_invert(0, mu)
+    N, V = orc.Vh, orc.V
+    fh = [random_spinor(210 + i, N) for i in range(4)]
+    fo = []
+    for a in fh:
+        b = orc.new_field(); b[:N] = a; fo.append(b)
+    fd = [lat.field(a) for a in fh]
+    swm, swp = np.zeros((V, 4, 3, 3, 2)), np.zeros((V, 4, 3, 3, 2))
+    orc.sw_spinor_eo(0, swm, swp, fo[2], fo[3], 0.7)
+    orc.sw_spinor_eo(1, swm, swp, fo[0], fo[1], 0.7)
+    orc.sw_deriv(0, swm, swp, mu)
+    lat.swpm_zero()
+    lat.sw_spinor_eo(0, fd[2], fd[3], 0.7)
+    lat.sw_spinor_eo(1, fd[0], fd[1], 0.7)
+    lat.sw_deriv(0, mu)
+    gm, gp = lat.get_swpm()
+    assert rel_err(gm, swm) < TOL and rel_err(gp, swp) < TOL
+    df = np.zeros((orc.VPR, 4, 8))
+    orc.deriv_Sb(1, fo[0], fo[2], df, 0.7)            # the hopping part goes into the same accumulator first
+    orc.sw_all(df, swm, swp, kappa, c_sw)
+    lat.derivative_zero()
+    lat.deriv_Sb(1, fd[0], fd[2], 0.7)
+    lat.sw_all(kappa, c_sw)                           # lexicographic links kept from sw_term
+    assert rel_err(lat.derivative(), df[:V]) < 4 * TOL     # atomics: the sum order of the <= 16 contributions per link is not fixed
+    lat.derivative_zero()
+    lat.sw_all(kappa, c_sw, gauge=g)                  # ... or handed over again
+    ref2 = np.zeros((orc.VPR, 4, 8)); orc.sw_all(ref2, swm, swp, kappa, c_sw)
+    assert rel_err(lat.derivative(), ref2[:V]) < 4 * TOL
+    lat.close()
+
+
+def test_clover_force_through_the_drop_in(host_stub):
+    """cloverdet_derivative's clover statements through the drop-in helpers on host arrays: the contribution lands in
+    hf->derivative next to deriv_Sb's (coherent mode)."""
+    from oracle.oraclebind import Oracle
+    stub, d = host_stub
+    VP = C.c_void_p
+    T, L = 4, 4
+    kappa, mu, c_sw, theta = 0.127, 0.01, 1.5, (1.0, 0.0, 0.0, 0.0)
+    V = T * L ** 3
+    N = V // 2
+    gptr = stub.stub_init(T, L, L, L)
+    g = random_gauge(301, V)
+    C.memmove(gptr, g.ctypes.data_as(VP), g.nbytes)
+    stub.stub_boundary(kappa, *theta)
+    stub.stub_set_mu(mu)
+    stub.stub_init_clover.restype = VP
+    stub.stub_init_clover.argtypes = [C.c_int]
+    stub.stub_init_clover(0)
+    orc = Oracle(T, L, L, L, kappa=kappa, mu=mu, theta=theta, threads=4)
+    orc.set_gauge(g)
+    sw = orc.sw_term(kappa, c_sw); swi, _ = orc.sw_invert(sw, 0, mu)
+    orc.set_clover(sw, swi)
+
+    class HF(C.Structure):
+        _fields_ = [("gaugefield", VP), ("momenta", VP), ("derivative", VP), ("update_gauge_copy", C.c_int), ("traj_counter", C.c_int)]
+    df_host = np.zeros((V, 4, 8))
+    drows = (VP * V)(*[df_host.ctypes.data + 4 * 8 * 8 * i for i in range(V)])
+    grows = (VP * V)(*[gptr + 4 * 144 * i for i in range(V)])
+    hf = HF(C.cast(grows, VP), None, C.cast(drows, VP), 0, 0)
+    d.tmlqcd_hip_sw_term.argtypes = [C.c_double, C.c_double]
+    d.tmlqcd_hip_sw_invert.argtypes = [C.c_int, C.c_double]
+    d.tmlqcd_hip_sw_spinor_eo.argtypes = [C.c_int, VP, VP, C.c_double]
+    d.tmlqcd_hip_sw_deriv.argtypes = [C.c_int, C.c_double]
+    d.tmlqcd_hip_sw_all.argtypes = [C.POINTER(HF), C.c_double, C.c_double]
+    d.deriv_Sb.argtypes = [C.c_int, VP, VP, C.POINTER(HF), C.c_double]
+    d.tmlqcd_hip_sw_term(kappa, c_sw)
+    d.tmlqcd_hip_sw_invert(0, mu)
+    w = [random_spinor(310 + i, N) for i in range(4)]
+    wo = []
+    for a in w:
+        b = orc.new_field(); b[:N] = a; wo.append(b)
+    p = lambda a: a.ctypes.data_as(VP)
+    d.tmlqcd_hip_swpm_zero()                                       # cloverdet_monomial.c:67-72
+    d.deriv_Sb(1, p(w[0]), p(w[2]), C.byref(hf), 0.8)              # :115
+    d.deriv_Sb(0, p(w[3]), p(w[1]), C.byref(hf), 0.8)              # :121
+    d.tmlqcd_hip_sw_spinor_eo(0, p(w[2]), p(w[3]), 0.8)            # :125
+    d.tmlqcd_hip_sw_spinor_eo(1, p(w[0]), p(w[1]), 0.8)            # :128
+    d.tmlqcd_hip_sw_deriv(0, mu)                                   # :134
+    d.tmlqcd_hip_sw_all(C.byref(hf), kappa, c_sw)                  # :147
+    ref = np.zeros((orc.VPR, 4, 8))
+    swm, swp = np.zeros((V, 4, 3, 3, 2)), np.zeros((V, 4, 3, 3, 2))
+    orc.deriv_Sb(1, wo[0], wo[2], ref, 0.8); orc.deriv_Sb(0, wo[3], wo[1], ref, 0.8)
+    orc.sw_spinor_eo(0, swm, swp, wo[2], wo[3], 0.8); orc.sw_spinor_eo(1, swm, swp, wo[0], wo[1], 0.8)
+    orc.sw_deriv(0, swm, swp, mu)
+    orc.sw_all(ref, swm, swp, kappa, c_sw)
+    assert rel_err(df_host, ref[:V]) < 4 * TOL
+    d.tmlqcd_hip_finalize()

@@ -98,6 +98,19 @@ for name in ("assign_mul_one_sw_pm_imu", "assign_mul_one_sw_pm_imu_inv"):
 for ieo in (0, 1):
     o.assign_mul_one_sw_pm_imu(ieo, q, k, 0.02); lib.assign_mul_one_sw_pm_imu(ieo, sp(3), sp(0), 0.02); same(q, 3, "assign_mul_one_sw_pm_imu")
 o.assign_mul_one_sw_pm_imu_inv(0, q, k, 0.02); lib.assign_mul_one_sw_pm_imu_inv(0, sp(3), sp(0), 0.02); same(q, 3, "assign_mul_one_sw_pm_imu_inv")
+# clover part of the force (operator/clover_deriv.c:72,252; operator/clover_accumulate_deriv.c:58)
+lib.sw_spinor_eo.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double]; lib.sw_deriv.argtypes = [C.c_int, C.c_double]
+lib.tmref_sw_all.argtypes = [C.c_double, C.c_double]
+lib.tmref_swpm_zero()
+lib.sw_spinor_eo(0, sp(0), sp(1), 0.7); lib.sw_spinor_eo(1, sp(1), sp(0), -0.3); lib.sw_deriv(0, 0.02)
+swm_r, swp_r = r.swpm()
+swm = np.zeros((V, 4, 3, 3, 2)); swp = np.zeros_like(swm)
+o.sw_spinor_eo(0, swm, swp, k, l, 0.7); o.sw_spinor_eo(1, swm, swp, l, k, -0.3); o.sw_deriv(0, swm, swp, 0.02)
+assert np.array_equal(swm, swm_r) and np.array_equal(swp, swp_r) and np.abs(swp).max() > 0, "sw_spinor_eo / sw_deriv"
+d0 = r.derivative().copy()
+lib.tmref_sw_all(kappa, 1.37)
+dfc = np.zeros((o.VPR, 4, 8)); o.sw_all(dfc, swm, swp, kappa, 1.37)
+assert np.array_equal(dfc[:V], r.derivative() - d0) or np.abs(dfc[:V] - (r.derivative() - d0)).max() < 1e-13 * np.abs(dfc).max(), "sw_all"
 lib.Msw_full.argtypes = [C.c_void_p] * 4; lib.Msw_full.restype = None
 en, on = o.new_field(), o.new_field()
 o.Msw_full(en, on, k, l); lib.Msw_full(sp(6), sp(7), sp(0), sp(1)); same(en, 6, "Msw_full even"); same(on, 7, "Msw_full odd")

@@ -337,6 +337,151 @@ __global__ __launch_bounds__(256) void swinv_unsort_kernel(v2d *__restrict__ raw
   for (int e = 0; e < 72; e++) dst[e] = src[(size_t)e * gs];
 }
 
+// ------------------------------------------------------------------ clover part of the fermion force
+// (cloverdet_monomial.c:110-147: sw_spinor_eo x2, sw_deriv, sw_all).  swm / swp live in ctx->swpm as [2][4][9][V] with
+// site index s = parity * Vh + e/o index.
+__device__ __forceinline__ v2d cf_cmulc(v2d a, v2d b) { return v2d{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }   // a conj(b)
+
+// operator/clover_deriv.c:252-318: thread = site of parity ieo; u carries the gamma5 sign (_mvector_tensor_vector)
+__global__ __launch_bounds__(128) void sw_spinor_eo_kernel(v2d *__restrict__ swpm, const v2d *__restrict__ kk, const v2d *__restrict__ ll, int ns,
+                                                           int Vh, int V, int ieo, double fac) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= Vh) return;
+  const size_t s = (size_t)ieo * Vh + i;
+  v2d r[4][3], q[4][3];
+#pragma unroll
+  for (int sp = 0; sp < 4; sp++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) { r[sp][c] = kk[(size_t)(3 * sp + c) * ns + i]; q[sp][c] = ll[(size_t)(3 * sp + c) * ns + i]; }
+  const int ra[4] = {0, 0, 1, 1}, sa[4] = {0, 1, 1, 0};     // v_n = r_{ra} (x) s_{sa}^dagger, u_n = -r_{ra+2} (x) s_{sa+2}^dagger
+#pragma unroll
+  for (int n = 0; n < 4; n++)
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const v2d v = cf_cmulc(r[ra[n]][a], q[sa[n]][b]), w = cf_cmulc(r[ra[n] + 2][a], q[sa[n] + 2][b]);
+        const v2d u = v2d{-w.x, -w.y};
+        v2d *pm = swpm + ((size_t)(0 * 4 + n) * 9 + 3 * a + b) * V + s, *pp = swpm + ((size_t)(1 * 4 + n) * 9 + 3 * a + b) * V + s;
+        const v2d m0 = *pm, p0 = *pp;
+        *pm = v2d{m0.x + fac * (u.x - v.x), m0.y + fac * (u.y - v.y)};
+        *pp = v2d{p0.x + fac * (u.x + v.x), p0.y + fac * (u.y + v.y)};
+      }
+}
+
+// operator/clover_deriv.c:72-153: thread = (site of parity ieo, n); sw_inv blocks [set][2n + b]
+__global__ __launch_bounds__(256) void sw_deriv_kernel(v2d *__restrict__ swpm, const v2d *__restrict__ swi, int gs, int Vh, int V, int ieo, int nsets,
+                                                       double fac) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Vh) return;
+  const int n = blockIdx.y;
+  const size_t s = (size_t)ieo * Vh + i;
+#pragma unroll
+  for (int e = 0; e < 9; e++) {
+    v2d lm = v2d{0.0, 0.0}, lp = v2d{0.0, 0.0};
+    for (int set = 0; set < nsets; set++) {
+      const v2d w0 = swi[((size_t)set * 72 + (size_t)(2 * n) * 9 + e) * gs + i], w1 = swi[((size_t)set * 72 + (size_t)(2 * n + 1) * 9 + e) * gs + i];
+      lp += w1 + w0; lm += w1 - w0;
+    }
+    v2d *pm = swpm + ((size_t)(0 * 4 + n) * 9 + e) * V + s, *pp = swpm + ((size_t)(1 * 4 + n) * 9 + e) * V + s;
+    const v2d m0 = *pm, p0 = *pp;
+    *pm = v2d{m0.x + fac * lm.x, m0.y + fac * lm.y};
+    *pp = v2d{p0.x + fac * lp.x, p0.y + fac * lp.y};
+  }
+}
+
+__device__ __forceinline__ M3 m3_dag(const M3 &a) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) r.e[3 * i + j] = m3_conj(a.e[3 * j + i]);
+  return r;
+}
+// su3adj.h:164-172 scattered with atomics: neighbouring sites contribute to the same link (the reference's _nonlocal update)
+__device__ __forceinline__ void tl_atomic_add(double *deriv, int Vh, int par, int idx, int mu, double c, const M3 &a) {
+  double *d = deriv + ((size_t)par * 32 + (size_t)mu * 8) * Vh + idx;
+  const size_t st = Vh;
+  atomicAdd(d + 0 * st, c * (-a.e[3].y - a.e[1].y));
+  atomicAdd(d + 1 * st, c * (+a.e[3].x - a.e[1].x));
+  atomicAdd(d + 2 * st, c * (-a.e[0].y + a.e[4].y));
+  atomicAdd(d + 3 * st, c * (-a.e[6].y - a.e[2].y));
+  atomicAdd(d + 4 * st, c * (+a.e[6].x - a.e[2].x));
+  atomicAdd(d + 5 * st, c * (-a.e[7].y - a.e[5].y));
+  atomicAdd(d + 6 * st, c * (+a.e[7].x - a.e[5].x));
+  atomicAdd(d + 7 * st, c * ((-a.e[0].y - a.e[4].y + 2.0 * a.e[8].y) * 0.577350269189625));
+}
+
+// operator/clover_accumulate_deriv.c:58-205: thread = (lexicographic site x, plane (k,l)); sixteen link derivatives from the
+// four leaves with the insertion matrix vis[k][l]
+__global__ __launch_bounds__(64) void sw_all_kernel(const v2d *__restrict__ raw, const v2d *__restrict__ swpm, double *__restrict__ deriv, LexGeom g,
+                                                    int Vh, double c) {
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  if (x >= g.V) return;
+  const int p = blockIdx.y;
+  const int k = p < 3 ? 0 : (p < 5 ? 1 : 2), l = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
+  int cd[4];
+  int r = x;
+  cd[3] = r % g.LZ; r /= g.LZ; cd[2] = r % g.LY; r /= g.LY; cd[1] = r % g.LX; cd[0] = r / g.LX;
+  const int p0 = (cd[0] + cd[1] + cd[2] + cd[3]) & 1, p1 = 1 - p0;
+  auto at = [&](int dk, int dl) {
+    int d[4] = {cd[0], cd[1], cd[2], cd[3]};
+    d[k] += dk; d[l] += dl;
+    return lex_index(g, d[0], d[1], d[2], d[3]);
+  };
+  const int xpk = at(1, 0), xpl = at(0, 1), xmk = at(-1, 0), xml = at(0, -1), xpkml = at(1, -1), xplmk = at(-1, 1), xmkml = at(-1, -1);
+  // vis[k][l] (clover_accumulate_deriv.c:73-96): (a, b, mode) = which two of the four matrices of swm (planes 0l) / swp (planes kl, k>0)
+  const size_t s = (size_t)p0 * Vh + (x >> 1);
+  const int set = p < 3 ? 0 : 1;
+  auto ld = [&](int n) { M3 mtx; for (int e = 0; e < 9; e++) mtx.e[e] = swpm[((size_t)(set * 4 + n) * 9 + e) * g.V + s]; return mtx; };
+  M3 V;
+  {
+    // p: 0 (01) -i(m1+m3), 1 (02) m1-m3, 2 (03) i(m2-m0), 3 (12) i(p2-p0), 4 (13) p3-p1, 5 (23) -i(p1+p3)
+    const bool diag = (p == 2 || p == 3);
+    const M3 A = ld(diag ? 2 : (p == 4 ? 3 : 1)), B = ld(diag ? 0 : (p == 4 ? 1 : 3));
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+      const v2d sum = A.e[e] + B.e[e], dif = A.e[e] - B.e[e];
+      if (p == 0 || p == 5) V.e[e] = v2d{sum.y, -sum.x};            // -i (A + B)
+      else if (p == 1 || p == 4) V.e[e] = dif;                        //  A - B
+      else V.e[e] = v2d{-dif.y, dif.x};                               //  i (A - B)
+    }
+    const M3 Vd = m3_dag(V);
+#pragma unroll
+    for (int e = 0; e < 9; e++) V.e[e] -= Vd.e[e];
+  }
+  M3 v1, v2, vv1, vv2, plaq, w1, w2, w3, w4;
+  const int ix = x >> 1;
+  // leaf 1
+  w1 = m3_load(raw, x, k); w2 = m3_load(raw, xpk, l); w3 = m3_load(raw, xpl, k); w4 = m3_load(raw, x, l);
+  v1 = m3_mul<false, false>(w1, w2); v2 = m3_mul<false, false>(w4, w3); plaq = m3_mul<false, true>(v1, v2);
+  vv1 = m3_mul<false, false>(plaq, V);                                           tl_atomic_add(deriv, Vh, p0, ix, k, c, vv1);
+  vv2 = m3_mul<true, false>(w1, vv1); vv1 = m3_mul<false, false>(vv2, w1);       tl_atomic_add(deriv, Vh, p1, xpk >> 1, l, c, vv1);
+  vv2 = m3_mul<false, false>(V, plaq); vv1 = m3_dag(vv2);                        tl_atomic_add(deriv, Vh, p0, ix, l, c, vv1);
+  vv2 = m3_mul<true, false>(w4, vv1); vv1 = m3_mul<false, false>(vv2, w4);       tl_atomic_add(deriv, Vh, p1, xpl >> 1, k, c, vv1);
+  // leaf 2
+  w1 = m3_load(raw, x, l); w2 = m3_load(raw, xplmk, k); w3 = m3_load(raw, xmk, l); w4 = m3_load(raw, xmk, k);
+  v1 = m3_mul<false, true>(w1, w2); v2 = m3_mul<true, false>(w3, w4); plaq = m3_mul<false, false>(v1, v2);
+  vv1 = m3_mul<false, false>(plaq, V);                                           tl_atomic_add(deriv, Vh, p0, ix, l, c, vv1);
+  vv1 = m3_dag(v1); vv2 = m3_mul<false, true>(vv1, V); vv1 = m3_mul<false, true>(vv2, v2);   tl_atomic_add(deriv, Vh, p0, xplmk >> 1, k, c, vv1);
+  vv2 = m3_mul<false, false>(w3, vv1); vv1 = m3_mul<false, true>(vv2, w3);       tl_atomic_add(deriv, Vh, p1, xmk >> 1, l, c, vv1);
+  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, Vh, p1, xmk >> 1, k, c, vv2);
+  // leaf 3
+  w1 = m3_load(raw, xmk, k); w2 = m3_load(raw, xmkml, l); w3 = m3_load(raw, xmkml, k); w4 = m3_load(raw, xml, l);
+  v2 = m3_mul<false, false>(w3, w4);
+  vv1 = m3_mul<false, true>(w1, V); vv2 = m3_mul<false, true>(vv1, v2); vv1 = m3_mul<false, false>(vv2, w2);   tl_atomic_add(deriv, Vh, p1, xmk >> 1, k, c, vv1);
+  vv2 = m3_mul<false, false>(w2, vv1); vv1 = m3_mul<false, true>(vv2, w2);       tl_atomic_add(deriv, Vh, p0, xmkml >> 1, l, c, vv1);
+  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, Vh, p0, xmkml >> 1, k, c, vv2);
+  vv1 = m3_mul<true, false>(w3, vv2); vv2 = m3_mul<false, false>(vv1, w3);       tl_atomic_add(deriv, Vh, p1, xml >> 1, l, c, vv2);
+  // leaf 4
+  w1 = m3_load(raw, xml, l); w2 = m3_load(raw, xml, k); w3 = m3_load(raw, xpkml, l); w4 = m3_load(raw, x, k);
+  v1 = m3_mul<true, false>(w1, w2); v2 = m3_mul<false, true>(w3, w4);
+  vv1 = m3_mul<false, true>(w1, V); vv2 = m3_mul<false, true>(vv1, v2); vv1 = m3_mul<false, true>(vv2, w2);    tl_atomic_add(deriv, Vh, p1, xml >> 1, l, c, vv1);
+  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, Vh, p1, xml >> 1, k, c, vv2);
+  vv1 = m3_mul<true, false>(w2, vv2); vv2 = m3_mul<false, false>(vv1, w2);       tl_atomic_add(deriv, Vh, p0, xpkml >> 1, l, c, vv2);
+  vv2 = m3_dag(v2); vv1 = m3_mul<false, true>(vv2, v1); vv2 = m3_mul<false, true>(vv1, V);   tl_atomic_add(deriv, Vh, p0, ix, k, c, vv2);
+}
+
 static int need64(const tmhip_field *f, const char *who) {
   if (!f || f->kind != TMHIP_FIELD_EO || f->prec != 0) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity fp64 field\n", who); return 1; }
   return 0;
@@ -403,8 +548,9 @@ int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c
   TMHIP_CHECK(hipSetDevice(ctx->device));
   if (clover_alloc(ctx)) return 1;
   const size_t gbytes = (size_t)ctx->VPR * 4 * 9 * sizeof(v2d), fbytes = (size_t)6 * 9 * ctx->V * sizeof(v2d);
-  void *raw = nullptr, *F = nullptr;
-  TMHIP_CHECK(hipMalloc(&raw, gbytes));
+  void *F = nullptr;
+  if (!ctx->gauge_raw) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge_raw, gbytes));   // kept: the clover force (tmhip_sw_all) walks the same links
+  void *raw = ctx->gauge_raw;
   TMHIP_CHECK(hipMalloc(&F, fbytes));
   TMHIP_CHECK(hipMemcpyAsync(raw, gauge_host, gbytes, hipMemcpyHostToDevice, ctx->stream));
   LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, ctx->g.nproc_t > 1 ? 1 : 0};
@@ -414,7 +560,7 @@ int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c
   TMHIP_CHECK(hipGetLastError());
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   TMHIP_CHECK(hipFree(F));
-  TMHIP_CHECK(hipFree(raw));
+  ctx->gauge_raw_valid = true;
   ctx->sw_set = true;
   ctx->clover_set = false;     // sw_inv no longer matches
   ctx->clover32_set = false;
@@ -467,6 +613,99 @@ int tmhip_get_clover(tmhip_ctx *ctx, void *sw_host, void *sw_inv_host) {
   }
   TMHIP_CHECK(hipGetLastError());
   TMHIP_CHECK(hipFree(raw));
+  return 0;
+}
+
+/* ---- clover part of the fermion force (SURVEY §8f rank 3 on top of the clover row): device-resident swm / swp -------------- */
+static int swpm_alloc(tmhip_ctx *ctx) {
+  if (ctx->swpm) return 0;
+  const size_t bytes = (size_t)2 * 4 * 9 * ctx->V * sizeof(v2d);
+  TMHIP_CHECK(hipMalloc((void **)&ctx->swpm, bytes));
+  TMHIP_CHECK(hipMemsetAsync(ctx->swpm, 0, bytes, ctx->stream));
+  return 0;
+}
+/* the loop that zeroes swm / swp at the start of cloverdet_derivative (monomial/cloverdet_monomial.c:67-72) */
+int tmhip_swpm_zero(tmhip_ctx *ctx) {
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  if (!ctx->swpm) return swpm_alloc(ctx);
+  TMHIP_CHECK(hipMemsetAsync(ctx->swpm, 0, (size_t)2 * 4 * 9 * ctx->V * sizeof(v2d), ctx->stream));
+  return 0;
+}
+/* operator/clover_deriv.c:252 sw_spinor_eo(ieo, kk, ll, fac) */
+int tmhip_sw_spinor_eo(tmhip_ctx *ctx, int ieo, tmhip_field *kk, tmhip_field *ll, double fac) {
+  if (need64(kk, "sw_spinor_eo") || need64(ll, "sw_spinor_eo")) return 1;
+  if (kk->ns != ll->ns) TMHIP_FAIL("sw_spinor_eo: fields with different strides");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  if (swpm_alloc(ctx)) return 1;
+  hipLaunchKernelGGL(sw_spinor_eo_kernel, dim3((ctx->Vh + 127) / 128), dim3(128), 0, ctx->stream, ctx->swpm, (const v2d *)kk->d, (const v2d *)ll->d,
+                     kk->ns, ctx->Vh, ctx->V, ieo ? 1 : 0, fac);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+/* operator/clover_deriv.c:72 sw_deriv(ieo, mu): needs the sw_inv of parity ieo (tmhip_sw_invert(ieo, mu) / tmhip_set_clover) */
+int tmhip_sw_deriv(tmhip_ctx *ctx, int ieo, double mu) {
+  if (!ctx->clover_set) TMHIP_FAIL("sw_deriv called before tmhip_sw_invert / tmhip_set_clover");
+  const int nsets = fabs(mu) > 0. ? 2 : 1;
+  if (nsets > ctx->sw_inv_sets) TMHIP_FAIL("sw_deriv: mu != 0 but sw_inv holds the +mu set only");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  if (swpm_alloc(ctx)) return 1;
+  hipLaunchKernelGGL(sw_deriv_kernel, dim3((ctx->Vh + 255) / 256, 4), dim3(256), 0, ctx->stream, ctx->swpm, (const v2d *)ctx->sw_inv, ctx->gs, ctx->Vh,
+                     ctx->V, ieo ? 1 : 0, nsets, nsets == 2 ? 0.5 : 1.0);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+/* operator/clover_accumulate_deriv.c:58 sw_all(hf, kappa, c_sw): adds the clover-leaf derivatives to the device-resident derivative
+ * field (the one tmhip_deriv_Sb accumulates into).  gauge_field: host links as for tmhip_set_gauge, or NULL to reuse the copy kept
+ * by the last tmhip_sw_term.  Single-rank lattices: the leaves of a T-split rank would touch links owned by its neighbours. */
+int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_sw) {
+  if (ctx->g.nproc_t > 1) TMHIP_FAIL("sw_all: T-split ranks need the derivative halo of xchange_deri, not built");
+  if (!ctx->swpm) TMHIP_FAIL("sw_all called before sw_spinor_eo / sw_deriv");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  const size_t gbytes = (size_t)ctx->VPR * 4 * 9 * sizeof(v2d);
+  if (gauge_host) {
+    if (!ctx->gauge_raw) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge_raw, gbytes));
+    TMHIP_CHECK(hipMemcpyAsync(ctx->gauge_raw, gauge_host, gbytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->gauge_raw_valid = true;
+  } else if (!ctx->gauge_raw_valid) {
+    TMHIP_FAIL("sw_all: no lexicographic gauge field on the device (pass the host field, or call tmhip_sw_term after tmhip_set_gauge)");
+  }
+  if (!ctx->deriv && tmhip_derivative_zero(ctx)) return 1;
+  LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, 0};
+  hipLaunchKernelGGL(sw_all_kernel, dim3((ctx->V + 63) / 64, 6), dim3(64), 0, ctx->stream, (const v2d *)ctx->gauge_raw, (const v2d *)ctx->swpm, ctx->deriv,
+                     g, ctx->Vh, -2. * (kappa * c_sw / 8.));
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+/* swm / swp in the reference's host layout: su3 [VOLUME][4] each (either pointer may be NULL) */
+__global__ __launch_bounds__(256) void swpm_unsort_kernel(v2d *__restrict__ out, const v2d *__restrict__ swpm, int which, int Vh, int V, int LX, int LY, int LZ) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Vh) return;
+  const int par = blockIdx.y;
+  const int LZh = LZ / 2;
+  int r = i / LZh;
+  const int y = r % LY;
+  r /= LY;
+  const int x = r % LX, t = r / LX;
+  const int o = (t + x + y + par) & 1;
+  v2d *dst = out + (2 * (size_t)i + o) * 36;
+  const size_t s = (size_t)par * Vh + i;
+#pragma unroll 4
+  for (int e = 0; e < 36; e++) dst[e] = swpm[((size_t)which * 36 + e) * V + s];
+}
+int tmhip_get_swpm(tmhip_ctx *ctx, void *swm_host, void *swp_host) {
+  if (!ctx->swpm) TMHIP_FAIL("tmhip_get_swpm: no clover-force accumulators on the device");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)ctx->V * 36 * sizeof(v2d);
+  if (tmhip_stage_reserve(ctx, bytes)) return 1;
+  void *hosts[2] = {swm_host, swp_host};
+  for (int w = 0; w < 2; w++) {
+    if (!hosts[w]) continue;
+    hipLaunchKernelGGL(swpm_unsort_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (v2d *)ctx->stage, (const v2d *)ctx->swpm, w, ctx->Vh,
+                       ctx->V, ctx->g.LX, ctx->g.LY, ctx->g.LZ);
+    TMHIP_CHECK(hipMemcpyAsync(hosts[w], ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  TMHIP_CHECK(hipGetLastError());
   return 0;
 }
 

@@ -207,6 +207,8 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->sw32) (void)hipFree(ctx->sw32);
   if (ctx->sw_inv32) (void)hipFree(ctx->sw_inv32);
   if (ctx->sw_fail) (void)hipFree(ctx->sw_fail);
+  if (ctx->swpm) (void)hipFree(ctx->swpm);
+  if (ctx->gauge_raw) (void)hipFree(ctx->gauge_raw);
   if (ctx->deriv) (void)hipFree(ctx->deriv);
   if (ctx->force_send) (void)hipFree(ctx->force_send);
   if (ctx->force_recv) (void)hipFree(ctx->force_recv);
@@ -309,6 +311,7 @@ int tmhip_set_gauge(tmhip_ctx *ctx, const void *host) {
   ctx->gauge_set = true;
   ctx->gauge32_set = false;  // the fp32 twin is rebuilt lazily from the new links
   ctx->gauge_recon_dev = -1.0;
+  ctx->gauge_raw_valid = false;   // tmhip_sw_all must not combine new links in the stencil with old ones in its leaves
   if (ctx->opt_recon == 12) return tmhip_check_gauge_recon(ctx);
   return 0;
 }

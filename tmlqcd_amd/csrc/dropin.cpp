@@ -732,6 +732,25 @@ void deriv_Sb(const int ieo, spinor *const l, spinor *const k, hamiltonian_field
   g_deriv_pending = true;
   if (g_mode == TMLQCD_HIP_COHERENT) tmlqcd_hip_flush_derivative(hf);
 }
+/* Clover part of the force under helper names (the reference keeps sw_deriv_nd / sw_spinor in the same objects, which therefore
+ * stay on the link line): the statements of cloverdet_derivative, monomial/cloverdet_monomial.c:67-72,125-147 */
+void tmlqcd_hip_swpm_zero(void) { CK(tmhip_swpm_zero(refresh(false))); }
+void tmlqcd_hip_sw_spinor_eo(const int ieo, const spinor *const kk, const spinor *const ll, const double fac) {   /* clover_deriv.c:252 */
+  tmhip_ctx *c = refresh(false);
+  tmhip_field *fk = in(c, kk, TMHIP_FIELD_EO), *fl = in(c, ll, TMHIP_FIELD_EO);
+  CK(tmhip_sw_spinor_eo(c, ieo, fk, fl, fac));
+}
+void tmlqcd_hip_sw_deriv(const int ieo, const double mu) {   /* clover_deriv.c:72 */
+  tmhip_ctx *c = refresh_clover();
+  CK(tmhip_sw_deriv(c, ieo, mu));
+}
+void tmlqcd_hip_sw_all(hamiltonian_field_t *const hf, const double kappa, const double c_sw) {   /* clover_accumulate_deriv.c:58 */
+  tmhip_ctx *c = refresh(true);
+  if (!g_deriv_pending) CK(tmhip_derivative_zero(c));
+  CK(tmhip_sw_all(c, &hf->gaugefield[0][0], kappa, c_sw));
+  g_deriv_pending = true;
+  if (g_mode == TMLQCD_HIP_COHERENT) tmlqcd_hip_flush_derivative(hf);
+}
 void tmlqcd_hip_flush_derivative(hamiltonian_field_t *const hf) {
   if (!g_deriv_pending) return;
   CK(tmhip_derivative_download(ctx(), &hf->derivative[0][0], 1));

@@ -72,6 +72,9 @@ struct tmhip_ctx {
   bool clover_set;     // sw and sw_inv both valid
   bool sw_set;         // sw valid (after tmhip_sw_term / tmhip_set_clover)
   int sw_inv_sets;     // 2 when the -mu set of sw_inv is valid as well (mu != 0), else 1
+  v2d *swpm;           // clover-force accumulators swm / swp (clover_leaf.c:141-172): [2][4][9][V], site = parity * Vh + e/o index
+  v2d *gauge_raw;      // lexicographic gauge field [VPR][4][9] kept from the last tmhip_sw_term for tmhip_sw_all; gauge_raw_valid
+  bool gauge_raw_valid;
   int *sw_fail;        // device counter of near-singular pivots met by tmhip_sw_invert
   v2f *sw32, *sw_inv32; bool clover32_set;
   v2f *gauge32;        // fp32 twin of the gauge copy (g_gauge_field_copy_32), built on first use

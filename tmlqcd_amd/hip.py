@@ -83,6 +83,8 @@ def load_library():
         "tmhip_sw_term": [vp, vp, d, d],
         "tmhip_gauge_su3_deviation": [vp, pd],
         "tmhip_derivative_zero": [vp],
+        "tmhip_swpm_zero": [vp], "tmhip_sw_spinor_eo": [vp, i, vp, vp, d], "tmhip_sw_deriv": [vp, i, d],
+        "tmhip_sw_all": [vp, vp, d, d], "tmhip_get_swpm": [vp, vp, vp],
         "tmhip_deriv_Sb": [vp, i, vp, vp, d],
         "tmhip_derivative_download": [vp, vp, i],
         "tmhip_multi_deriv_Sb": [i, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), d],
@@ -295,6 +297,24 @@ class Lattice:
             return out
         _ck(self.lib.tmhip_derivative_download(self.h, _hp(into), 1), "tmhip_derivative_download")
         return into
+
+    # --- clover part of the force (clover_deriv.c, clover_accumulate_deriv.c) ---
+    def swpm_zero(self):
+        _ck(self.lib.tmhip_swpm_zero(self.h), "tmhip_swpm_zero")
+
+    def sw_spinor_eo(self, ieo, kk, ll, fac):
+        _ck(self.lib.tmhip_sw_spinor_eo(self.h, ieo, kk.h, ll.h, fac), "sw_spinor_eo")
+
+    def sw_deriv(self, ieo, mu):
+        _ck(self.lib.tmhip_sw_deriv(self.h, ieo, mu), "sw_deriv")
+
+    def sw_all(self, kappa, c_sw, gauge=None):
+        _ck(self.lib.tmhip_sw_all(self.h, _hp(gauge) if gauge is not None else None, kappa, c_sw), "sw_all")
+
+    def get_swpm(self):
+        swm, swp = np.zeros((self.V, 4, 3, 3, 2)), np.zeros((self.V, 4, 3, 3, 2))
+        _ck(self.lib.tmhip_get_swpm(self.h, _hp(swm), _hp(swp)), "tmhip_get_swpm")
+        return swm, swp
 
     def sw_term(self, gauge, kappa, c_sw):
         """operator/clover_term.c:88 on the device; `gauge` as for set_gauge ([VPR][4][3][3][2])."""

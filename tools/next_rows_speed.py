@@ -46,6 +46,11 @@ lat.Hopping_Matrix(0, b, a)
 lat.derivative_zero()
 # deriv_Sb: per site (either parity) own spinor 192 + 4 neighbour spinors 768 + 4 links 576 + 4 su3adj rd+wr 512 = 2048 B
 timed("deriv_Sb", lambda: lat.deriv_Sb(1, a, b, 0.5), 20, 2048, 2 * Vh)
+# clover part of the force: outer products (2 x 192 B spinors + 8 su3 RMW), tr-log term, and the leaf kernel with atomics
+lat.swpm_zero()
+timed("sw_spinor_eo", lambda: lat.sw_spinor_eo(1, a, b, 0.5), 20, 384 + 2 * 1152, Vh)
+timed("sw_deriv(EE, mu)", lambda: lat.sw_deriv(0, mu), 20, 2 * 1152 + 2 * 1152, Vh)
+timed("sw_all (96 atomic su3adj adds per site)", lambda: lat.sw_all(kappa, c_sw), 5)
 for name in ("Qtm_pm_psi", "Mtm_plus_psi", "Mtm_plus_sym_psi", "Qtm_plus_sym_psi", "Mtm_plus_sym_dagg_psi", "Qsw_pm_psi"):
     timed(name, lambda n=name: lat.op(n, c, a), 20)
 
