@@ -103,7 +103,7 @@ def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface):
     finally:
         lat.set_loopback(0)
         lat.set_option("flagsync", 1)
-        lat.set_option("fusedface", 0)
+        lat.set_option("fusedface", -1)
     dk.free(); dl.free()
 
 

@@ -245,12 +245,12 @@ def test_cg_fused_scalar_product_path(fused):
     assert rel_err(dp.download(), Pc[:N]) < 1e-9          # P after exactly 7 updates, no extra / missing alpha p
     # the same solve on the split-phase path (T-split rank rehearsed on one GPU): with cg_fused_dot = 2 the reductions are
     # spread over the boundary kernel (comm stream) and the interior kernel (main stream)
-    for mode in (1, 2):
-        lat.set_loopback(mode)
+    for mode, ff in ((1, 0), (2, 0), (1, 1), (2, 1)):      # ff = 1: interior and faces in ONE launch, face blocks wait in-kernel
+        lat.set_loopback(mode); lat.set_option("fusedface", ff)
         dp.zero()
         it4, hist4 = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
-        lat.set_loopback(0)
-        assert abs(it4 - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9
+        lat.set_loopback(0); lat.set_option("fusedface", -1)
+        assert abs(it4 - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9, (mode, ff)
         m4 = min(len(hist4), len(hist_ref)) - 1
         assert np.allclose(hist4[:m4], hist_ref[:m4], rtol=1e-6)
     lat.close()

@@ -119,7 +119,7 @@ int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in,
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx) {
   const int spb = fp32_pairs(ctx) ? 512 : 256;
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
-  return ctx->Vh % spb == 0 && (!split || (ctx->face % spb == 0 && !ctx->opt_fusedface && ctx->g.T >= 3));
+  return ctx->Vh % spb == 0 && (!split || (ctx->face % spb == 0 && ctx->g.T >= 3));
 }
 
 // Single-process ring: n contexts (one per GPU, or several on one GPU for the self-test) that
