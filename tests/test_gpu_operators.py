@@ -328,3 +328,27 @@ def test_t_split_two_contexts_on_one_gpu(T):
             assert rel_err(ls[r].download(), ref[r * Vh:(r + 1) * Vh]) < TOL, (ieo, r)
     for lat in lats:
         lat.close()
+
+
+def test_linalg_empty_and_out_of_range_site_counts(setup):
+    """N = 0 is a legal empty loop in the reference's linalg (returns 0 / leaves the fields alone); N outside [0, V/2] must
+    fail loudly instead of running past the device arrays."""
+    from tmlqcd_amd.hip import TmHipError
+    orc, lat = setup
+    N = orc.Vh
+    a, b = random_spinor(401, N), random_spinor(402, N)
+    da, db = lat.field(a), lat.field(b)
+    assert lat.square_norm(da, 0) == 0.0 and lat.scalar_prod_r(da, db, 0) == 0.0
+    lat.assign_add_mul_r(da, db, 0.5, 0); lat.diff(da, da, db, 0); lat.assign(da, db, 0)
+    assert np.array_equal(da.download(), a)
+    half = N // 2 + 3                                        # ragged prefix: only the first `half` sites take part
+    assert abs(lat.square_norm(da, half) - (a[:half] ** 2).sum()) <= 1e-13 * (a[:half] ** 2).sum()
+    lat.assign_add_mul_r(da, db, 0.25, half)
+    out = da.download()
+    assert rel_err(out[:half], a[:half] + 0.25 * b[:half]) < TOL and np.array_equal(out[half:], a[half:])
+    for bad in (-1, N + 1):
+        with pytest.raises(TmHipError):
+            lat.square_norm(da, bad)
+        with pytest.raises(TmHipError):
+            lat.assign_add_mul_r(da, db, 1.0, bad)
+    da.free(); db.free()

@@ -157,10 +157,19 @@ int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out) 
   return 0;
 }
 
+// N is a site count of a one-parity field: 0 is a legal empty loop in the reference (linalg/*.c), anything outside [0, V/2] would
+// run past the device arrays
+#define LA_CHECK_N(who, zero_out)                                                                                       \
+  do {                                                                                                                  \
+    if (N < 0 || N > ctx->Vh) TMHIP_FAIL("%s: N = %d is outside [0, VOLUME/2 = %d]", who, N, ctx->Vh);                  \
+    if (N == 0) { zero_out; return 0; }                                                                                 \
+  } while (0)
+
 extern "C" {
 
 int tmhip_square_norm(tmhip_ctx *ctx, tmhip_field *P, int N, int parallel, double *out) {
   if (check_eo(P, "square_norm")) return 1;
+  LA_CHECK_N("square_norm", *out = 0.0);
   const dim3 g = la_grid(N);
   hipLaunchKernelGGL(sqnorm_kernel, g, dim3(LA_BS), 0, ctx->stream, P->d, P->ns, N, ctx->partials);
   return tmhip_reduce_finish(ctx, g.x * g.y, parallel, out);
@@ -168,6 +177,7 @@ int tmhip_square_norm(tmhip_ctx *ctx, tmhip_field *P, int N, int parallel, doubl
 
 int tmhip_scalar_prod_r(tmhip_ctx *ctx, tmhip_field *S, tmhip_field *R, int N, int parallel, double *out) {
   if (check_eo(S, "scalar_prod_r") || check_eo(R, "scalar_prod_r")) return 1;
+  LA_CHECK_N("scalar_prod_r", *out = 0.0);
   const dim3 g = la_grid(N);
   hipLaunchKernelGGL(dotr_kernel, g, dim3(LA_BS), 0, ctx->stream, S->d, R->d, S->ns, N, ctx->partials);
   return tmhip_reduce_finish(ctx, g.x * g.y, parallel, out);
@@ -176,6 +186,7 @@ int tmhip_scalar_prod_r(tmhip_ctx *ctx, tmhip_field *S, tmhip_field *R, int N, i
 int tmhip_assign_mul_add_r_and_square(tmhip_ctx *ctx, tmhip_field *R, double c, tmhip_field *S, int N, int parallel,
                                       double *out) {
   if (check_eo(R, "assign_mul_add_r_and_square") || check_eo(S, "assign_mul_add_r_and_square")) return 1;
+  LA_CHECK_N("assign_mul_add_r_and_square", *out = 0.0);
   const dim3 g = la_grid(N);
   hipLaunchKernelGGL(xpay_sq_kernel, g, dim3(LA_BS), 0, ctx->stream, R->d, c, S->d, R->ns, N, ctx->partials);
   return tmhip_reduce_finish(ctx, g.x * g.y, parallel, out);
@@ -183,6 +194,7 @@ int tmhip_assign_mul_add_r_and_square(tmhip_ctx *ctx, tmhip_field *R, double c, 
 
 int tmhip_assign_add_mul_r(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, double c, int N) {
   if (check_eo(P, "assign_add_mul_r") || check_eo(Q, "assign_add_mul_r")) return 1;
+  LA_CHECK_N("assign_add_mul_r", (void)0);
   hipLaunchKernelGGL(stream_kernel<0>, la_grid(N), dim3(LA_BS), 0, ctx->stream, P->d, Q->d, (const v2d *)nullptr, c, P->ns, N);
   TMHIP_CHECK(hipGetLastError());
   return 0;
@@ -190,6 +202,7 @@ int tmhip_assign_add_mul_r(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, doubl
 
 int tmhip_assign_mul_add_r(tmhip_ctx *ctx, tmhip_field *R, double c, tmhip_field *S, int N) {
   if (check_eo(R, "assign_mul_add_r") || check_eo(S, "assign_mul_add_r")) return 1;
+  LA_CHECK_N("assign_mul_add_r", (void)0);
   hipLaunchKernelGGL(stream_kernel<1>, la_grid(N), dim3(LA_BS), 0, ctx->stream, R->d, S->d, (const v2d *)nullptr, c, R->ns, N);
   TMHIP_CHECK(hipGetLastError());
   return 0;
@@ -197,6 +210,7 @@ int tmhip_assign_mul_add_r(tmhip_ctx *ctx, tmhip_field *R, double c, tmhip_field
 
 int tmhip_diff(tmhip_ctx *ctx, tmhip_field *Q, tmhip_field *R, tmhip_field *S, int N) {
   if (check_eo(Q, "diff") || check_eo(R, "diff") || check_eo(S, "diff")) return 1;
+  LA_CHECK_N("diff", (void)0);
   hipLaunchKernelGGL(stream_kernel<2>, la_grid(N), dim3(LA_BS), 0, ctx->stream, Q->d, R->d, S->d, 0.0, Q->ns, N);
   TMHIP_CHECK(hipGetLastError());
   return 0;
@@ -204,6 +218,7 @@ int tmhip_diff(tmhip_ctx *ctx, tmhip_field *Q, tmhip_field *R, tmhip_field *S, i
 
 int tmhip_assign(tmhip_ctx *ctx, tmhip_field *R, tmhip_field *S, int N) {
   if (check_eo(R, "assign") || check_eo(S, "assign")) return 1;
+  LA_CHECK_N("assign", (void)0);
   if (R->d == S->d) return 0;
   hipLaunchKernelGGL(stream_kernel<3>, la_grid(N), dim3(LA_BS), 0, ctx->stream, R->d, S->d, (const v2d *)nullptr, 0.0, R->ns, N);
   TMHIP_CHECK(hipGetLastError());
@@ -213,6 +228,7 @@ int tmhip_assign(tmhip_ctx *ctx, tmhip_field *R, tmhip_field *S, int N) {
 static int launch_diag(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, tmhip_field *j, double zre, double zim, int beta,
                        int g5, int N) {
   if (check_eo(l, "diag") || check_eo(k, "diag") || (j && check_eo(j, "diag"))) return 1;
+  LA_CHECK_N("site-diagonal operator", (void)0);
   hipLaunchKernelGGL(diag_kernel, la_grid(N), dim3(LA_BS), 0, ctx->stream, l->d, k->d, j ? j->d : (const v2d *)nullptr, zre,
                      zim, beta, g5, l->ns, N);
   TMHIP_CHECK(hipGetLastError());
