@@ -157,14 +157,6 @@ int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out) 
   return 0;
 }
 
-// N is a site count of a one-parity field: 0 is a legal empty loop in the reference (linalg/*.c), anything outside [0, V/2] would
-// run past the device arrays
-#define LA_CHECK_N(who, zero_out)                                                                                       \
-  do {                                                                                                                  \
-    if (N < 0 || N > ctx->Vh) TMHIP_FAIL("%s: N = %d is outside [0, VOLUME/2 = %d]", who, N, ctx->Vh);                  \
-    if (N == 0) { zero_out; return 0; }                                                                                 \
-  } while (0)
-
 extern "C" {
 
 int tmhip_square_norm(tmhip_ctx *ctx, tmhip_field *P, int N, int parallel, double *out) {

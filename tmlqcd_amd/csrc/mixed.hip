@@ -158,6 +158,7 @@ int tmhip_field_download32(tmhip_ctx *ctx, tmhip_field *f, void *host, int nsite
 /* linalg/assign_to_32.c */
 int tmhip_assign_to_32(tmhip_ctx *ctx, tmhip_field *R32, tmhip_field *S64, int N) {
   if (need32(R32, "assign_to_32") || need64(S64, "assign_to_32")) return 1;
+  LA_CHECK_N("assign_to_32", (void)0);
   hipLaunchKernelGGL((convert_kernel<v2f, v2d>), la_grid(N), dim3(LA_BS), 0, ctx->stream, R32->d32, (const v2d *)S64->d, R32->ns, N);
   TMHIP_CHECK(hipGetLastError());
   return 0;
@@ -165,12 +166,14 @@ int tmhip_assign_to_32(tmhip_ctx *ctx, tmhip_field *R32, tmhip_field *S64, int N
 /* linalg/assign_to_64.c */
 int tmhip_assign_to_64(tmhip_ctx *ctx, tmhip_field *R64, tmhip_field *S32, int N) {
   if (need64(R64, "assign_to_64") || need32(S32, "assign_to_64")) return 1;
+  LA_CHECK_N("assign_to_64", (void)0);
   hipLaunchKernelGGL((convert_kernel<v2d, v2f>), la_grid(N), dim3(LA_BS), 0, ctx->stream, R64->d, (const v2f *)S32->d32, R64->ns, N);
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }
 int tmhip_add_from_32(tmhip_ctx *ctx, tmhip_field *P64, tmhip_field *X32, int N) {
   if (need64(P64, "add_from_32") || need32(X32, "add_from_32")) return 1;
+  LA_CHECK_N("add_from_32", (void)0);
   hipLaunchKernelGGL(add_from32_kernel, la_grid(N), dim3(LA_BS), 0, ctx->stream, P64->d, (const v2f *)X32->d32, P64->ns, N);
   TMHIP_CHECK(hipGetLastError());
   return 0;
@@ -179,12 +182,14 @@ int tmhip_add_from_32(tmhip_ctx *ctx, tmhip_field *P64, tmhip_field *X32, int N)
 /* linalg/square_norm_32.c, scalar_prod_r_32.c (double accumulation) */
 int tmhip_square_norm_32(tmhip_ctx *ctx, tmhip_field *P, int N, int parallel, double *out) {
   if (need32(P, "square_norm_32")) return 1;
+  LA_CHECK_N("square_norm_32", *out = 0.0);
   const dim3 g = la_grid(N);
   hipLaunchKernelGGL(reduce32_kernel<0>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)P->d32, (const v2f *)nullptr, P->ns, N, ctx->partials);
   return tmhip_reduce_finish(ctx, g.x * g.y, parallel, out);
 }
 int tmhip_scalar_prod_r_32(tmhip_ctx *ctx, tmhip_field *S, tmhip_field *R, int N, int parallel, double *out) {
   if (need32(S, "scalar_prod_r_32") || need32(R, "scalar_prod_r_32")) return 1;
+  LA_CHECK_N("scalar_prod_r_32", *out = 0.0);
   const dim3 g = la_grid(N);
   hipLaunchKernelGGL(reduce32_kernel<1>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)S->d32, (const v2f *)R->d32, S->ns, N, ctx->partials);
   return tmhip_reduce_finish(ctx, g.x * g.y, parallel, out);
@@ -192,12 +197,14 @@ int tmhip_scalar_prod_r_32(tmhip_ctx *ctx, tmhip_field *S, tmhip_field *R, int N
 /* linalg/assign_add_mul_r_32.c, assign_mul_add_r_32.c */
 int tmhip_assign_add_mul_r_32(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, float c, int N) {
   if (need32(P, "assign_add_mul_r_32") || need32(Q, "assign_add_mul_r_32")) return 1;
+  LA_CHECK_N("assign_add_mul_r_32", (void)0);
   hipLaunchKernelGGL(stream32_kernel<0>, la_grid(N), dim3(LA_BS), 0, ctx->stream, P->d32, (const v2f *)Q->d32, c, P->ns, N);
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }
 int tmhip_assign_mul_add_r_32(tmhip_ctx *ctx, tmhip_field *R, float c, tmhip_field *S, int N) {
   if (need32(R, "assign_mul_add_r_32") || need32(S, "assign_mul_add_r_32")) return 1;
+  LA_CHECK_N("assign_mul_add_r_32", (void)0);
   hipLaunchKernelGGL(stream32_kernel<1>, la_grid(N), dim3(LA_BS), 0, ctx->stream, R->d32, (const v2f *)S->d32, c, R->ns, N);
   TMHIP_CHECK(hipGetLastError());
   return 0;

@@ -104,6 +104,14 @@ struct tmhip_ctx {
   double gauge_recon_dev;   // max |U_row2 - conj(row0 x row1)| over all links of the resident gauge field (-1: not measured)
 };
 
+// N is a site count of a one-parity field: 0 is a legal empty loop in the reference (linalg/*.c), anything outside [0, V/2] would
+// run past the device arrays
+#define LA_CHECK_N(who, zero_out)                                                                                       \
+  do {                                                                                                                  \
+    if (N < 0 || N > ctx->Vh) TMHIP_FAIL("%s: N = %d is outside [0, VOLUME/2 = %d]", who, N, ctx->Vh);                  \
+    if (N == 0) { zero_out; return 0; }                                                                                 \
+  } while (0)
+
 // ---- launch helpers implemented across the .hip files ----
 enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4, EPI_CLOVER_INV = 5, EPI_CLOVER_G5 = 6, EPI_CLOVER = 7,
        EPI_TM_SUB_G5_NRM = 8 /* + partials of |out|^2 */, EPI_TM_SUB_G5_RES = 9 /* resid -= alpha out, partials of |resid|^2; out not stored */,
