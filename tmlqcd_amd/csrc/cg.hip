@@ -129,14 +129,15 @@ __global__ __launch_bounds__(LA_BS) void cg_xp_kernel(V2 *__restrict__ X, V2 *__
 }
 
 // fixed-order sum of the per-block partials into *out (same scheme as linalg.hip)
-__global__ __launch_bounds__(256) void cg_sum_kernel(const double *__restrict__ partials, int n, double *out, const CgState *st) {
+#define CG_SUM_BS 1024   // one block; the fused stencils deliver one partial per wave (8192 at 32^4), so use the widest block
+__global__ __launch_bounds__(CG_SUM_BS) void cg_sum_kernel(const double *__restrict__ partials, int n, double *out, const CgState *st) {
   if (st->done) return;
-  __shared__ double sm[256];
+  __shared__ double sm[CG_SUM_BS];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  for (int i = threadIdx.x; i < n; i += CG_SUM_BS) acc += partials[i];
   sm[threadIdx.x] = acc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = CG_SUM_BS / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
     __syncthreads();
   }
@@ -203,15 +204,15 @@ __global__ void cg_scalar_kernel(CgState *st, const double *sum, double *hist, i
 
 // single rank: the fixed-order sum of the partials and the scalar update in one launch (no all-reduce in between)
 template <int WHICH>
-__global__ __launch_bounds__(256) void cg_sum_scalar_kernel(const double *__restrict__ partials, int n, double *out, CgState *st, double *hist,
-                                                            int hist_len) {
+__global__ __launch_bounds__(CG_SUM_BS) void cg_sum_scalar_kernel(const double *__restrict__ partials, int n, double *out, CgState *st, double *hist,
+                                                                  int hist_len) {
   if (st->done) { if (WHICH == 0 && threadIdx.x == 0) st->x_pending = 0; return; }
-  __shared__ double sm[256];
+  __shared__ double sm[CG_SUM_BS];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  for (int i = threadIdx.x; i < n; i += CG_SUM_BS) acc += partials[i];
   sm[threadIdx.x] = acc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = CG_SUM_BS / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
     __syncthreads();
   }
@@ -273,11 +274,11 @@ template <int WHICH>
 static int cg_reduce_update(tmhip_ctx *ctx, int n, CgState *st, double *hist, int hist_len) {
   double *sum = ctx->result_dev + 1;
   if (ctx->comm_ready && ctx->g.nproc_t > 1) {
-    hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, n, sum, st);
+    hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(CG_SUM_BS), 0, ctx->stream, ctx->partials, n, sum, st);
     if (cg_allreduce(ctx, sum)) return 1;
     hipLaunchKernelGGL(cg_scalar_kernel<WHICH>, dim3(1), dim3(1), 0, ctx->stream, st, sum, hist, hist_len);
   } else {
-    hipLaunchKernelGGL(cg_sum_scalar_kernel<WHICH>, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, n, sum, st, hist, hist_len);
+    hipLaunchKernelGGL(cg_sum_scalar_kernel<WHICH>, dim3(1), dim3(CG_SUM_BS), 0, ctx->stream, ctx->partials, n, sum, st, hist, hist_len);
   }
   return 0;
 }
