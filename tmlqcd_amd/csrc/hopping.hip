@@ -17,21 +17,7 @@
 //  * gauge links are used exactly once per call -> loaded non-temporally so they do
 //    not evict the re-used spinor lines from L2.
 //  * MFMA is not used: 3x3 complex mat-vec at 1 flop/B, HBM-bound by ~10x.
-#include "tmhip_internal.h"
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-// ---- one site per thread: the value type is the memory element itself -------------------------------------------
-#define TMHIP_SCALAR_COMPLEX_OPS(ETYPE, RTYPE)                                                                   \
-  typedef ETYPE ET;                                                                                              \
-  typedef ETYPE V2T;                                                                                             \
-  typedef RTYPE RT;                                                                                              \
-  template <bool NT> __device__ __forceinline__ V2T ldc(const ET *p) { if (NT) return __builtin_nontemporal_load(p); return *p; } \
-  template <bool NT> __device__ __forceinline__ void stc(ET *p, V2T v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; } \
-  __device__ __forceinline__ V2T ldc2(const ET *p0, const ET *) { return *p0; }                                  \
-  __device__ __forceinline__ V2T czero() { return V2T{0, 0}; }                                                   \
-  __device__ __forceinline__ V2T cbcast(double re, double im) { return V2T{(RT)re, (RT)im}; }                    \
-  __device__ __forceinline__ double cdotd(V2T w, V2T r) { return (double)w.x * (double)r.x + (double)w.y * (double)r.y; }
+#include "hopping_common.h"
 
 namespace hop64 {
 TMHIP_SCALAR_COMPLEX_OPS(v2d, double)
@@ -46,54 +32,8 @@ TMHIP_SCALAR_COMPLEX_OPS(v2d, double)
 #undef HOP_SITES
 }  // namespace hop64
 
-#define HOP_CTX_GAUGE(ctx) ((ctx)->gauge32)
-#define HOP_CTX_GAUGE_READY(ctx) ((ctx)->gauge32_set)
-#define HOP_CTX_OCC(ctx) ((ctx)->opt_occ32)
-namespace hop32 {
-TMHIP_SCALAR_COMPLEX_OPS(v2f, float)
-#define HOP_SITES 1
-#include "hopping_impl.inc"
-#undef HOP_SITES
-}  // namespace hop32
-
-// ---- fp32, two sites per thread: x = (re of site i, re of site i+1), y = (im, im) ----------------------------------
-namespace hop32p {
-typedef v2f ET;
-typedef float vf2 __attribute__((ext_vector_type(2)));
-typedef float vf4 __attribute__((ext_vector_type(4)));
-struct V2T {
-  vf2 x, y;
-  __device__ __forceinline__ V2T &operator+=(const V2T &o) { x += o.x; y += o.y; return *this; }
-  __device__ __forceinline__ V2T &operator-=(const V2T &o) { x -= o.x; y -= o.y; return *this; }
-};
-__device__ __forceinline__ V2T operator+(V2T a, V2T b) { return V2T{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ V2T operator-(V2T a, V2T b) { return V2T{a.x - b.x, a.y - b.y}; }
-typedef vf2 RT;
-template <bool NT> __device__ __forceinline__ V2T ldc(const ET *p) {  // sites i, i+1: one 16-byte access
-  const vf4 v = NT ? __builtin_nontemporal_load((const vf4 *)p) : *(const vf4 *)p;
-  return V2T{vf2{v.x, v.z}, vf2{v.y, v.w}};
-}
-template <bool NT> __device__ __forceinline__ void stc(ET *p, V2T v) {
-  const vf4 w = vf4{v.x.x, v.y.x, v.x.y, v.y.y};
-  if (NT) __builtin_nontemporal_store(w, (vf4 *)p);
-  else *(vf4 *)p = w;
-}
-__device__ __forceinline__ V2T ldc2(const ET *p0, const ET *p1) {
-  const ET a = *p0, b = *p1;
-  return V2T{vf2{a.x, b.x}, vf2{a.y, b.y}};
-}
-__device__ __forceinline__ V2T czero() { return V2T{vf2{0.f, 0.f}, vf2{0.f, 0.f}}; }
-__device__ __forceinline__ V2T cbcast(double re, double im) { return V2T{vf2{(float)re, (float)re}, vf2{(float)im, (float)im}}; }
-__device__ __forceinline__ double cdotd(V2T w, V2T r) {
-  return (double)w.x.x * r.x.x + (double)w.y.x * r.y.x + (double)w.x.y * r.x.y + (double)w.y.y * r.y.y;
-}
-#define HOP_SITES 2
-#include "hopping_impl.inc"
-#undef HOP_SITES
-}  // namespace hop32p
-#undef HOP_CTX_OCC
-#undef HOP_CTX_GAUGE
-#undef HOP_CTX_GAUGE_READY
+TMHIP_DECLARE_HOP32(hop32)
+TMHIP_DECLARE_HOP32(hop32p)
 
 // the two-site fp32 variant needs whole site pairs inside one z-row: LZ/2 even
 static inline bool fp32_pairs(const tmhip_ctx *ctx) { return ctx->opt_fp32_pairs && ((ctx->g.LZ / 2) % 2 == 0); }
