@@ -451,17 +451,29 @@ static int tm_sub_H_eo_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *p, tm
   const double sign = _sign < 0. ? -1. : 1.;
   return tmhip_tm_sub_hopping_matrix(ctx, ieo, l, p, k, 1., sign * ctx->mu);
 }
+// raw-pointer forms with the chaining hint: inside a composition every stencil after the first gathers the previous one's output
+static int hop_tm_inv(tmhip_ctx *ctx, v2d *l, const v2d *k, int ieo, double _sign, int flags) {   /* tm_operators.c:508-526 */
+  const double nrm = 1. / (1. + ctx->mu * ctx->mu), sign = _sign < 0. ? 1. : -1.;
+  return tmhip_launch_hopping(ctx, ieo, l, k, nullptr, EPI_TM_TIMES, nrm, sign * nrm * ctx->mu, flags);
+}
+static int hop_tm_sub_g5(tmhip_ctx *ctx, v2d *l, const v2d *p, const v2d *k, int ieo, double _sign, int flags) {   /* :528-546 */
+  return tmhip_launch_hopping(ctx, ieo, l, k, p, EPI_TM_SUB_G5, 1., (_sign < 0. ? -1. : 1.) * ctx->mu, flags);
+}
+#define HOP_FIRST HOP_COMM
+#define HOP_NEXT (HOP_COMM | HOP_CHAINED)
 /* l may alias k for these (invert_eo.c:270 calls Qtm_minus_psi in place): the last stencil reads
  * k only through the element-wise epilogue `p`, never as a gathered neighbour field. */
 /* tm_operators.c:172-177 */
 int tmhip_Qtm_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
-  return tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, +1.) ||
-         tm_sub_H_eo_gamma5(ctx, l, k, ctx->scratch[1], TMHIP_OE, +1.);
+  if (need_eo(l, "Qtm_plus_psi") || need_eo(k, "Qtm_plus_psi")) return 1;
+  return hop_tm_inv(ctx, ctx->scratch[1]->d, k->d, TMHIP_EO, +1., HOP_FIRST) ||
+         hop_tm_sub_g5(ctx, l->d, k->d, ctx->scratch[1]->d, TMHIP_OE, +1., HOP_NEXT);
 }
 /* tm_operators.c:216-221 */
 int tmhip_Qtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
-  return tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, -1.) ||
-         tm_sub_H_eo_gamma5(ctx, l, k, ctx->scratch[1], TMHIP_OE, -1.);
+  if (need_eo(l, "Qtm_minus_psi") || need_eo(k, "Qtm_minus_psi")) return 1;
+  return hop_tm_inv(ctx, ctx->scratch[1]->d, k->d, TMHIP_EO, -1., HOP_FIRST) ||
+         hop_tm_sub_g5(ctx, l->d, k->d, ctx->scratch[1]->d, TMHIP_OE, -1., HOP_NEXT);
 }
 /* tm_operators.c:245-250 */
 int tmhip_Mtm_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
@@ -475,10 +487,10 @@ int tmhip_Mtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
 }
 /* tm_operators.c:338-345 : 4 stencil launches, twists fused into the epilogues */
 int tmhip_Qtm_pm_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
-  return tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, -1.) ||
-         tm_sub_H_eo_gamma5(ctx, ctx->scratch[0], k, ctx->scratch[1], TMHIP_OE, -1.) ||
-         tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], ctx->scratch[0], TMHIP_EO, +1.) ||
-         tm_sub_H_eo_gamma5(ctx, l, ctx->scratch[0], ctx->scratch[1], TMHIP_OE, +1.);
+  if (need_eo(l, "Qtm_pm_psi") || need_eo(k, "Qtm_pm_psi")) return 1;
+  v2d *s0 = ctx->scratch[0]->d, *s1 = ctx->scratch[1]->d;
+  return hop_tm_inv(ctx, s1, k->d, TMHIP_EO, -1., HOP_FIRST) || hop_tm_sub_g5(ctx, s0, k->d, s1, TMHIP_OE, -1., HOP_NEXT) ||
+         hop_tm_inv(ctx, s1, s0, TMHIP_EO, +1., HOP_NEXT) || hop_tm_sub_g5(ctx, l->d, s0, s1, TMHIP_OE, +1., HOP_NEXT);
 }
 /* The "symmetric" e/o preconditioning family (tm_operators.c:186-192,223-229,259-265,296-302):
  *   X_sym = k - (1 +- i mu g5)^-1 H_oe (1 +- i mu g5)^-1 H_eo k.
@@ -605,9 +617,12 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int a, int b, double *ms) {
 /* benchmark.c:291-300 */
 int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_field *f2, int iters, double *ms_total) {
   if (tmhip_event_record(ctx, 14)) return 1;
+  if (need_eo(f0, "bench") || need_eo(f1, "bench") || need_eo(f2, "bench")) return 1;
   for (int j = 0; j < iters; j++) {
-    if (tmhip_hopping_matrix(ctx, 0, f1, f0)) return 1;
-    if (tmhip_hopping_matrix(ctx, 1, f2, f1)) return 1;
+    // back-to-back stencils (benchmark.c:295-296): f1 is the previous stencil's output and f0 has not been written since the loop
+    // began, so on a split lattice their faces may be packed early (HOP_CHAINED); the very first call makes no such promise
+    if (tmhip_launch_hopping(ctx, 0, f1->d, f0->d, nullptr, EPI_STORE, 0, 0, j ? (HOP_COMM | HOP_CHAINED) : HOP_COMM)) return 1;
+    if (tmhip_launch_hopping(ctx, 1, f2->d, f1->d, nullptr, EPI_STORE, 0, 0, HOP_COMM | HOP_CHAINED)) return 1;
   }
   if (tmhip_event_record(ctx, 15)) return 1;
   return tmhip_event_elapsed_ms(ctx, 14, 15, ms_total);

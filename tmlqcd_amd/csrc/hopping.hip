@@ -39,22 +39,22 @@ TMHIP_DECLARE_HOP32(hop32p)
 static inline bool fp32_pairs(const tmhip_ctx *ctx) { return ctx->opt_fp32_pairs && ((ctx->g.LZ / 2) % 2 == 0); }
 
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
-                         double cre, double cim, bool comm, const v2d *cw) {
+                         double cre, double cim, int comm, const v2d *cw) {
   return hop64::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
 }
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
-                             double cre, double cim, int *npartials, int mode, v2d *resid, const double *scal, const v2d *cw) {
-  return hop64::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw);
+                             double cre, double cim, int *npartials, int mode, v2d *resid, const double *scal, const v2d *cw, int chained) {
+  return hop64::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
 }
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
-                           double cre, double cim, bool comm, const v2f *cw) {
+                           double cre, double cim, int comm, const v2f *cw) {
   if (fp32_pairs(ctx)) return hop32p::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
   return hop32::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
 }
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
-                               double cre, double cim, int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw) {
-  if (fp32_pairs(ctx)) return hop32p::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw);
-  return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw);
+                               double cre, double cim, int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw, int chained) {
+  if (fp32_pairs(ctx)) return hop32p::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
+  return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
 }
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx) {
   const int spb = fp32_pairs(ctx) ? 512 : 256;

@@ -116,17 +116,21 @@ struct tmhip_ctx {
 enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4, EPI_CLOVER_INV = 5, EPI_CLOVER_G5 = 6, EPI_CLOVER = 7,
        EPI_TM_SUB_G5_NRM = 8 /* + partials of |out|^2 */, EPI_TM_SUB_G5_RES = 9 /* resid -= alpha out, partials of |resid|^2; out not stored */,
        EPI_CLOVER_G5_NRM = 10, EPI_CLOVER_G5_RES = 11 /* the same two on top of the clover_gamma5 epilogue */ };
+// `comm`: 0 no halo exchange (Hopping_Matrix_nocom), HOP_COMM exchange first, HOP_COMM | HOP_CHAINED additionally promises that the
+// face slices of `in` were final before the previous split-phase stencil of this context finished on the comm stream (its own
+// output, or a field not written since), so the faces of `in` may be packed and exchanged while the main stream is still busy
+enum { HOP_COMM = 1, HOP_CHAINED = 2 };
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
-                         double cre, double cim, bool comm, const v2d *cw = nullptr);
+                         double cre, double cim, int comm, const v2d *cw = nullptr);
 // mode 0: partials of <dotv, out>; 1: of |out|^2; 2: resid -= (*scal) * out without storing out, partials of |resid|^2
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
                              double cre, double cim, int *npartials, int mode = 0, v2d *resid = nullptr, const double *scal = nullptr,
-                             const v2d *cw = nullptr);   // cw: clover blocks => clover_gamma5 epilogue (modes 1, 2 only)
+                             const v2d *cw = nullptr, int chained = 0);   // cw: clover blocks => clover_gamma5 epilogue (modes 1, 2 only)
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
-                           double cre, double cim, bool comm, const v2f *cw = nullptr);
+                           double cre, double cim, int comm, const v2f *cw = nullptr);
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
                                double cre, double cim, int *npartials, int mode = 0, v2f *resid = nullptr, const double *scal = nullptr,
-                               const v2f *cw = nullptr);
+                               const v2f *cw = nullptr, int chained = 0);
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx);
 int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out);
 extern "C" int tmhip_check_gauge_recon(tmhip_ctx *ctx);   // context.hip: unitarity guard of the gauge_recon=12 option
