@@ -256,6 +256,33 @@ def test_cg_fused_scalar_product_path(fused):
     lat.close()
 
 
+def test_cg_fused_split_path_wide_short_local_lattice():
+    """A T-split rank whose faces are a large part of its volume (4 x 16^3: half the sites are face sites): the face kernel
+    writes more reduction partials than the interior kernel.  Every face-kernel variant must reproduce the unsplit solve."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T, L = 4, 16
+    lat = Lattice(T, L, L, L, kappa=0.13, mu=0.015)
+    orc = Oracle(T, L, L, L, kappa=0.13, mu=0.015, threads=8)
+    g = syn.gauge_field(31, T, L, L, L)
+    lat.set_gauge(g); orc.set_gauge(g)
+    N = lat.Vh
+    q = syn.spinor_field_eo(32, 1, T, L, L, L)
+    P = orc.new_field()
+    it_ref, hist_ref = orc.cg_her(P, q.copy(), 500, 1e-20, 1, N)
+    dq, dp = lat.field(q), lat.field()
+    for loop, fs, ff in ((0, 1, 0), (1, 1, 0), (1, 0, 0), (1, 1, 1), (2, 1, 0)):
+        lat.set_loopback(loop); lat.set_option("facesplit", fs); lat.set_option("fusedface", ff)
+        dp.zero()
+        it, hist = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
+        assert abs(it - it_ref) <= 1, (loop, fs, ff, it, it_ref)
+        m = min(len(hist), len(hist_ref)) - 1
+        assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6), (loop, fs, ff)
+        assert rel_err(dp.download(), P[:N]) < 1e-9, (loop, fs, ff)
+    lat.close()
+
+
 def test_cg_not_converged_returns_minus_one(setup):
     orc, lat = setup
     N = orc.Vh

@@ -156,7 +156,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->V = g.T * g.LX * g.LY * g.LZ; ctx->Vh = ctx->V / 2; ctx->face = g.LX * g.LY * g.LZ / 2;
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
-  ctx->opt_block = 256; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0; ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 2; ctx->opt_fusedface = -1; ctx->opt_gaux = -1; ctx->opt_gdrop = 0; ctx->opt_fp32_pairs = 0; ctx->opt_occ32 = 0; ctx->opt_recon = 0; ctx->gauge_recon_dev = -1.0;
+  ctx->opt_block = 256; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0; ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 2; ctx->opt_fusedface = -1; ctx->opt_gaux = -1; ctx->opt_gdrop = 0; ctx->opt_fp32_pairs = 0; ctx->opt_occ32 = 0; ctx->opt_facesplit = 1; ctx->opt_recon = 0; ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
     int lo = 0, hi = 0;
@@ -168,7 +168,11 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   for (int i = 0; i < 16; i++) TMHIP_CHECK(hipEventCreate(&ctx->ev_slots[i]));
   TMHIP_CHECK(hipMalloc((void **)&ctx->gauge, (size_t)2 * 72 * ctx->gs * sizeof(v2d)));
   ctx->max_partials = 12 * ((ctx->ns + 1023) / 1024 + 1);
-  if (ctx->max_partials < 4 * ((ctx->ns + 255) / 256 + 8 + 7 * ctx->g.T)) ctx->max_partials = 4 * ((ctx->ns + 255) / 256 + 8 + 7 * ctx->g.T);  // fused stencil+reduction: one per wave of the (padded) grid
+  {
+    // fused stencil+reduction: one per wave of the (padded) grid, plus -- on the split path -- four per 64 face sites of the face kernel
+    const int need = 4 * ((ctx->ns + 255) / 256 + 8 + 7 * ctx->g.T) + 8 * ((ctx->face + 63) / 64 + 1);
+    if (ctx->max_partials < need) ctx->max_partials = need;
+  }
   TMHIP_CHECK(hipMalloc((void **)&ctx->partials, ctx->max_partials * sizeof(double)));
   TMHIP_CHECK(hipMalloc((void **)&ctx->result_dev, 4 * sizeof(double)));
   TMHIP_CHECK(hipHostMalloc((void **)&ctx->result_host, 4 * sizeof(double)));
@@ -278,6 +282,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "flagsync")) ctx->opt_flagsync = value;
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
   else if (!strcmp(name, "fusedface")) ctx->opt_fusedface = value;
+  else if (!strcmp(name, "facesplit")) ctx->opt_facesplit = value;
   else if (!strcmp(name, "gaux")) ctx->opt_gaux = value;
   else if (!strcmp(name, "gdrop")) ctx->opt_gdrop = value;
   else if (!strcmp(name, "occ32")) ctx->opt_occ32 = value;

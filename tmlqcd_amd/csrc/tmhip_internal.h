@@ -100,7 +100,7 @@ struct tmhip_ctx {
   // device-resident CG state (cg.hip)
   void *cg_state; double *cg_hist; int cg_hist_len;
   // options
-  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface; int opt_gaux; int opt_gdrop; int opt_fp32_pairs; int opt_occ32; int opt_recon;   // opt_recon: 12 = rebuild the third row of every link in registers (opt-in)
+  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface; int opt_gaux; int opt_gdrop; int opt_fp32_pairs; int opt_occ32; int opt_facesplit; int opt_recon;   // opt_recon: 12 = rebuild the third row of every link in registers (opt-in)
   double gauge_recon_dev;   // max |U_row2 - conj(row0 x row1)| over all links of the resident gauge field (-1: not measured)
 };
 
