@@ -94,6 +94,8 @@ void assign_mul_add_r(spinor *const R, const double c, const spinor *const S, co
 double assign_mul_add_r_and_square(spinor *const R, const double c, const spinor *const S, const int N, const int parallel);
 void diff(spinor *const Q, const spinor *const R, const spinor *const S, const int N);
 void assign(spinor *const R, spinor *const S, const int N);
+void add(spinor *const Q, const spinor *const R, const spinor *const S, const int N);   /* linalg/add.h */
+void mul_r(spinor *const R, const double c, spinor *const S, const int N);               /* linalg/mul_r.h */
 
 /* ---- solver/cg_her.h ------------------------------------------------------- */
 int cg_her(spinor *const P, spinor *const Q, const int max_iter, double eps_sq, const int rel_prec,

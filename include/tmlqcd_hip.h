@@ -122,6 +122,8 @@ int tmhip_assign_mul_add_r_and_square(tmhip_ctx *ctx, tmhip_field *R, double c, 
                                       int parallel, double *out);                                             /* assign_mul_add_r_and_square.c:145 */
 int tmhip_diff(tmhip_ctx *ctx, tmhip_field *Q, tmhip_field *R, tmhip_field *S, int N);                         /* diff.c:270 */
 int tmhip_assign(tmhip_ctx *ctx, tmhip_field *R, tmhip_field *S, int N);                                       /* assign.c:42 */
+int tmhip_add(tmhip_ctx *ctx, tmhip_field *Q, tmhip_field *R, tmhip_field *S, int N);                          /* linalg/add.c:45   Q = R + S */
+int tmhip_mul_r(tmhip_ctx *ctx, tmhip_field *R, double c, tmhip_field *S, int N);                              /* linalg/mul_r.c:40 R = c S */
 
 /* ---- solver --------------------------------------------------------------- */
 enum { TMHIP_OP_QTM_PM = 0, TMHIP_OP_QTM_PLUS = 1, TMHIP_OP_QTM_MINUS = 2, TMHIP_OP_MTM_PLUS = 3, TMHIP_OP_MTM_MINUS = 4,

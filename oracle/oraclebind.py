@@ -75,6 +75,8 @@ def _lib():
         lib.tmo_assign_mul_add_r_and_square.restype = d
         lib.tmo_assign_mul_add_r_and_square.argtypes = [vp, d, vp, i]
         lib.tmo_diff.argtypes = [vp, vp, vp, i]
+        lib.tmo_add.argtypes = [vp, vp, vp, i]
+        lib.tmo_mul_r.argtypes = [vp, C.c_double, vp, i]
         lib.tmo_assign.argtypes = [vp, vp, i]
         lib.tmo_cg_her.restype = i
         lib.tmo_cg_her.argtypes = [vp, vp, vp, i, d, i, i, vp, vp, i]
@@ -264,6 +266,12 @@ class Oracle:
 
     def diff(self, Q, R, S, N):
         self.lib.tmo_diff(_p(Q), _p(R), _p(S), N)
+
+    def add(self, Q, R, S, N):
+        self.lib.tmo_add(_p(Q), _p(R), _p(S), N)
+
+    def mul_r(self, R, c, S, N):
+        self.lib.tmo_mul_r(_p(R), c, _p(S), N)
 
     def cg_her(self, P, Q, max_iter, eps_sq, rel_prec, N, opname="Qtm_pm_psi"):
         f = C.cast(getattr(self.lib, "tmo_" + opname), C.c_void_p)

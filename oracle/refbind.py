@@ -55,6 +55,9 @@ class RefLattice:
         lib.assign_mul_add_r_and_square.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
         lib.diff.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.assign.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        if hasattr(lib, "mul_r"):
+            lib.add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            lib.mul_r.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int]
         lib.gamma5.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         for name in ("Qtm_pm_psi", "Qtm_plus_psi", "Qtm_minus_psi", "Mtm_plus_psi", "Mtm_minus_psi",
                      "D_psi", "Q_pm_psi", "Q_plus_psi", "Q_minus_psi", "Qtm_plus_sym_psi", "Qtm_minus_sym_psi",

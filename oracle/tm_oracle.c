@@ -1158,6 +1158,18 @@ void tmo_diff(tmo_spinor *Q, const tmo_spinor *R, const tmo_spinor *S, int N) {
 #pragma omp parallel for
   for (long i = 0; i < 24L * N; i++) q[i] = r[i] - s[i];
 }
+/* linalg/add.c:45-80  Q = R + S */
+void tmo_add(tmo_spinor *Q, const tmo_spinor *R, const tmo_spinor *S, int N) {
+  double *q = (double *)Q; const double *r = (const double *)R, *s = (const double *)S;
+#pragma omp parallel for
+  for (long i = 0; i < 24L * N; i++) q[i] = r[i] + s[i];
+}
+/* linalg/mul_r.c:40-75  R = c S */
+void tmo_mul_r(tmo_spinor *R, double c, const tmo_spinor *S, int N) {
+  double *r = (double *)R; const double *s = (const double *)S;
+#pragma omp parallel for
+  for (long i = 0; i < 24L * N; i++) r[i] = c * s[i];
+}
 /* linalg/assign.c:42-46 */
 void tmo_assign(tmo_spinor *R, const tmo_spinor *S, int N) { memcpy(R, S, (size_t)N * sizeof(tmo_spinor)); }
 

@@ -36,6 +36,8 @@ def host(host_stub):
     d.square_norm.restype = C.c_double; d.square_norm.argtypes = [VP, C.c_int, C.c_int]
     d.scalar_prod_r.restype = C.c_double; d.scalar_prod_r.argtypes = [VP, VP, C.c_int, C.c_int]
     d.assign_add_mul_r.argtypes = [VP, VP, C.c_double, C.c_int]
+    d.add.argtypes = [VP, VP, VP, C.c_int]
+    d.mul_r.argtypes = [VP, C.c_double, VP, C.c_int]
     d.cg_her.restype = C.c_int; d.cg_her.argtypes = [VP, VP, C.c_int, C.c_double, C.c_int, C.c_int, VP]
     d.tmlqcd_hip_set_residency.argtypes = [C.c_int]
     d.tmlqcd_hip_sync_to_host.argtypes = [VP]
@@ -64,6 +66,12 @@ def test_coherent_mode_is_a_plain_drop_in(host):
     assert abs(d.square_norm(_p(k), N, 0) - orc.square_norm(k, N)) <= TOL * orc.square_norm(k, N)
     a = k.copy(); d.assign_add_mul_r(_p(a), _p(p), 0.5, N)
     assert rel_err(a, k + 0.5 * p) < TOL
+    s = np.zeros_like(k); d.add(_p(s), _p(k), _p(p), N)          # linalg/add.c, linalg/mul_r.c (mixed_cg_her.c, operator.c callers)
+    assert np.array_equal(s, k + p)
+    d.mul_r(_p(s), 0.25, _p(k), N)
+    assert np.array_equal(s, 0.25 * k)
+    full = random_spinor(3, V); sf = np.zeros_like(full); d.mul_r(_p(sf), -2.0, _p(full), V)   # N = VOLUME: both parities
+    assert np.array_equal(sf, -2.0 * full)
     kk = k.copy(); ref2 = orc.new_field(); ref2[:N] = k
     d.Qtm_minus_psi(_p(kk), _p(kk)); orc.op("Qtm_minus_psi", ref2, ref2)   # in place (invert_eo.c:270)
     assert rel_err(kk, ref2[:N]) < TOL

@@ -69,6 +69,13 @@ def test_streaming_updates(setup):
     assert rel_err(dc.download(), rc) < TOL
     lat.assign(dc, db, N)
     assert np.array_equal(dc.download(), b)
+    da.upload(np.ascontiguousarray(ra))                           # identical inputs from here on
+    orc.add(rc, ra, b, N); lat.add(dc, da, db, N)                 # linalg/add.c, linalg/mul_r.c: one rounding each, so bit for bit
+    assert np.array_equal(dc.download(), rc)
+    orc.mul_r(rc, -0.73, b, N); lat.mul_r(dc, -0.73, db, N)
+    assert np.array_equal(dc.download(), rc)
+    lat.mul_r(dc, 2.0, dc, N)                                     # in place, as operator.c normalises a propagator
+    assert np.array_equal(dc.download(), 2.0 * rc)
     for f in (da, db, dc):
         f.free()
 
@@ -366,7 +373,7 @@ def test_linalg_empty_and_out_of_range_site_counts(setup):
     a, b = random_spinor(401, N), random_spinor(402, N)
     da, db = lat.field(a), lat.field(b)
     assert lat.square_norm(da, 0) == 0.0 and lat.scalar_prod_r(da, db, 0) == 0.0
-    lat.assign_add_mul_r(da, db, 0.5, 0); lat.diff(da, da, db, 0); lat.assign(da, db, 0)
+    lat.assign_add_mul_r(da, db, 0.5, 0); lat.diff(da, da, db, 0); lat.assign(da, db, 0); lat.add(da, da, db, 0); lat.mul_r(da, 3.0, db, 0)
     assert np.array_equal(da.download(), a)
     half = N // 2 + 3                                        # ragged prefix: only the first `half` sites take part
     assert abs(lat.square_norm(da, half) - (a[:half] ** 2).sum()) <= 1e-13 * (a[:half] ** 2).sum()

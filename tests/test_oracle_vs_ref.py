@@ -61,6 +61,8 @@ o.assign_mul_add_r(x, -1.2, q, N); lib.assign_mul_add_r(sp(5), -1.2, sp(3), N); 
 n1 = o.assign_mul_add_r_and_square(x, 0.6, q, N); n2 = lib.assign_mul_add_r_and_square(sp(5), 0.6, sp(3), N, 0)
 assert n1 == n2; same(x, 5, "assign_mul_add_r_and_square")
 o.diff(x, k, q, N); lib.diff(sp(5), sp(0), sp(3), N); same(x, 5, "diff")
+o.add(x, k, q, N); lib.add(sp(5), sp(0), sp(3), N); same(x, 5, "add")
+o.mul_r(x, -0.73, q, N); lib.mul_r(sp(5), -0.73, sp(3), N); same(x, 5, "mul_r")
 # M_full and D_psi
 en, on = o.new_field(), o.new_field()
 o.M_full(en, on, k, q); lib.M_full(sp(6), sp(7), sp(0), sp(3)); same(en, 6, "M_full even"); same(on, 7, "M_full odd")

@@ -628,6 +628,22 @@ void diff(spinor *const Q, const spinor *const R, const spinor *const S, const i
   for (int p = 0; p <= kind; p++) CK(tmhip_diff(c, half(fq, kind, p), half(fr, kind, p), half(fs, kind, p), VOLUME / 2));
   done(c, Q);
 }
+/* linalg/add.c:45-80 */
+void add(spinor *const Q, const spinor *const R, const spinor *const S, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fr = in(c, R, kind), *fs = in(c, S, kind), *fq = out(c, Q, kind);
+  for (int p = 0; p <= kind; p++) CK(tmhip_add(c, half(fq, kind, p), half(fr, kind, p), half(fs, kind, p), VOLUME / 2));
+  done(c, Q);
+}
+/* linalg/mul_r.c:40-75 */
+void mul_r(spinor *const R, const double cc, spinor *const S, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const int kind = kind_of_N(N);
+  tmhip_field *fs = in(c, S, kind), *fr = out(c, R, kind);
+  for (int p = 0; p <= kind; p++) CK(tmhip_mul_r(c, half(fr, kind, p), cc, half(fs, kind, p), VOLUME / 2));
+  done(c, R);
+}
 /* linalg/assign.c:42-46 */
 void assign(spinor *const R, spinor *const S, const int N) {
   tmhip_ctx *c = refresh(false);

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double *__restr
   if (threadIdx.x == 0) *out = sm[0];
 }
 
-// MODE 0: P += c Q   1: R = c R + S   2: Q = R - S   3: R = S
+// MODE 0: P += c Q   1: R = c R + S   2: Q = R - S   3: R = S   4: Q = R + S   5: R = c S
 template <int MODE>
 __global__ __launch_bounds__(LA_BS) void stream_kernel(v2d *__restrict__ X, const v2d *__restrict__ Y, const v2d *__restrict__ Z,
                                                        double c, int ns, int N) {
@@ -110,6 +110,8 @@ __global__ __launch_bounds__(LA_BS) void stream_kernel(v2d *__restrict__ X, cons
       if (MODE == 1) { const v2d a = x[i], b = y[i]; x[i] = v2d{c * a.x + b.x, c * a.y + b.y}; }
       if (MODE == 2) { x[i] = y[i] - z[i]; }
       if (MODE == 3) { x[i] = y[i]; }
+      if (MODE == 4) { x[i] = y[i] + z[i]; }
+      if (MODE == 5) { const v2d b = y[i]; x[i] = v2d{c * b.x, c * b.y}; }
     }
   }
 }
@@ -204,6 +206,22 @@ int tmhip_diff(tmhip_ctx *ctx, tmhip_field *Q, tmhip_field *R, tmhip_field *S, i
   if (check_eo(Q, "diff") || check_eo(R, "diff") || check_eo(S, "diff")) return 1;
   LA_CHECK_N("diff", (void)0);
   hipLaunchKernelGGL(stream_kernel<2>, la_grid(N), dim3(LA_BS), 0, ctx->stream, Q->d, R->d, S->d, 0.0, Q->ns, N);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int tmhip_add(tmhip_ctx *ctx, tmhip_field *Q, tmhip_field *R, tmhip_field *S, int N) {
+  if (check_eo(Q, "add") || check_eo(R, "add") || check_eo(S, "add")) return 1;
+  LA_CHECK_N("add", (void)0);
+  hipLaunchKernelGGL(stream_kernel<4>, la_grid(N), dim3(LA_BS), 0, ctx->stream, Q->d, R->d, S->d, 0.0, Q->ns, N);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int tmhip_mul_r(tmhip_ctx *ctx, tmhip_field *R, double c, tmhip_field *S, int N) {
+  if (check_eo(R, "mul_r") || check_eo(S, "mul_r")) return 1;
+  LA_CHECK_N("mul_r", (void)0);
+  hipLaunchKernelGGL(stream_kernel<5>, la_grid(N), dim3(LA_BS), 0, ctx->stream, R->d, S->d, (const v2d *)nullptr, c, R->ns, N);
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -78,6 +78,8 @@ def load_library():
         "tmhip_assign_mul_add_r_and_square": [vp, vp, d, vp, i, i, pd],
         "tmhip_diff": [vp, vp, vp, vp, i],
         "tmhip_assign": [vp, vp, vp, i],
+        "tmhip_add": [vp, vp, vp, vp, i],
+        "tmhip_mul_r": [vp, vp, d, vp, i],
         "tmhip_cg_her": [vp, vp, vp, i, d, i, i, i, C.POINTER(i), pd, i],
         "tmhip_set_clover": [vp, vp, vp],
         "tmhip_sw_term": [vp, vp, d, d],
@@ -481,6 +483,12 @@ class Lattice:
 
     def diff(self, Q, R, S, N):
         _ck(self.lib.tmhip_diff(self.h, Q.h, R.h, S.h, N), "diff")
+
+    def add(self, Q, R, S, N):
+        _ck(self.lib.tmhip_add(self.h, Q.h, R.h, S.h, N), "add")
+
+    def mul_r(self, R, c, S, N):
+        _ck(self.lib.tmhip_mul_r(self.h, R.h, c, S.h, N), "mul_r")
 
     def assign(self, R, S, N):
         _ck(self.lib.tmhip_assign(self.h, R.h, S.h, N), "assign")
