@@ -236,7 +236,7 @@ int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_
 int tmhip_event_record(tmhip_ctx *ctx, int slot);
 int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double *ms);
 /* Kernel variant selection for A/B measurements; the defaults are the measured best.
- *   "block" 256|64 threads per block          "nt" 1|0 non-temporal link loads / output stores
+ *   "block" 0|256|64 threads per block (0: automatic, 64 on small local lattices)         "nt" 1|0 non-temporal link loads / output stores
  *   "xcd"   block order: 2 automatic (default; tile order up to L = 32, slab order above), 0 none, 1 one chunk per XCD,
  *           3 slab, 4 tile;  "tgrp" time-slices per tile group (0 = automatic)
  *   "occ" / "occ32"  waves per SIMD allowed by a dynamic-LDS cap for the fp64 / fp32 stencil (3 / 0 = no cap)

@@ -367,7 +367,7 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
   const int nblk = g.x * g.y;
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;   // T-split rank (or its single-rank rehearsal): reductions fused into the interior + boundary kernels
-  const bool fusable = ctx->opt_cg_fused_dot && ctx->opt_block == 256 && ctx->Vh % 256 == 0 &&
+  const bool fusable = ctx->opt_cg_fused_dot && ctx->Vh % (split ? 256 : tmhip_hop_block(ctx)) == 0 &&
                        (!split || (ctx->face % 256 == 0 && ctx->g.T >= 3));
   const bool fused = fusable && !split && op == TMHIP_OP_QTM_PM;                            // scalar product in the last stencil (cg_fused_dot = 1)
   const bool fused_full = fusable && ctx->opt_cg_fused_dot >= 2 && (op == TMHIP_OP_QTM_PM || op == TMHIP_OP_QSW_PM);

@@ -156,7 +156,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->V = g.T * g.LX * g.LY * g.LZ; ctx->Vh = ctx->V / 2; ctx->face = g.LX * g.LY * g.LZ / 2;
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
-  ctx->opt_block = 256; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0; ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 2; ctx->opt_fusedface = -1; ctx->opt_gaux = -1; ctx->opt_gdrop = 0; ctx->opt_fp32_pairs = 0; ctx->opt_occ32 = 0; ctx->opt_facesplit = 1; ctx->opt_recon = 0; ctx->gauge_recon_dev = -1.0;
+  ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0; ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 2; ctx->opt_fusedface = -1; ctx->opt_gaux = -1; ctx->opt_gdrop = 0; ctx->opt_fp32_pairs = 0; ctx->opt_occ32 = 0; ctx->opt_facesplit = 1; ctx->opt_recon = 0; ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
     int lo = 0, hi = 0;
@@ -273,7 +273,7 @@ int tmhip_gauge_su3_deviation(tmhip_ctx *ctx, double *maxdev) {
 }
 
 int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
-  if (!strcmp(name, "block")) { if (value != 64 && value != 256) TMHIP_FAIL("block must be 64 or 256"); ctx->opt_block = value; }
+  if (!strcmp(name, "block")) { if (value != 0 && value != 64 && value != 256) TMHIP_FAIL("block must be 0 (automatic), 64 or 256"); ctx->opt_block = value; }
   else if (!strcmp(name, "minw")) ctx->opt_minw = value;
   else if (!strcmp(name, "occ")) ctx->opt_occ = value;
   else if (!strcmp(name, "xcd")) ctx->opt_xcd = value;
@@ -283,6 +283,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
   else if (!strcmp(name, "fusedface")) ctx->opt_fusedface = value;
   else if (!strcmp(name, "facesplit")) ctx->opt_facesplit = value;
+  else if (!strcmp(name, "bench_graph")) ctx->opt_bench_graph = value;
   else if (!strcmp(name, "gaux")) ctx->opt_gaux = value;
   else if (!strcmp(name, "gdrop")) ctx->opt_gdrop = value;
   else if (!strcmp(name, "occ32")) ctx->opt_occ32 = value;
@@ -621,8 +622,28 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int a, int b, double *ms) {
 
 /* benchmark.c:291-300 */
 int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_field *f2, int iters, double *ms_total) {
-  if (tmhip_event_record(ctx, 14)) return 1;
   if (need_eo(f0, "bench") || need_eo(f1, "bench") || need_eo(f2, "bench")) return 1;
+  if (ctx->opt_bench_graph && ctx->g.nproc_t == 1 && !ctx->loopback) {
+    // diagnostic ("bench_graph" 1): the same loop captured into ONE hipGraph and replayed -- separates host enqueue cost from
+    // the GPU-side cost of a kernel boundary on small lattices (profiles/r01_diagnostics.md)
+    hipGraph_t graph; hipGraphExec_t exec;
+    TMHIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    for (int j = 0; j < iters; j++) {
+      if (tmhip_launch_hopping(ctx, 0, f1->d, f0->d, nullptr, EPI_STORE, 0, 0, HOP_COMM)) return 1;
+      if (tmhip_launch_hopping(ctx, 1, f2->d, f1->d, nullptr, EPI_STORE, 0, 0, HOP_COMM)) return 1;
+    }
+    TMHIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
+    TMHIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    TMHIP_CHECK(hipGraphLaunch(exec, ctx->stream));          // first replay untimed (upload of the executable graph)
+    if (tmhip_event_record(ctx, 14)) return 1;
+    TMHIP_CHECK(hipGraphLaunch(exec, ctx->stream));
+    if (tmhip_event_record(ctx, 15)) return 1;
+    const int rc = tmhip_event_elapsed_ms(ctx, 14, 15, ms_total);
+    TMHIP_CHECK(hipGraphExecDestroy(exec));
+    TMHIP_CHECK(hipGraphDestroy(graph));
+    return rc;
+  }
+  if (tmhip_event_record(ctx, 14)) return 1;
   for (int j = 0; j < iters; j++) {
     // back-to-back stencils (benchmark.c:295-296): f1 is the previous stencil's output and f0 has not been written since the loop
     // began, so on a split lattice their faces may be packed early (HOP_CHAINED); the very first call makes no such promise

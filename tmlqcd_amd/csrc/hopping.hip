@@ -57,9 +57,10 @@ int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in,
   return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
 }
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx) {
-  const int spb = fp32_pairs(ctx) ? 512 : 256;
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
-  return ctx->Vh % spb == 0 && (!split || (ctx->face % spb == 0 && ctx->g.T >= 3));
+  const int sites = fp32_pairs(ctx) ? 2 : 1;
+  const int spb = (split ? 256 : tmhip_hop_block(ctx)) * sites;
+  return ctx->Vh % spb == 0 && (!split || (ctx->face % (256 * sites) == 0 && ctx->g.T >= 3));
 }
 
 // Single-process ring: n contexts (one per GPU, or several on one GPU for the self-test) that
@@ -95,7 +96,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipEventRecord(c->ev_comm, c->comm_stream));
     hop64::HopArgs a;
     hop64::fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const hop64::HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr};
+    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr};
     hop64::launch_interior(c, a, EPI_STORE, o);
   }
   for (int r = 0; r < n; r++) {
@@ -104,7 +105,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     hop64::HopArgs a;
     hop64::fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const hop64::HopLaunch o = {c->opt_block, c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr};
+    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr};
     hop64::launch_boundary(c, a, EPI_STORE, o, c->stream);
     TMHIP_CHECK(hipGetLastError());
   }

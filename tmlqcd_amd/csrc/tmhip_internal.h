@@ -100,7 +100,7 @@ struct tmhip_ctx {
   // device-resident CG state (cg.hip)
   void *cg_state; double *cg_hist; int cg_hist_len;
   // options
-  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface; int opt_gaux; int opt_gdrop; int opt_fp32_pairs; int opt_occ32; int opt_facesplit; int opt_recon;   // opt_recon: 12 = rebuild the third row of every link in registers (opt-in)
+  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface; int opt_gaux; int opt_gdrop; int opt_fp32_pairs; int opt_occ32; int opt_facesplit; int opt_bench_graph; int opt_recon;   // opt_recon: 12 = rebuild the third row of every link in registers (opt-in)
   double gauge_recon_dev;   // max |U_row2 - conj(row0 x row1)| over all links of the resident gauge field (-1: not measured)
 };
 
@@ -111,6 +111,11 @@ struct tmhip_ctx {
     if (N < 0 || N > ctx->Vh) TMHIP_FAIL("%s: N = %d is outside [0, VOLUME/2 = %d]", who, N, ctx->Vh);                  \
     if (N == 0) { zero_out; return 0; }                                                                                 \
   } while (0)
+
+// Threads per stencil block: "block" 0 (default) picks 64 for small local lattices -- below ~2 blocks of 256 per CU a launch is
+// latency-bound and four times as many independent blocks finish sooner (8^4: 5.7 vs 7.5 us, 12^4: 9.9 vs 14.1, 20^4: 25.3 vs
+// 33.0; level at 24^4, 256 ahead from there: profiles/r01_diagnostics.md) -- and 256 otherwise.
+static inline int tmhip_hop_block(const tmhip_ctx *ctx) { return ctx->opt_block ? ctx->opt_block : (ctx->Vh <= 131072 ? 64 : 256); }
 
 // ---- launch helpers implemented across the .hip files ----
 enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4, EPI_CLOVER_INV = 5, EPI_CLOVER_G5 = 6, EPI_CLOVER = 7,
