@@ -151,7 +151,6 @@ def gen_rg(T, L, full):
     """solver/rg_mixed_cg_her.c:180 run by the reference's default (half-spinor) build: iteration counts for two
     values of mcg_delta, and the 4^4 solution."""
     sys.path.insert(0, ROOT)
-    import ctypes as C
     import numpy as np
     from oracle.refbind import RefLattice
     kappa, mu = 0.125, 0.01

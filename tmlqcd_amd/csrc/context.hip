@@ -452,11 +452,6 @@ int tmhip_H_eo_tm_inv_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int ie
   const double nrm = 1. / (1. + ctx->mu * ctx->mu), sign = _sign < 0. ? 1. : -1.;
   return tmhip_tm_times_hopping_matrix(ctx, ieo, l, k, nrm, sign * nrm * ctx->mu);
 }
-/* tm_operators.c:528-546 */
-static int tm_sub_H_eo_gamma5(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *p, tmhip_field *k, int ieo, double _sign) {
-  const double sign = _sign < 0. ? -1. : 1.;
-  return tmhip_tm_sub_hopping_matrix(ctx, ieo, l, p, k, 1., sign * ctx->mu);
-}
 // raw-pointer forms with the chaining hint: inside a composition every stencil after the first gathers the previous one's output
 static int hop_tm_inv(tmhip_ctx *ctx, v2d *l, const v2d *k, int ieo, double _sign, int flags) {   /* tm_operators.c:508-526 */
   const double nrm = 1. / (1. + ctx->mu * ctx->mu), sign = _sign < 0. ? 1. : -1.;

@@ -1,6 +1,5 @@
 """Tile-order / occupancy sweep of the plain stencil on the production-size lattices (48^3x96 = BASELINE configs[4],
 32^3x64 = configs[3] unsplit).  Usage: python tools/variants_big.py L T"""
-import itertools
 import os
 import sys
 import time
