@@ -94,6 +94,13 @@ def test_mirror_registry_is_bounded(host):
     k0, l0 = keep[0]                                          # its mirror is long gone: transparently re-created
     d.Hopping_Matrix(0, _p(l0), _p(k0)); orc.Hopping_Matrix(0, ref, k0)
     assert rel_err(l0, ref[:N]) < TOL
+    # a host buffer first seen as a full-lattice field, then re-used (same address) as a one-parity input while the registry is
+    # crowded: the re-created mirror must not become the eviction victim of the output mirror created right after it
+    buf = random_spinor(200, V); tmp = np.zeros_like(buf)
+    d.mul_r(_p(tmp), 2.0, _p(buf), V)
+    lnew = np.zeros((N, 4, 3, 2))
+    d.Hopping_Matrix(1, _p(lnew), _p(buf)); orc.Hopping_Matrix(1, ref, np.ascontiguousarray(buf[:N]))
+    assert rel_err(lnew, ref[:N]) < TOL
     d.tmlqcd_hip_set_max_mirrors(64)
 
 

@@ -130,18 +130,20 @@ __global__ __launch_bounds__(LA_BS) void cg_xp_kernel(V2 *__restrict__ X, V2 *__
 
 // fixed-order sum of the per-block partials into *out (same scheme as linalg.hip)
 #define CG_SUM_BS 1024   // one block; the fused stencils deliver one partial per wave (8192 at 32^4), so use the widest block
+// (no look at st->done: after convergence the sum is computed and ignored, which is cheaper than a dependent load in front of it)
 __global__ __launch_bounds__(CG_SUM_BS) void cg_sum_kernel(const double *__restrict__ partials, int n, double *out, const CgState *st) {
-  if (st->done) return;
-  __shared__ double sm[CG_SUM_BS];
+  __shared__ double sm[CG_SUM_BS / 64];
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += CG_SUM_BS) acc += partials[i];
-  sm[threadIdx.x] = acc;
+  acc = cg_wave_reduce(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
   __syncthreads();
-  for (int s = CG_SUM_BS / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < CG_SUM_BS / 64; w++) tot += sm[w];
+    *out = tot;
   }
-  if (threadIdx.x == 0) *out = sm[0];
 }
 
 // WHICH 0: after the dot  -> alpha = normsq / pro            (cg_her.c:93-94)
@@ -196,30 +198,50 @@ __device__ __forceinline__ void cg_scalar_update(CgState *st, const double *sum,
   }
 }
 
+// one wave: the state travels through LDS (one round trip to memory instead of a chain of dependent loads)
 template <int WHICH>
-__global__ void cg_scalar_kernel(CgState *st, const double *sum, double *hist, int hist_len) {
-  if (st->done) { if (WHICH == 0) st->x_pending = 0; return; }
-  cg_scalar_update<WHICH>(st, sum, hist, hist_len);
+__global__ __launch_bounds__(64) void cg_scalar_kernel(CgState *st, const double *sum, double *hist, int hist_len) {
+  constexpr int NW = sizeof(CgState) / sizeof(double);
+  static_assert(sizeof(CgState) % sizeof(double) == 0 && NW <= 64, "CgState is copied as doubles by one wave");
+  __shared__ CgState ls;
+  __shared__ double s;
+  const int l = threadIdx.x;
+  if (l < NW) reinterpret_cast<double *>(&ls)[l] = reinterpret_cast<const double *>(st)[l];
+  if (l == 63) s = *sum;
+  __syncthreads();
+  if (ls.done) { if (WHICH == 0 && l == 0) st->x_pending = 0; return; }
+  if (l == 0) cg_scalar_update<WHICH>(&ls, &s, hist, hist_len);
+  __syncthreads();
+  if (l < NW) reinterpret_cast<double *>(st)[l] = reinterpret_cast<const double *>(&ls)[l];
 }
 
 // single rank: the fixed-order sum of the partials and the scalar update in one launch (no all-reduce in between)
 template <int WHICH>
 __global__ __launch_bounds__(CG_SUM_BS) void cg_sum_scalar_kernel(const double *__restrict__ partials, int n, double *out, CgState *st, double *hist,
                                                                   int hist_len) {
-  if (st->done) { if (WHICH == 0 && threadIdx.x == 0) st->x_pending = 0; return; }
-  __shared__ double sm[CG_SUM_BS];
+  // The state is fetched into LDS by the last wave while the others are already loading partials: the scalar update then works
+  // on LDS instead of walking a chain of dependent global loads (done, inner, normsq, ...) after the reduction.
+  static_assert(sizeof(CgState) % sizeof(double) == 0 && sizeof(CgState) / sizeof(double) <= 64, "CgState is copied as doubles by one wave");
+  constexpr int NW = sizeof(CgState) / sizeof(double);
+  __shared__ CgState ls;
+  __shared__ double sm[CG_SUM_BS / 64];
+  const int lw = (int)threadIdx.x - (CG_SUM_BS - 64);
+  if (lw >= 0 && lw < NW) reinterpret_cast<double *>(&ls)[lw] = reinterpret_cast<const double *>(st)[lw];
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += CG_SUM_BS) acc += partials[i];
-  sm[threadIdx.x] = acc;
+  acc = cg_wave_reduce(acc);                       // fixed order: strided per-lane sums, butterfly per wave, then the 16 wave sums
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
   __syncthreads();
-  for (int s = CG_SUM_BS / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-    __syncthreads();
-  }
+  if (ls.done) { if (WHICH == 0 && threadIdx.x == 0) st->x_pending = 0; return; }   // block-uniform
   if (threadIdx.x == 0) {
-    *out = sm[0];
-    cg_scalar_update<WHICH>(st, out, hist, hist_len);
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < CG_SUM_BS / 64; w++) tot += sm[w];
+    *out = tot;
+    cg_scalar_update<WHICH>(&ls, &tot, hist, hist_len);
   }
+  __syncthreads();
+  if (lw >= 0 && lw < NW) reinterpret_cast<double *>(st)[lw] = reinterpret_cast<const double *>(&ls)[lw];
 }
 
 int tmhip_apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k) {
@@ -264,7 +286,7 @@ static int cg_her_sync(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_i
 }
 
 static int cg_allreduce(tmhip_ctx *ctx, double *x) {
-  if (ctx->comm_ready && ctx->g.nproc_t > 1)
+  if (tmhip_reduce_over_ranks(ctx))
     TMHIP_NCCL_CHECK(ncclAllReduce(x, x, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
   return 0;
 }
@@ -273,10 +295,10 @@ static int cg_allreduce(tmhip_ctx *ctx, double *x) {
 template <int WHICH>
 static int cg_reduce_update(tmhip_ctx *ctx, int n, CgState *st, double *hist, int hist_len) {
   double *sum = ctx->result_dev + 1;
-  if (ctx->comm_ready && ctx->g.nproc_t > 1) {
+  if (tmhip_reduce_over_ranks(ctx)) {
     hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(CG_SUM_BS), 0, ctx->stream, ctx->partials, n, sum, st);
     if (cg_allreduce(ctx, sum)) return 1;
-    hipLaunchKernelGGL(cg_scalar_kernel<WHICH>, dim3(1), dim3(1), 0, ctx->stream, st, sum, hist, hist_len);
+    hipLaunchKernelGGL(cg_scalar_kernel<WHICH>, dim3(1), dim3(64), 0, ctx->stream, st, sum, hist, hist_len);
   } else {
     hipLaunchKernelGGL(cg_sum_scalar_kernel<WHICH>, dim3(1), dim3(CG_SUM_BS), 0, ctx->stream, ctx->partials, n, sum, st, hist, hist_len);
   }

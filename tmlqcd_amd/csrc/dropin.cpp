@@ -123,7 +123,6 @@ void evict_if_crowded(tmhip_ctx *c, const void *keep) {
 Mirror &mirror(tmhip_ctx *c, const void *host, int kind) {
   if (g_reg.find(host) == g_reg.end()) evict_if_crowded(c, host);
   Mirror &m = g_reg[host];
-  m.last_use = ++g_tick;
   if (m.f && m.kind != kind) {   // same host buffer re-used with another shape
     if (m.dev_valid && !m.host_valid) download(c, host, m);
     tmhip_field_free(c, m.f);
@@ -133,6 +132,7 @@ Mirror &mirror(tmhip_ctx *c, const void *host, int kind) {
     CK(tmhip_field_alloc(c, kind, &m.f));
     m.kind = kind; m.dev_valid = false; m.host_valid = true;
   }
+  m.last_use = ++g_tick;   // after the reset above: a mirror in use by the current call must never be the eviction victim of its sibling
   return m;
 }
 

@@ -149,7 +149,7 @@ static int check_eo(const tmhip_field *f, const char *who) {
 
 int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out) {
   hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblocks, ctx->result_dev);
-  if (parallel && ctx->comm_ready && ctx->g.nproc_t > 1) {
+  if (parallel && tmhip_reduce_over_ranks(ctx)) {
     // MPI_Allreduce(..., MPI_SUM) of the reference (square_norm.c:314): one double over RCCL
     TMHIP_NCCL_CHECK(ncclAllReduce(ctx->result_dev, ctx->result_dev, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
   }

@@ -117,6 +117,10 @@ struct tmhip_ctx {
 // 33.0; level at 24^4, 256 ahead from there: profiles/r01_diagnostics.md) -- and 256 otherwise.
 static inline int tmhip_hop_block(const tmhip_ctx *ctx) { return ctx->opt_block ? ctx->opt_block : (ctx->Vh <= 131072 ? 64 : 256); }
 
+// Reductions go through RCCL on T-split ranks -- and in the one-rank RCCL loopback (tmhip_comm_set_loopback(ctx, 2)), so that the
+// multi-rank code path (partial sums, ncclAllReduce, scalar update as separate steps) runs in the single-GPU tests too.
+static inline bool tmhip_reduce_over_ranks(const tmhip_ctx *ctx) { return ctx->comm_ready && (ctx->g.nproc_t > 1 || ctx->loopback_rccl); }
+
 // ---- launch helpers implemented across the .hip files ----
 enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4, EPI_CLOVER_INV = 5, EPI_CLOVER_G5 = 6, EPI_CLOVER = 7,
        EPI_TM_SUB_G5_NRM = 8 /* + partials of |out|^2 */, EPI_TM_SUB_G5_RES = 9 /* resid -= alpha out, partials of |resid|^2; out not stored */,
