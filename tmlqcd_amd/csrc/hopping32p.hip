@@ -36,8 +36,10 @@ __device__ __forceinline__ double cdotd(V2T w, V2T r) {
   return (double)w.x.x * r.x.x + (double)w.y.x * r.y.x + (double)w.x.y * r.x.y + (double)w.y.y * r.y.y;
 }
 #define HOP_SITES 2
+#define HOP_COMPLEX_COMPONENTWISE 1
 #include "hopping_impl.inc"
 #undef HOP_SITES
+#undef HOP_COMPLEX_COMPONENTWISE
 }  // namespace hop32p
 #undef HOP_CTX_OCC
 #undef HOP_CTX_GAUGE
