@@ -72,8 +72,9 @@ def test_fused_epilogues(setup16, ieo):
         f.free()
 
 
-@pytest.mark.parametrize("mode,flagsync,fusedface", [(1, 1, 0), (2, 1, 0), (1, 0, 0), (1, 1, 1), (2, 1, 1)])
-def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface):
+@pytest.mark.parametrize("mode,flagsync,fusedface,facesplit", [(1, 1, 0, 1), (2, 1, 0, 1), (1, 0, 0, 1), (1, 1, 1, 1), (2, 1, 1, 1),
+                                                               (1, 1, 0, 0), (1, 0, 0, 0)])
+def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface, facesplit):
     """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self,
     consumed by the boundary kernels -- must equal the plain periodic stencil."""
     orc, lat = setup16
@@ -83,6 +84,7 @@ def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface):
     dk, dl = lat.field(k), lat.field()
     lat.set_option("fusedface", fusedface)  # 1: one kernel, face blocks wait in-kernel for the exchanged faces
     lat.set_option("flagsync", flagsync)  # cross-stream ordering by device flags (default) or HIP events
+    lat.set_option("facesplit", facesplit)  # 1: face kernel with the hops of a site over four waves, 0: one thread per face site
     lat.set_loopback(mode)  # 1: D2D copies, 2: one-rank RCCL communicator (ncclSend/Recv to self)
     try:
         for rep in range(3):       # repeated calls re-use the face buffers: a stale-cache bug would show here
@@ -104,6 +106,7 @@ def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface):
         lat.set_loopback(0)
         lat.set_option("flagsync", 1)
         lat.set_option("fusedface", -1)
+        lat.set_option("facesplit", 1)
     dk.free(); dl.free()
 
 
