@@ -245,6 +245,7 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "facesplit" 1|0 two-kernel split path: face kernel with the eight hops of a site spread over the four waves of a block (default) vs one thread per face site
  *   "cg_fused_dot" 2 (default: alpha / residual / norm in the stencil epilogues), 1 scalar product only, 0 plain linalg kernels
  *   "cg_sync" 1: host-side scalars as in the reference loop;  "cg_batch" n: iterations enqueued between two polls of `done`
+ *   "bench_graph" 1: tmhip_bench_hopping captures its loop into one hipGraph and replays it (diagnostic: launch floor on small lattices)
  *   "gaux" / "gdrop": diagnostics (gauge links through a buffer descriptor / dropped), profiles/r01_diagnostics.md
  * One option changes what is read from memory:
  * "gauge_recon" = 12 makes the twisted-mass stencil launches (fp64 and fp32) fetch only the first two rows of every link and
