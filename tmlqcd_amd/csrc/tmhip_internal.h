@@ -100,7 +100,12 @@ struct tmhip_ctx {
   // device-resident CG state (cg.hip)
   void *cg_state; double *cg_hist; int cg_hist_len;
   // options
-  int opt_block; int opt_xcd; int opt_nt; int opt_minw; int opt_occ; int opt_cg_sync; int opt_cg_batch; int opt_tgrp; int opt_shape; int opt_flagsync; int opt_cg_fused_dot; int opt_fusedface; int opt_gaux; int opt_gdrop; int opt_fp32_pairs; int opt_occ32; int opt_facesplit; int opt_bench_graph; int opt_recon;   // opt_recon: 12 = rebuild the third row of every link in registers (opt-in)
+  int opt_block, opt_xcd, opt_nt, opt_minw, opt_occ, opt_occ32;        // stencil launch shape (tmhip_set_option, include/tmlqcd_hip.h)
+  int opt_tgrp, opt_shape, opt_gaux, opt_gdrop, opt_fp32_pairs;
+  int opt_recon;                                                        // 12 = rebuild the third row of every link in registers (opt-in)
+  int opt_flagsync, opt_fusedface, opt_facesplit;                       // split path
+  int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot;                      // cg_her
+  int opt_bench_graph;
   double gauge_recon_dev;   // max |U_row2 - conj(row0 x row1)| over all links of the resident gauge field (-1: not measured)
 };
 
