@@ -150,11 +150,15 @@ int tmhip_multi_deriv_Sb(int n, tmhip_ctx **ctxs, int ieo, tmhip_field **l, tmhi
  * device-resident; zero them, accumulate the spinor outer products (operator/clover_deriv.c:252) and the tr-log term
  * (clover_deriv.c:72; needs sw_inv of that parity), then tmhip_sw_all (operator/clover_accumulate_deriv.c:58) adds the sixteen
  * link derivatives per plane and site to the SAME derivative accumulator tmhip_deriv_Sb uses.  gauge_field = NULL reuses the
- * lexicographic copy kept by the last tmhip_sw_term.  tmhip_get_swpm returns su3 swm[VOLUME][4] / swp[VOLUME][4].  Single rank. */
+ * lexicographic copy kept by the last tmhip_sw_term.  tmhip_get_swpm returns su3 swm[VOLUME][4] / swp[VOLUME][4].
+ * T-split ranks: sw_spinor_eo / sw_deriv are site-local; sw_all exchanges its contributions to the neighbours' links (see below). */
 int tmhip_swpm_zero(tmhip_ctx *ctx);
 int tmhip_sw_spinor_eo(tmhip_ctx *ctx, int ieo, tmhip_field *kk, tmhip_field *ll, double fac);
 int tmhip_sw_deriv(tmhip_ctx *ctx, int ieo, double mu);
 int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_field, double kappa, double c_sw);
+/* sw_all on a T-split lattice held by n contexts of THIS process (peer copies instead of RCCL for the two-sided derivative halo
+ * that xchange/xchange_deri.c ships); every context needs its own tmhip_sw_term (which keeps the links incl. halo slabs). */
+int tmhip_multi_sw_all(int n, tmhip_ctx **ctxs, double kappa, double c_sw);
 int tmhip_get_swpm(tmhip_ctx *ctx, void *swm, void *swp);
 
 /* ---- clover twisted mass (invert_clover_eo.c:63-165) ------

@@ -195,6 +195,57 @@ def test_clover_force_chain_against_oracle(dims, mu):
     lat.close()
 
 
+@pytest.mark.parametrize("T", [2, 4])
+def test_clover_force_on_two_t_slabs(T):
+    """sw_all on T-split ranks: the leaves next to the t-faces reach links of BOTH ring neighbours (the two-sided derivative halo
+    of xchange_deri.c).  Two contexts holding the two halves of the lattice (own sw_term / sw_invert from halo links, site-local
+    sw_spinor_eo / sw_deriv, contributions exchanged by peer copies) == the unsplit oracle, together with deriv_Sb."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    from tmlqcd_amd.hip import multi_deriv_Sb, multi_sw_all
+    L, world = 4, 2
+    Tg = T * world
+    kappa, mu, c_sw, theta = 0.13, 0.02, 1.4, (1.0, 0.25, 0.0, 0.5)
+    g = Oracle(Tg, L, L, L, kappa=kappa, mu=mu, theta=theta, threads=4)
+    g.set_gauge(syn.gauge_field(16, Tg, L, L, L))
+    sw = g.sw_term(kappa, c_sw); swi, _ = g.sw_invert(sw, 0, mu)
+    g.set_clover(sw, swi)
+    Ng, Vg = g.Vh, g.V
+    fo = []
+    for i, par in enumerate((1, 1, 0, 0)):                    # fields 0,1 on odd sites, 2,3 on even sites
+        b = g.new_field(); b[:Ng] = syn.spinor_field_eo(20 + i, par, Tg, L, L, L); fo.append(b)
+    swm, swp = np.zeros((Vg, 4, 3, 3, 2)), np.zeros((Vg, 4, 3, 3, 2))
+    g.sw_spinor_eo(0, swm, swp, fo[2], fo[3], 0.7)
+    g.sw_spinor_eo(1, swm, swp, fo[0], fo[1], 0.7)
+    g.sw_deriv(0, swm, swp, mu)
+    ref = np.zeros((g.VPR, 4, 8))
+    g.deriv_Sb(1, fo[0], fo[2], ref, 0.7)
+    g.sw_all(ref, swm, swp, kappa, c_sw)
+    lats = [Lattice(T, L, L, L, kappa=kappa, mu=mu, theta=theta, nproc_t=world, proc_t=r) for r in range(world)]
+    fd = []
+    for r, lat in enumerate(lats):
+        gr = syn.gauge_field(16, T, L, L, L, world, r)
+        lat.set_gauge(gr)
+        lat.sw_term(gr, kappa, c_sw); lat.sw_invert(0, mu)
+        fr = [lat.field(syn.spinor_field_eo(20 + i, par, T, L, L, L, world, r)) for i, par in enumerate((1, 1, 0, 0))]
+        fd.append(fr)
+        lat.swpm_zero()
+        lat.sw_spinor_eo(0, fr[2], fr[3], 0.7)
+        lat.sw_spinor_eo(1, fr[0], fr[1], 0.7)
+        lat.sw_deriv(0, mu)
+        gm, gp = lat.get_swpm()
+        V = lat.V
+        assert rel_err(gm, swm[r * V:(r + 1) * V]) < TOL and rel_err(gp, swp[r * V:(r + 1) * V]) < TOL, r
+        lat.derivative_zero()
+    multi_deriv_Sb(lats, 1, [f[0] for f in fd], [f[2] for f in fd], 0.7)
+    multi_sw_all(lats, kappa, c_sw)
+    V = lats[0].V
+    for r, lat in enumerate(lats):
+        assert rel_err(lat.derivative(), ref[r * V:(r + 1) * V]) < 4 * TOL, r
+        lat.close()
+
+
 def test_clover_force_through_the_drop_in(host_stub):
     """cloverdet_derivative's clover statements through the drop-in helpers on host arrays: the contribution lands in
     hf->derivative next to deriv_Sb's (coherent mode)."""

@@ -398,10 +398,21 @@ __device__ __forceinline__ M3 m3_dag(const M3 &a) {
     for (int j = 0; j < 3; j++) r.e[3 * i + j] = m3_conj(a.e[3 * j + i]);
   return r;
 }
-// su3adj.h:164-172 scattered with atomics: neighbouring sites contribute to the same link (the reference's _nonlocal update)
-__device__ __forceinline__ void tl_atomic_add(double *deriv, int Vh, int par, int idx, int mu, double c, const M3 &a) {
-  double *d = deriv + ((size_t)par * 32 + (size_t)mu * 8) * Vh + idx;
-  const size_t st = Vh;
+// su3adj.h:164-172 scattered with atomics: neighbouring sites contribute to the same link (the reference's _nonlocal update).
+// `site` is a lexicographic index; on a T-split rank it may lie in the t = T / t = -1 halo slabs (site >= V): those
+// contributions belong to links of the ring neighbours and are collected in `halo` [2 slabs][4 mu][8][XYZ] for the exchange
+// (xchange_deri.c, both directions).
+__device__ __forceinline__ void tl_atomic_add(double *deriv, double *halo, const LexGeom &g, int Vh, int par, int site, int mu, double c, const M3 &a) {
+  double *d;
+  size_t st;
+  if (site >= g.V) {
+    const int XYZ = g.LX * g.LY * g.LZ, slab = (site - g.V) / XYZ, sp = (site - g.V) - slab * XYZ;
+    d = halo + ((size_t)slab * 32 + (size_t)mu * 8) * XYZ + sp;
+    st = XYZ;
+  } else {
+    d = deriv + ((size_t)par * 32 + (size_t)mu * 8) * Vh + (site >> 1);
+    st = Vh;
+  }
   atomicAdd(d + 0 * st, c * (-a.e[3].y - a.e[1].y));
   atomicAdd(d + 1 * st, c * (+a.e[3].x - a.e[1].x));
   atomicAdd(d + 2 * st, c * (-a.e[0].y + a.e[4].y));
@@ -414,8 +425,8 @@ __device__ __forceinline__ void tl_atomic_add(double *deriv, int Vh, int par, in
 
 // operator/clover_accumulate_deriv.c:58-205: thread = (lexicographic site x, plane (k,l)); sixteen link derivatives from the
 // four leaves with the insertion matrix vis[k][l]
-__global__ __launch_bounds__(64) void sw_all_kernel(const v2d *__restrict__ raw, const v2d *__restrict__ swpm, double *__restrict__ deriv, LexGeom g,
-                                                    int Vh, double c) {
+__global__ __launch_bounds__(64) void sw_all_kernel(const v2d *__restrict__ raw, const v2d *__restrict__ swpm, double *__restrict__ deriv,
+                                                    double *__restrict__ halo, LexGeom g, int Vh, double c) {
   const int x = blockIdx.x * 64 + threadIdx.x;
   if (x >= g.V) return;
   const int p = blockIdx.y;
@@ -451,35 +462,34 @@ __global__ __launch_bounds__(64) void sw_all_kernel(const v2d *__restrict__ raw,
     for (int e = 0; e < 9; e++) V.e[e] -= Vd.e[e];
   }
   M3 v1, v2, vv1, vv2, plaq, w1, w2, w3, w4;
-  const int ix = x >> 1;
   // leaf 1
   w1 = m3_load(raw, x, k); w2 = m3_load(raw, xpk, l); w3 = m3_load(raw, xpl, k); w4 = m3_load(raw, x, l);
   v1 = m3_mul<false, false>(w1, w2); v2 = m3_mul<false, false>(w4, w3); plaq = m3_mul<false, true>(v1, v2);
-  vv1 = m3_mul<false, false>(plaq, V);                                           tl_atomic_add(deriv, Vh, p0, ix, k, c, vv1);
-  vv2 = m3_mul<true, false>(w1, vv1); vv1 = m3_mul<false, false>(vv2, w1);       tl_atomic_add(deriv, Vh, p1, xpk >> 1, l, c, vv1);
-  vv2 = m3_mul<false, false>(V, plaq); vv1 = m3_dag(vv2);                        tl_atomic_add(deriv, Vh, p0, ix, l, c, vv1);
-  vv2 = m3_mul<true, false>(w4, vv1); vv1 = m3_mul<false, false>(vv2, w4);       tl_atomic_add(deriv, Vh, p1, xpl >> 1, k, c, vv1);
+  vv1 = m3_mul<false, false>(plaq, V);                                           tl_atomic_add(deriv, halo, g, Vh, p0, x, k, c, vv1);
+  vv2 = m3_mul<true, false>(w1, vv1); vv1 = m3_mul<false, false>(vv2, w1);       tl_atomic_add(deriv, halo, g, Vh, p1, xpk, l, c, vv1);
+  vv2 = m3_mul<false, false>(V, plaq); vv1 = m3_dag(vv2);                        tl_atomic_add(deriv, halo, g, Vh, p0, x, l, c, vv1);
+  vv2 = m3_mul<true, false>(w4, vv1); vv1 = m3_mul<false, false>(vv2, w4);       tl_atomic_add(deriv, halo, g, Vh, p1, xpl, k, c, vv1);
   // leaf 2
   w1 = m3_load(raw, x, l); w2 = m3_load(raw, xplmk, k); w3 = m3_load(raw, xmk, l); w4 = m3_load(raw, xmk, k);
   v1 = m3_mul<false, true>(w1, w2); v2 = m3_mul<true, false>(w3, w4); plaq = m3_mul<false, false>(v1, v2);
-  vv1 = m3_mul<false, false>(plaq, V);                                           tl_atomic_add(deriv, Vh, p0, ix, l, c, vv1);
-  vv1 = m3_dag(v1); vv2 = m3_mul<false, true>(vv1, V); vv1 = m3_mul<false, true>(vv2, v2);   tl_atomic_add(deriv, Vh, p0, xplmk >> 1, k, c, vv1);
-  vv2 = m3_mul<false, false>(w3, vv1); vv1 = m3_mul<false, true>(vv2, w3);       tl_atomic_add(deriv, Vh, p1, xmk >> 1, l, c, vv1);
-  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, Vh, p1, xmk >> 1, k, c, vv2);
+  vv1 = m3_mul<false, false>(plaq, V);                                           tl_atomic_add(deriv, halo, g, Vh, p0, x, l, c, vv1);
+  vv1 = m3_dag(v1); vv2 = m3_mul<false, true>(vv1, V); vv1 = m3_mul<false, true>(vv2, v2);   tl_atomic_add(deriv, halo, g, Vh, p0, xplmk, k, c, vv1);
+  vv2 = m3_mul<false, false>(w3, vv1); vv1 = m3_mul<false, true>(vv2, w3);       tl_atomic_add(deriv, halo, g, Vh, p1, xmk, l, c, vv1);
+  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, halo, g, Vh, p1, xmk, k, c, vv2);
   // leaf 3
   w1 = m3_load(raw, xmk, k); w2 = m3_load(raw, xmkml, l); w3 = m3_load(raw, xmkml, k); w4 = m3_load(raw, xml, l);
   v2 = m3_mul<false, false>(w3, w4);
-  vv1 = m3_mul<false, true>(w1, V); vv2 = m3_mul<false, true>(vv1, v2); vv1 = m3_mul<false, false>(vv2, w2);   tl_atomic_add(deriv, Vh, p1, xmk >> 1, k, c, vv1);
-  vv2 = m3_mul<false, false>(w2, vv1); vv1 = m3_mul<false, true>(vv2, w2);       tl_atomic_add(deriv, Vh, p0, xmkml >> 1, l, c, vv1);
-  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, Vh, p0, xmkml >> 1, k, c, vv2);
-  vv1 = m3_mul<true, false>(w3, vv2); vv2 = m3_mul<false, false>(vv1, w3);       tl_atomic_add(deriv, Vh, p1, xml >> 1, l, c, vv2);
+  vv1 = m3_mul<false, true>(w1, V); vv2 = m3_mul<false, true>(vv1, v2); vv1 = m3_mul<false, false>(vv2, w2);   tl_atomic_add(deriv, halo, g, Vh, p1, xmk, k, c, vv1);
+  vv2 = m3_mul<false, false>(w2, vv1); vv1 = m3_mul<false, true>(vv2, w2);       tl_atomic_add(deriv, halo, g, Vh, p0, xmkml, l, c, vv1);
+  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, halo, g, Vh, p0, xmkml, k, c, vv2);
+  vv1 = m3_mul<true, false>(w3, vv2); vv2 = m3_mul<false, false>(vv1, w3);       tl_atomic_add(deriv, halo, g, Vh, p1, xml, l, c, vv2);
   // leaf 4
   w1 = m3_load(raw, xml, l); w2 = m3_load(raw, xml, k); w3 = m3_load(raw, xpkml, l); w4 = m3_load(raw, x, k);
   v1 = m3_mul<true, false>(w1, w2); v2 = m3_mul<false, true>(w3, w4);
-  vv1 = m3_mul<false, true>(w1, V); vv2 = m3_mul<false, true>(vv1, v2); vv1 = m3_mul<false, true>(vv2, w2);    tl_atomic_add(deriv, Vh, p1, xml >> 1, l, c, vv1);
-  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, Vh, p1, xml >> 1, k, c, vv2);
-  vv1 = m3_mul<true, false>(w2, vv2); vv2 = m3_mul<false, false>(vv1, w2);       tl_atomic_add(deriv, Vh, p0, xpkml >> 1, l, c, vv2);
-  vv2 = m3_dag(v2); vv1 = m3_mul<false, true>(vv2, v1); vv2 = m3_mul<false, true>(vv1, V);   tl_atomic_add(deriv, Vh, p0, ix, k, c, vv2);
+  vv1 = m3_mul<false, true>(w1, V); vv2 = m3_mul<false, true>(vv1, v2); vv1 = m3_mul<false, true>(vv2, w2);    tl_atomic_add(deriv, halo, g, Vh, p1, xml, l, c, vv1);
+  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, halo, g, Vh, p1, xml, k, c, vv2);
+  vv1 = m3_mul<true, false>(w2, vv2); vv2 = m3_mul<false, false>(vv1, w2);       tl_atomic_add(deriv, halo, g, Vh, p0, xpkml, l, c, vv2);
+  vv2 = m3_dag(v2); vv1 = m3_mul<false, true>(vv2, v1); vv2 = m3_mul<false, true>(vv1, V);   tl_atomic_add(deriv, halo, g, Vh, p0, x, k, c, vv2);
 }
 
 static int need64(const tmhip_field *f, const char *who) {
@@ -654,11 +664,21 @@ int tmhip_sw_deriv(tmhip_ctx *ctx, int ieo, double mu) {
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }
-/* operator/clover_accumulate_deriv.c:58 sw_all(hf, kappa, c_sw): adds the clover-leaf derivatives to the device-resident derivative
- * field (the one tmhip_deriv_Sb accumulates into).  gauge_field: host links as for tmhip_set_gauge, or NULL to reuse the copy kept
- * by the last tmhip_sw_term.  Single-rank lattices: the leaves of a T-split rank would touch links owned by its neighbours. */
-int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_sw) {
-  if (ctx->g.nproc_t > 1) TMHIP_FAIL("sw_all: T-split ranks need the derivative halo of xchange_deri, not built");
+// what the ring neighbours computed for OUR links: slab 0 of the down neighbour is our t = 0 slice, slab 1 of the up neighbour our t = T-1
+__global__ __launch_bounds__(256) void deriv_halo_add_kernel(double *__restrict__ deriv, const double *__restrict__ recv, LexGeom g, int Vh) {
+  const int XYZ = g.LX * g.LY * g.LZ;
+  const int sp = blockIdx.x * 256 + threadIdx.x;
+  if (sp >= XYZ) return;
+  const int w = blockIdx.y;                         // 0: t = 0 (from below), 1: t = T-1 (from above)
+  const int t = w ? g.T - 1 : 0;
+  const int z = sp % g.LZ, y = (sp / g.LZ) % g.LY, x = sp / (g.LZ * g.LY);
+  const int par = (t + x + y + z) & 1;              // local T is even: local and global parity agree
+  const int idx = (t * XYZ + sp) >> 1;
+#pragma unroll 4
+  for (int m = 0; m < 32; m++) deriv[((size_t)par * 32 + m) * Vh + idx] += recv[((size_t)w * 32 + m) * XYZ + sp];
+}
+
+static int sw_all_prepare(tmhip_ctx *ctx, const void *gauge_host) {
   if (!ctx->swpm) TMHIP_FAIL("sw_all called before sw_spinor_eo / sw_deriv");
   TMHIP_CHECK(hipSetDevice(ctx->device));
   const size_t gbytes = (size_t)ctx->VPR * 4 * 9 * sizeof(v2d);
@@ -670,10 +690,66 @@ int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_
     TMHIP_FAIL("sw_all: no lexicographic gauge field on the device (pass the host field, or call tmhip_sw_term after tmhip_set_gauge)");
   }
   if (!ctx->deriv && tmhip_derivative_zero(ctx)) return 1;
-  LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, 0};
+  if (ctx->g.nproc_t > 1) {
+    const size_t hb = (size_t)2 * 32 * ctx->g.LX * ctx->g.LY * ctx->g.LZ * sizeof(double);
+    if (!ctx->deriv_halo) TMHIP_CHECK(hipMalloc((void **)&ctx->deriv_halo, hb));
+    if (!ctx->deriv_halo_recv) TMHIP_CHECK(hipMalloc((void **)&ctx->deriv_halo_recv, hb));
+    TMHIP_CHECK(hipMemsetAsync(ctx->deriv_halo, 0, hb, ctx->stream));
+  }
+  return 0;
+}
+static int sw_all_launch(tmhip_ctx *ctx, double kappa, double c_sw) {
+  LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, ctx->g.nproc_t > 1 ? 1 : 0};
   hipLaunchKernelGGL(sw_all_kernel, dim3((ctx->V + 63) / 64, 6), dim3(64), 0, ctx->stream, (const v2d *)ctx->gauge_raw, (const v2d *)ctx->swpm, ctx->deriv,
-                     g, ctx->Vh, -2. * (kappa * c_sw / 8.));
+                     ctx->deriv_halo, g, ctx->Vh, -2. * (kappa * c_sw / 8.));
   TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+static int sw_all_add_received(tmhip_ctx *ctx) {
+  LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, 1};
+  const int XYZ = ctx->g.LX * ctx->g.LY * ctx->g.LZ;
+  hipLaunchKernelGGL(deriv_halo_add_kernel, dim3((XYZ + 255) / 256, 2), dim3(256), 0, ctx->stream, ctx->deriv, (const double *)ctx->deriv_halo_recv, g, ctx->Vh);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* operator/clover_accumulate_deriv.c:58 sw_all(hf, kappa, c_sw): adds the clover-leaf derivatives to the device-resident derivative
+ * field (the one tmhip_deriv_Sb accumulates into).  gauge_field: host links as for tmhip_set_gauge (with the halo slabs on a
+ * T-split rank), or NULL to reuse the copy kept by the last tmhip_sw_term.  On T-split ranks the leaves next to the t-faces reach
+ * links of both ring neighbours: those contributions are collected per slab and exchanged over RCCL (the job of xchange_deri.c,
+ * which ships one direction only and marks the other as missing for the clover case, :88-89), then added to the own links. */
+int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_sw) {
+  if (sw_all_prepare(ctx, gauge_host) || sw_all_launch(ctx, kappa, c_sw)) return 1;
+  if (ctx->g.nproc_t == 1) return 0;
+  if (!ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
+  const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
+  const size_t n = (size_t)32 * ctx->g.LX * ctx->g.LY * ctx->g.LZ;   // doubles per slab
+  TMHIP_NCCL_CHECK(ncclGroupStart());
+  TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo, n, ncclDouble, up, ctx->comm, ctx->stream));            // our t = T slab  -> up neighbour's t = 0
+  TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo + n, n, ncclDouble, dn, ctx->comm, ctx->stream));        // our t = -1 slab -> down neighbour's t = T-1
+  TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv, n, ncclDouble, dn, ctx->comm, ctx->stream));       // the down neighbour's t = T slab is our t = 0
+  TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv + n, n, ncclDouble, up, ctx->comm, ctx->stream));   // the up neighbour's t = -1 slab is our t = T-1
+  TMHIP_NCCL_CHECK(ncclGroupEnd());
+  return sw_all_add_received(ctx);
+}
+/* The same on a T-split lattice held by n contexts of one process (peer copies instead of RCCL), as tmhip_multi_deriv_Sb. */
+int tmhip_multi_sw_all(int n, tmhip_ctx **ctxs, double kappa, double c_sw) {
+  if (n < 2) TMHIP_FAIL("tmhip_multi_sw_all needs >= 2 contexts");
+  for (int r = 0; r < n; r++) {
+    tmhip_ctx *c = ctxs[r];
+    if (c->g.nproc_t != n || c->g.proc_t != r) TMHIP_FAIL("context %d is not rank %d of a %d-way T split", r, r, n);
+    if (sw_all_prepare(c, nullptr) || sw_all_launch(c, kappa, c_sw)) return 1;
+  }
+  for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
+  const size_t sb = (size_t)32 * ctxs[0]->g.LX * ctxs[0]->g.LY * ctxs[0]->g.LZ * sizeof(double);
+  for (int r = 0; r < n; r++) {
+    tmhip_ctx *c = ctxs[r], *up = ctxs[(r + 1) % n], *dn = ctxs[(r + n - 1) % n];
+    TMHIP_CHECK(hipSetDevice(c->device));
+    TMHIP_CHECK(hipMemcpyPeerAsync(c->deriv_halo_recv, c->device, dn->deriv_halo, dn->device, sb, c->stream));
+    TMHIP_CHECK(hipMemcpyPeerAsync((char *)c->deriv_halo_recv + sb, c->device, (char *)up->deriv_halo + sb, up->device, sb, c->stream));
+    if (sw_all_add_received(c)) return 1;
+  }
+  for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
   return 0;
 }
 /* swm / swp in the reference's host layout: su3 [VOLUME][4] each (either pointer may be NULL) */

@@ -219,6 +219,8 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->deriv) (void)hipFree(ctx->deriv);
   if (ctx->force_send) (void)hipFree(ctx->force_send);
   if (ctx->force_recv) (void)hipFree(ctx->force_recv);
+  if (ctx->deriv_halo) (void)hipFree(ctx->deriv_halo);
+  if (ctx->deriv_halo_recv) (void)hipFree(ctx->deriv_halo_recv);
   if (ctx->comm_ready) ncclCommDestroy(ctx->comm);
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);

@@ -96,6 +96,7 @@ struct tmhip_ctx {
   unsigned int *sync_flags; unsigned int hop_seq;  // [0] in-ready, [1] boundary-done, [2] timeout error
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
   double *deriv;
+  double *deriv_halo, *deriv_halo_recv;   // T-split sw_all: [2 slabs (t = T, t = -1)][4 mu][8][LX LY LZ] contributions to the neighbours' links / theirs to ours
   v2d *force_send, *force_recv;   // T-split deriv_Sb: [24][face] t=0 slices of (l, k), ours / the up-neighbour's
   // device-resident CG state (cg.hip)
   void *cg_state; double *cg_hist; int cg_hist_len;

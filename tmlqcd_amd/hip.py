@@ -90,6 +90,7 @@ def load_library():
         "tmhip_deriv_Sb": [vp, i, vp, vp, d],
         "tmhip_derivative_download": [vp, vp, i],
         "tmhip_multi_deriv_Sb": [i, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), d],
+        "tmhip_multi_sw_all": [i, C.POINTER(vp), d, d],
         "tmhip_sw_invert": [vp, i, d],
         "tmhip_get_clover": [vp, vp, vp],
         "tmhip_clover_inv": [vp, vp, i, d],
@@ -543,3 +544,10 @@ def multi_deriv_Sb(lats, ieo, ls, ks, factor):
     arr = C.c_void_p * n
     _ck(lats[0].lib.tmhip_multi_deriv_Sb(n, arr(*[l.h for l in lats]), ieo, arr(*[f.h for f in ls]), arr(*[f.h for f in ks]),
                                          factor), "tmhip_multi_deriv_Sb")
+
+
+def multi_sw_all(lats, kappa, c_sw):
+    """sw_all on a T-split lattice held by several contexts of THIS process (two-sided derivative halo by peer copies)."""
+    n = len(lats)
+    arr = C.c_void_p * n
+    _ck(lats[0].lib.tmhip_multi_sw_all(n, arr(*[l.h for l in lats]), kappa, c_sw), "tmhip_multi_sw_all")
