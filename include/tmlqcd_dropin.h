@@ -80,6 +80,7 @@ void Q_plus_psi(spinor *const l, spinor *const k);
 void Q_minus_psi(spinor *const l, spinor *const k);
 void M_minus_psi(spinor *const l, spinor *const k);
 void D_dagg_psi(spinor *const l, spinor *const k);
+void Q_pm_psi_prec(spinor *const l, spinor *const k);   /* tm_operators.c:402; spinorPrecondition stays reference code (weak reference) */
 void Q_pm_psi2(spinor *const l, spinor *const k);       /* tm_operators.c:453 */
 void Q_pm_psi_gpu(spinor *const l, spinor *const k);    /* tm_operators.c:440; gamma5 is applied to k IN PLACE first */
 void Q_minus_psi_gpu(spinor *const l, spinor *const k); /* tm_operators.c:476; likewise */

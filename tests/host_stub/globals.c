@@ -36,6 +36,7 @@ void stub_boundary(double kappa, double x0, double x1, double x2, double x3) {
   ka2 = kappa * cexp(x2 * PI_ / LY * I); ka3 = kappa * cexp(x3 * PI_ / LZ * I);
 }
 void stub_set_mu(double mu) { g_mu = mu; }
+double stub_get_mu(void) { return g_mu; }
 void stub_mark_gauge_dirty(void) { g_update_gauge_copy = 1; }
 int stub_gauge_flag(void) { return g_update_gauge_copy; }
 

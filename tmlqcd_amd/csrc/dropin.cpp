@@ -543,6 +543,44 @@ void Q_pm_psi2(spinor *const l, spinor *const k) {
   g5_full(c, fl, fl);
   done(c, l);
 }
+/* tm_operators.c:402-436 : Q_pm_psi with spinorPrecondition() (solver/dirac_operator_eigenvectors.c, FFTW-based, stays in
+ * tmLQCD) applied before, between and after the two D_psi where g_prec_sequence_d_dagger_d[] is non-zero.  Host-level
+ * composition over this library's own assign / D_psi / gamma5; the preconditioner and its globals are weak references, so a host
+ * program that does not link them still resolves this symbol and gets the unpreconditioned sequence. */
+extern void *g_precWS __attribute__((weak));                       /* global.h:267 */
+extern double g_prec_sequence_d_dagger_d[3] __attribute__((weak)); /* solver/dirac_operator_eigenvectors.h:67 */
+extern int L __attribute__((weak));                                /* global.h:82 */
+void spinorPrecondition(spinor *spinor_out, const spinor *spinor_in, void *ws, int tt, int ll, const TM_COMPLEX alpha,
+                        unsigned int dagger, unsigned int autofft) __attribute__((weak));
+void Q_pm_psi_prec(spinor *const l, spinor *const k) {
+  double seq[3] = {0., 0., 0.};
+  if (g_prec_sequence_d_dagger_d) for (int i = 0; i < 3; i++) seq[i] = g_prec_sequence_d_dagger_d[i];
+  const bool any = seq[0] != 0. || seq[1] != 0. || seq[2] != 0.;
+  if (any && (!spinorPrecondition || !&g_precWS || !&L))
+    die("Q_pm_psi_prec: g_prec_sequence_d_dagger_d is set but spinorPrecondition (solver/dirac_operator_eigenvectors.c) is not linked");
+  static spinor *tmp = nullptr;
+  static int tmp_sites = 0;
+  if (tmp_sites < VOLUMEPLUSRAND) {
+    free(tmp);
+    tmp = (spinor *)malloc((size_t)VOLUMEPLUSRAND * sizeof(spinor));
+    if (!tmp) die("Q_pm_psi_prec: out of host memory");
+    tmp_sites = VOLUMEPLUSRAND;
+  }
+  auto prec = [&](spinor *out_, const spinor *in_, double a) {
+    TM_COMPLEX alpha = a;
+    spinorPrecondition(out_, in_, g_precWS, T, L, alpha, 0, 1);
+    tmlqcd_hip_host_modified(out_);
+  };
+  if (seq[0] != 0.) { tmlqcd_hip_sync_to_host(k); prec(l, k, seq[0]); } else assign(l, k, VOLUME);
+  g_mu = -g_mu;
+  D_psi(tmp, l);
+  gamma5(l, tmp, VOLUME);
+  g_mu = -g_mu;
+  if (seq[1] != 0.) { tmlqcd_hip_sync_to_host(l); prec(l, l, seq[1]); }
+  D_psi(tmp, l);
+  gamma5(l, tmp, VOLUME);
+  if (seq[2] != 0.) { tmlqcd_hip_sync_to_host(l); prec(l, l, seq[2]); }
+}
 /* tm_operators.c:440-449 : "version for the gpu", gamma5 applied to the INPUT in place first, none at the end */
 void Q_pm_psi_gpu(spinor *const l, spinor *const k) {
   tmhip_ctx *c = refresh(true);
