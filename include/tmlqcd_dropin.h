@@ -80,6 +80,10 @@ void Q_plus_psi(spinor *const l, spinor *const k);
 void Q_minus_psi(spinor *const l, spinor *const k);
 void M_minus_psi(spinor *const l, spinor *const k);
 void D_dagg_psi(spinor *const l, spinor *const k);
+typedef struct { float c[24]; } spinor32;   /* su3.h:83: spinor32 = 4 x su3_vector32 = 12 complex float */
+void mul_one_pm_imu_inv_32(spinor32 *const l, const double _sign, const int N);                                        /* tm_operators.c:74 */
+void assign_mul_one_pm_imu_inv_32(spinor32 *const l, spinor32 *const k, const double _sign, const int N);              /* tm_operators.h */
+void mul_one_pm_imu_sub_mul_32(spinor32 *const l, spinor32 *const k, spinor32 *const j, const double _sign, const int N); /* tm_operators.c:103 */
 void Q_pm_psi_prec(spinor *const l, spinor *const k);   /* tm_operators.c:402; spinorPrecondition stays reference code (weak reference) */
 void Q_pm_psi2(spinor *const l, spinor *const k);       /* tm_operators.c:453 */
 void Q_pm_psi_gpu(spinor *const l, spinor *const k);    /* tm_operators.c:440; gamma5 is applied to k IN PLACE first */

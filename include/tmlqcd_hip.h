@@ -206,6 +206,10 @@ int tmhip_square_norm_32(tmhip_ctx *ctx, tmhip_field *P, int N, int parallel, do
 int tmhip_scalar_prod_r_32(tmhip_ctx *ctx, tmhip_field *S, tmhip_field *R, int N, int parallel, double *out);
 int tmhip_assign_add_mul_r_32(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, float c, int N);
 int tmhip_assign_mul_add_r_32(tmhip_ctx *ctx, tmhip_field *R, float c, tmhip_field *S, int N);
+/* l = zc (.) k [- j] on HOST spinor32 arrays of any length N (zc = z on spin 0,1, conj(z) on spin 2,3; j may be NULL; l may alias
+ * k or j): the fp32 instances mul_one_pm_imu_inv_32 / assign_mul_one_pm_imu_inv_32 / mul_one_pm_imu_sub_mul_32 that
+ * operator/tm_operators.c:8-47 generates and solver/Msap.c calls on domain blocks.  Staged through the device, synchronous. */
+int tmhip_diag32_host(tmhip_ctx *ctx, void *l, const void *k, const void *j, double zre, double zim, int N);
 /* mixed_cg_her(P,Q,params,max_iter,eps_sq,rel_prec,N,f,f32)  solver/mixed_cg_her.c:65-202 with f = Qtm_pm_psi,
  * f32 = Qtm_pm_psi_32; innereps / max_inner_it are the reference's mixcg_innereps / mixcg_maxinnersolverit
  * (default_input_values.h:193-194: 5.0e-5, 5000).  *iters = the reference's return value (-1: not converged). */

@@ -77,6 +77,39 @@ def test_coherent_mode_is_a_plain_drop_in(host):
     assert rel_err(kk, ref2[:N]) < TOL
 
 
+def test_fp32_site_diagonal_twists_on_blocks_of_any_length(host):
+    """mul_one_pm_imu_inv_32 / assign_mul_one_pm_imu_inv_32 / mul_one_pm_imu_sub_mul_32 (the fp32 instances tm_operators.c
+    generates from mul_one_pm_imu_inv_body.c / mul_one_pm_imu_sub_mul_body.c): solver/Msap.c calls them on domain blocks, so N is
+    arbitrary.  Checked against the formula of the body files in float arithmetic."""
+    stub, d, orc, g, (T, L, V) = host
+    mu = np.float32(stub.stub_get_mu())
+    d.mul_one_pm_imu_inv_32.argtypes = [VP, C.c_double, C.c_int]
+    d.assign_mul_one_pm_imu_inv_32.argtypes = [VP, VP, C.c_double, C.c_int]
+    d.mul_one_pm_imu_sub_mul_32.argtypes = [VP, VP, VP, C.c_double, C.c_int]
+
+    def twist(k, z):                                            # spin 0,1: z, spin 2,3: conj(z)   ([N][4][3] complex64)
+        out = k.copy()
+        out[:, :2] = (z * k[:, :2]).astype(np.complex64); out[:, 2:] = (np.conj(z) * k[:, 2:]).astype(np.complex64)
+        return out
+
+    rng = np.random.default_rng(77)
+    for N in (1, 100, 257, V // 2):
+        k = (rng.standard_normal((N, 4, 3)) + 1j * rng.standard_normal((N, 4, 3))).astype(np.complex64)
+        j = (rng.standard_normal((N, 4, 3)) + 1j * rng.standard_normal((N, 4, 3))).astype(np.complex64)
+        for sign in (+1.0, -1.0):
+            nrm = np.float32(1.0 / (1.0 + float(mu) ** 2))
+            zinv = np.complex64(nrm + 1j * (1.0 if sign < 0 else -1.0) * nrm * mu)
+            l = np.zeros_like(k)
+            d.assign_mul_one_pm_imu_inv_32(_p(l), _p(k), sign, N)
+            assert np.allclose(l, twist(k, zinv), rtol=2e-6, atol=1e-6)
+            m = k.copy(); d.mul_one_pm_imu_inv_32(_p(m), sign, N)                       # in place
+            assert np.allclose(m, twist(k, zinv), rtol=2e-6, atol=1e-6)
+            z = np.complex64(1.0 + 1j * (1.0 if sign >= 0 else -1.0) * mu)
+            d.mul_one_pm_imu_sub_mul_32(_p(l), _p(k), _p(j), sign, N)
+            assert np.allclose(l, twist(k, z) - j, rtol=2e-6, atol=1e-6)
+    d.mul_one_pm_imu_inv_32(_p(k), 1.0, 0)                      # N = 0: nothing happens
+
+
 def test_mirror_registry_is_bounded(host):
     """Ever new host addresses (work fields allocated per solve, solver/solver_field.c): the registry drops the least recently
     used mirrors whose host copy is current instead of growing; results are unaffected."""

@@ -691,6 +691,23 @@ void assign(spinor *const R, spinor *const S, const int N) {
   done(c, R);
 }
 
+/* fp32 instances of the site-diagonal twists (tm_operators.c:8-47 -> mul_one_pm_imu_inv_body.c, mul_one_pm_imu_sub_mul_body.c);
+ * callers hand over domain blocks of any length (solver/Msap.c:409-418), so these go through a staging buffer, not the registry */
+void mul_one_pm_imu_inv_32(spinor32 *const l, const double _sign, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const float nrm = (float)(1. / (1. + g_mu * g_mu));
+  CK(tmhip_diag32_host(c, l, l, nullptr, nrm, (_sign < 0. ? 1. : -1.) * nrm * g_mu, N));
+}
+void assign_mul_one_pm_imu_inv_32(spinor32 *const l, spinor32 *const k, const double _sign, const int N) {
+  tmhip_ctx *c = refresh(false);
+  const float nrm = (float)(1. / (1. + g_mu * g_mu));
+  CK(tmhip_diag32_host(c, l, k, nullptr, nrm, (_sign < 0. ? 1. : -1.) * nrm * g_mu, N));
+}
+void mul_one_pm_imu_sub_mul_32(spinor32 *const l, spinor32 *const k, spinor32 *const j, const double _sign, const int N) {
+  tmhip_ctx *c = refresh(false);
+  CK(tmhip_diag32_host(c, l, k, j, 1., (_sign < 0. ? -1. : 1.) * g_mu, N));
+}
+
 // ------------------------------------------------------------------ solver
 /* solver/cg_her.c:62-141.  For the e/o operators of this library the whole solve runs
  * device-resident (tmhip_cg_her); for any other `f` the reference loop is executed with the

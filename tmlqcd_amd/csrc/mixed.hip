@@ -230,3 +230,33 @@ int tmhip_Qtm_pm_psi_32(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
 }
 
 }  // extern "C"
+
+// ---- fp32 site-diagonal twists on HOST arrays of any length (the _32 instances of operator/mul_one_pm_imu_inv_body.c and
+// operator/mul_one_pm_imu_sub_mul_body.c that tm_operators.c:8-20,35-47 generates; solver/Msap.c calls them on domain blocks) ----
+// The reference's AoS spinor32 is processed as it is: element e of a site is (spin e/3, colour e%3), spin 2,3 take conj(z).
+__global__ __launch_bounds__(256) void diag32_aos_kernel(v2f *__restrict__ l, const v2f *__restrict__ k, const v2f *__restrict__ j, float zre, float zim, size_t n) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const float zi = (idx % 12) >= 6 ? -zim : zim;
+  const v2f a = k[idx];
+  v2f r = v2f{zre * a.x - zi * a.y, zre * a.y + zi * a.x};
+  if (j) r -= j[idx];
+  l[idx] = r;
+}
+
+extern "C" int tmhip_diag32_host(tmhip_ctx *ctx, void *l, const void *k, const void *j, double zre, double zim, int N) {
+  if (!l || !k) TMHIP_FAIL("tmhip_diag32_host: null argument");
+  if (N < 0) TMHIP_FAIL("tmhip_diag32_host: N = %d", N);
+  if (N == 0) return 0;
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  const size_t n = (size_t)N * 12, bytes = n * sizeof(v2f);
+  if (tmhip_stage_reserve(ctx, (j ? 3 : 2) * bytes)) return 1;
+  v2f *dl = (v2f *)ctx->stage, *dk = dl + n, *dj = j ? dk + n : nullptr;
+  TMHIP_CHECK(hipMemcpyAsync(dk, k, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (j) TMHIP_CHECK(hipMemcpyAsync(dj, j, bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(diag32_aos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dl, (const v2f *)dk, (const v2f *)dj, (float)zre, (float)zim, n);
+  TMHIP_CHECK(hipGetLastError());
+  TMHIP_CHECK(hipMemcpyAsync(l, dl, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
