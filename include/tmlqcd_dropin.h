@@ -193,6 +193,7 @@ void tmlqcd_hip_set_residency(int mode);
  * least recently used mirror whose host copy is current is freed.  Host programs that allocate work fields per solve
  * (solver/solver_field.c) hand in ever new addresses; mirrors holding device-only data (resident mode) are never dropped. */
 void tmlqcd_hip_set_max_mirrors(int n);
+unsigned long tmlqcd_hip_calls(void);   /* number of reference-named entry points served so far (integration checks) */
 void tmlqcd_hip_sync_to_host(spinor *field);       /* download the device mirror of `field` if it is newer */
 void tmlqcd_hip_sync_all_to_host(void);
 void tmlqcd_hip_host_modified(spinor *field);      /* the host wrote `field`: drop its device mirror */

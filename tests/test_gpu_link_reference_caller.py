@@ -87,3 +87,65 @@ def test_c_main_linked_at_link_time_runs_the_benchmark_loop(c_host_program):
     assert r.returncode == 0, r.stdout + r.stderr
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["max_rel_err_vs_oracle"] < 1e-13 and d["mflops_resident"] > d["mflops_coherent"] > 0
+
+
+HOSTPROG_LOC = os.path.join(ROOT, "oracle", "_ref", "libtmhostprog_loc.so")
+
+CHILD_LOC = r'''
+import ctypes as C, json, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+host = C.CDLL(%(hostprog)r, mode=C.RTLD_GLOBAL)
+dropin = C.CDLL(%(root)r + "/tmlqcd_amd/lib/libtmlqcd_dropin.so", mode=C.RTLD_GLOBAL)
+dropin.tmlqcd_hip_calls.restype = C.c_ulong
+host.tmref_init.argtypes = [C.c_int] * 4 + [C.c_double] * 2 + [C.c_int] * 2
+host.tmref_spinor.restype = C.c_void_p; host.tmref_spinor.argtypes = [C.c_int]
+host.tmref_gauge.restype = C.c_void_p
+host.tmref_clover.argtypes = [C.c_double, C.c_double]
+L, kappa, mu, c_sw = 8, 0.125, 0.02, 1.3
+assert host.tmref_init(L, L, L, L, kappa, mu, 14, 1) == 0
+host.tmref_random_fields(4711)
+host.tmref_clover(c_sw, mu)                               # the reference's sw_term / sw_invert fill ITS sw / sw_inv arrays
+V, N = L ** 4, L ** 4 // 2
+sp = host.tmref_spinor
+def view(i, n=N):
+    return np.frombuffer((C.c_double * (n * 24)).from_address(sp(i)), dtype=np.float64).reshape(n, 4, 3, 2)
+gauge = np.frombuffer((C.c_double * (V * 72)).from_address(host.tmref_gauge()), dtype=np.float64).reshape(V, 4, 3, 3, 2).copy()
+rng = np.random.default_rng(5)
+view(0)[:] = rng.standard_normal((N, 4, 3, 2)); view(1)[:] = rng.standard_normal((N, 4, 3, 2))
+e, o_ = view(0).copy(), view(1).copy()
+# Qsw_full is NOT in the drop-in library: the reference's object code runs, and what it calls across object boundaries
+# (Hopping_Matrix, assign_add_mul_r, gamma5) must come from the library, what it calls inside its own object stays CPU code
+assert not hasattr(dropin, "Qsw_full_does_not_exist")
+n0 = dropin.tmlqcd_hip_calls()
+host.Qsw_full.argtypes = [C.c_void_p] * 4
+host.Qsw_full(sp(2), sp(3), sp(0), sp(1))
+served = dropin.tmlqcd_hip_calls() - n0
+en, on = view(2).copy(), view(3).copy()
+from oracle.oraclebind import Oracle
+orc = Oracle(L, L, L, L, kappa=kappa, mu=mu)
+orc.set_gauge(gauge)
+sw = orc.sw_term(kappa, c_sw); swi, _ = orc.sw_invert(sw, 0, mu)
+orc.set_clover(sw, swi); orc.set_mu(mu)
+fe, fo, re_, ro = orc.new_field(), orc.new_field(), orc.new_field(), orc.new_field()
+fe[:N] = e; fo[:N] = o_
+orc.Msw_full(re_, ro, fe, fo)
+g5 = np.array([1.0, 1.0, -1.0, -1.0]).reshape(1, 4, 1, 1)
+err = max(float(np.abs(en - g5 * re_[:N]).max()), float(np.abs(on - g5 * ro[:N]).max())) / float(np.abs(re_[:N]).max())
+dropin.tmlqcd_hip_finalize()
+print(json.dumps({"served": int(served), "err": err}))
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(HOSTPROG_LOC), reason="oracle/_ref/libtmhostprog_loc.so not built (needs /root/reference)")
+def test_complete_reference_build_with_replaced_symbols_localized():
+    """The other recipe of INTEGRATION.md: nothing is removed from the reference build; the symbols this library provides are
+    made local in the reference objects.  The reference's Qsw_full (operator/clovertm_operators.c:98, not provided here) then
+    runs as object code, its two Hopping_Matrix, two assign_add_mul_r and two gamma5 calls are served by the library, its
+    assign_mul_one_sw_pm_imu calls stay inside its own object, and the result is the all-CPU one."""
+    r = subprocess.run([sys.executable, "-c", CHILD_LOC % {"root": ROOT, "hostprog": HOSTPROG_LOC}],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["served"] == 6, d
+    assert d["err"] < 1e-13, d

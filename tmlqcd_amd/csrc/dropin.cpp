@@ -77,8 +77,10 @@ tmhip_ctx *ctx() {
 }
 
 // Re-read everything the reference reads through globals (SURVEY §8b "Data it reads through globals").
+unsigned long g_calls = 0;   // entry-point calls served (tmlqcd_hip_calls): lets an integration test see that a symbol resolved to this library
 tmhip_ctx *refresh(bool need_gauge) {
   tmhip_ctx *c = ctx();
+  g_calls++;
   const double ka[8] = {__real__ ka0, __imag__ ka0, __real__ ka1, __imag__ ka1,
                         __real__ ka2, __imag__ ka2, __real__ ka3, __imag__ ka3};
   CK(tmhip_set_ka(c, ka));
@@ -330,6 +332,7 @@ static tmhip_ctx *refresh_clover() {
 }
 void tmlqcd_hip_update_clover(void) { g_clover_uploaded = false; }
 void tmlqcd_hip_set_max_mirrors(int n) { if (n >= 8) g_mirror_cap = (size_t)n; }
+unsigned long tmlqcd_hip_calls(void) { return g_calls; }
 /* sw_term(g_gauge_field, kappa, c_sw) (operator/clover_term.c:88) computed in HBM; the host's sw array, if the program
  * has one (init_sw_fields), receives a copy so that host-side consumers (sw_trace, sw_deriv ...) keep working. */
 void tmlqcd_hip_sw_term(const double kappa, const double c_sw) {
