@@ -99,6 +99,27 @@ def test_reference_caller_host_program_links_against_the_drop_in():
         assert (" U " + sym) in und, sym                       # really taken from the drop-in, not from reference objects
 
 
+def test_complete_reference_build_with_localized_symbols_links_against_the_drop_in():
+    """The other recipe of INTEGRATION.md section 2.1 (oracle/Makefile target libtmhostprog_loc.so): the complete reference
+    hot-path build with the library's symbols made local.  What the library provides is undefined in the host program (so it
+    comes from the library), what it does not provide is still the reference's own definition."""
+    import subprocess, sys
+    so = os.path.join(ROOT, "oracle", "_ref", "libtmhostprog_loc.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libtmhostprog_loc.so not built (needs /root/reference)")
+    code = "import ctypes as C; h = C.CDLL(%r, mode=C.RTLD_GLOBAL); assert h.Qsw_full and h.Block_D_psi and h.sw_term; print('linked')" % so
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "linked" in r.stdout, r.stderr
+    und = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+    dfd = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    for sym in ("Hopping_Matrix", "D_psi", "assign_add_mul_r", "gamma5"):       # called across object boundaries: taken from the library
+        assert (" U " + sym + "\n") in und and (" T " + sym + "\n") not in dfd, sym
+    for sym in ("Qsw_pm_psi", "Qtm_pm_psi", "cg_her", "square_norm"):            # the reference's definitions are no longer visible
+        assert (" T " + sym + "\n") not in dfd, sym
+    for sym in ("Qsw_full", "Block_D_psi", "init_sw_fields", "sw_term", "update_backward_gauge"):
+        assert (" T " + sym + "\n") in dfd, sym
+
+
 def test_c_host_program_links_against_the_drop_in_at_link_time(c_host_program):
     """A C main (tests/c_host/mini_benchmark.c, the shape of benchmark.c) with `-ltmlqcd_dropin -ltmlqcd_hip` on its link line:
     every reference-named symbol it calls is bound to the drop-in library, the globals to the program itself."""
