@@ -290,6 +290,34 @@ def test_cg_fused_split_path_wide_short_local_lattice():
     lat.close()
 
 
+@pytest.mark.parametrize("dims", [(6, 4, 4, 4), (4, 4, 4, 8), (12, 4, 4, 4), (2, 4, 6, 2)])
+def test_cg_fused_iteration_on_small_block_counts(dims):
+    """V/2 = 192, 256, 384: whole 64-thread blocks but not (always) whole 256-thread blocks -- the fused iteration runs with the
+    64-thread instances of the reducing epilogues (3, 4, 6 blocks); V/2 = 48 has no whole block and takes the plain kernels.
+    All against the oracle's cg_her, twisted boundary conditions in every direction."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T, LX, LY, LZ = dims
+    theta = (1.0, 0.3, -0.2, 0.5)
+    orc = Oracle(T, LX, LY, LZ, kappa=0.135, mu=0.03, theta=theta, threads=4)
+    lat = Lattice(T, LX, LY, LZ, kappa=0.135, mu=0.03, theta=theta)
+    g = random_gauge(sum(dims) + 1, orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    N = orc.Vh
+    q = random_spinor(41, N)
+    P = orc.new_field()
+    it_ref, hist_ref = orc.cg_her(P, q.copy(), 500, 1e-22, 1, N)
+    for fused in (2, 0):
+        lat.set_option("cg_fused_dot", fused)
+        dq, dp = lat.field(q), lat.field()
+        it, hist = lat.cg_her(dp, dq, 500, 1e-22, 1, N)
+        assert abs(it - it_ref) <= 1, (fused, it, it_ref)
+        m = min(len(hist), len(hist_ref)) - 1
+        assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6), fused
+        assert rel_err(dp.download(), P[:N]) < 1e-9, fused
+    lat.close()
+
+
 def test_cg_not_converged_returns_minus_one(setup):
     orc, lat = setup
     N = orc.Vh
