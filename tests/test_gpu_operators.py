@@ -318,6 +318,36 @@ def test_cg_fused_iteration_on_small_block_counts(dims):
     lat.close()
 
 
+@pytest.mark.parametrize("block", [256, 64])
+def test_cg_fused_iteration_with_both_block_sizes(block):
+    """The automatic block size picks 64 threads on every test-sized lattice; the 256-thread instances of the reducing epilogues
+    are what runs at 32^4.  Both, forced, on 8^4 (unsplit and on the split path) against the oracle."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T = L = 8
+    orc = Oracle(T, L, L, L, kappa=0.13, mu=0.015, threads=8)
+    lat = Lattice(T, L, L, L, kappa=0.13, mu=0.015)
+    g = syn.gauge_field(21, T, L, L, L)
+    orc.set_gauge(g); lat.set_gauge(g)
+    N = orc.Vh
+    q = syn.spinor_field_eo(22, 1, T, L, L, L)
+    P = orc.new_field()
+    it_ref, hist_ref = orc.cg_her(P, q.copy(), 500, 1e-20, 1, N)
+    lat.set_option("block", block)
+    dq, dp = lat.field(q), lat.field()
+    for loop in (0, 1):
+        lat.set_loopback(loop)
+        dp.zero()
+        it, hist = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
+        assert abs(it - it_ref) <= 1, (block, loop)
+        m = min(len(hist), len(hist_ref)) - 1
+        assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6) and rel_err(dp.download(), P[:N]) < 1e-9, (block, loop)
+    it32, outer = lat.mixed_cg_her(dp, dq, 500, 1e-20, 1, N)     # fp32 inner loops: the same epilogues in float
+    assert rel_err(dp.download(), P[:N]) < 1e-8, block
+    lat.close()
+
+
 def test_cg_not_converged_returns_minus_one(setup):
     orc, lat = setup
     N = orc.Vh
