@@ -250,7 +250,7 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "occ" / "occ32"  waves per SIMD allowed by a dynamic-LDS cap for the fp64 / fp32 stencil (3 / 0 = no cap)
  *   "minw" 4: __launch_bounds__(BS, 4);  "shape" n: compact n-x-plane block shape;  "fp32_pairs" 1: two sites per thread in fp32
  *   "flagsync" 1|0 flag kernels vs HIP events on the split path;  "fusedface" -1 (default: on from T_local = 16 up) | 1 | 0: faces in the same launch as the interior;
- *   "facesplit" 1|0 two-kernel split path: face kernel with the eight hops of a site spread over the four waves of a block (default) vs one thread per face site
+ *   "facesplit" 0|1 two-kernel split path: one thread per face site (default) vs the face kernel with the eight hops of a site spread over the four waves of a block
  *   "cg_fused_dot" 2 (default: alpha / residual / norm in the stencil epilogues), 1 scalar product only, 0 plain linalg kernels
  *   "cg_sync" 1: host-side scalars as in the reference loop;  "cg_batch" n: iterations enqueued between two polls of `done`
  *   "bench_graph" 1: tmhip_bench_hopping captures its loop into one hipGraph and replays it (diagnostic: launch floor on small lattices)

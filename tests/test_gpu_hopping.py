@@ -106,7 +106,7 @@ def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface, facespl
         lat.set_loopback(0)
         lat.set_option("flagsync", 1)
         lat.set_option("fusedface", -1)
-        lat.set_option("facesplit", 1)
+        lat.set_option("facesplit", 0)
     dk.free(); dl.free()
 
 

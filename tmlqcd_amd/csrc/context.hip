@@ -158,7 +158,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
   ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 2; ctx->opt_fusedface = -1; ctx->opt_gaux = -1;
-  ctx->opt_gdrop = 0; ctx->opt_fp32_pairs = 0; ctx->opt_occ32 = 0; ctx->opt_facesplit = 1; ctx->opt_recon = 0;
+  ctx->opt_gdrop = 0; ctx->opt_fp32_pairs = 0; ctx->opt_occ32 = 0; ctx->opt_facesplit = 0; ctx->opt_recon = 0;
   ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
