@@ -180,8 +180,15 @@ class Field:
         _ck(self.lat.lib.tmhip_field_upload(self.lat.h, self.h, _hp(host), nsites), "tmhip_field_upload")
         return self
 
-    def download(self, nsites=None):
+    def download(self, nsites=None, out=None):
+        """Returns the field as a host AoS array; `out`: an existing fp64 array of the right shape to fill instead (a host
+        program's own, already touched, buffer)."""
         nsites = nsites if nsites is not None else (self.lat.V if self.kind == FIELD_FULL else self.lat.Vh)
+        if out is not None:
+            if self.prec == 32 or out.dtype != np.float64 or out.shape != (nsites, 4, 3, 2) or not out.flags.c_contiguous:
+                raise TmHipError("download(out=...): needs a C-contiguous float64 [%d][4][3][2] array and an fp64 field" % nsites)
+            _ck(self.lat.lib.tmhip_field_download(self.lat.h, self.h, _hp(out), nsites), "tmhip_field_download")
+            return out
         if self.prec == 32:
             out = np.empty((nsites, 4, 3, 2), dtype=np.float32)
             _ck(self.lat.lib.tmhip_field_download32(self.lat.h, self.h, out.ctypes.data_as(C.c_void_p), nsites), "tmhip_field_download32")
