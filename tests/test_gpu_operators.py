@@ -69,6 +69,10 @@ def test_streaming_updates(setup):
     assert rel_err(dc.download(), rc) < TOL
     lat.assign(dc, db, N)
     assert np.array_equal(dc.download(), b)
+    mine = np.full_like(b, 7.0)                                   # download into the caller's own array
+    assert dc.download(out=mine) is mine and np.array_equal(mine, b)
+    with pytest.raises(Exception):
+        dc.download(out=np.zeros((N, 4, 3), dtype=np.float64))
     da.upload(np.ascontiguousarray(ra))                           # identical inputs from here on
     orc.add(rc, ra, b, N); lat.add(dc, da, db, N)                 # linalg/add.c, linalg/mul_r.c: one rounding each, so bit for bit
     assert np.array_equal(dc.download(), rc)
