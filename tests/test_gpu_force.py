@@ -195,8 +195,8 @@ def test_clover_force_chain_against_oracle(dims, mu):
     lat.close()
 
 
-@pytest.mark.parametrize("T", [2, 4])
-def test_clover_force_on_two_t_slabs(T):
+@pytest.mark.parametrize("T,L,world", [(2, 4, 2), (4, 4, 2), (2, 6, 3), (4, 8, 2)])
+def test_clover_force_on_two_t_slabs(T, L, world):
     """sw_all on T-split ranks: the leaves next to the t-faces reach links of BOTH ring neighbours (the two-sided derivative halo
     of xchange_deri.c).  Two contexts holding the two halves of the lattice (own sw_term / sw_invert from halo links, site-local
     sw_spinor_eo / sw_deriv, contributions exchanged by peer copies) == the unsplit oracle, together with deriv_Sb."""
@@ -204,8 +204,7 @@ def test_clover_force_on_two_t_slabs(T):
     from tmlqcd_amd import Lattice
     from tmlqcd_amd import synthetic as syn
     from tmlqcd_amd.hip import multi_deriv_Sb, multi_sw_all
-    L, world = 4, 2
-    Tg = T * world
+    Tg = T * world                                                # world = 3: the two ring neighbours are different ranks
     kappa, mu, c_sw, theta = 0.13, 0.02, 1.4, (1.0, 0.25, 0.0, 0.5)
     g = Oracle(Tg, L, L, L, kappa=kappa, mu=mu, theta=theta, threads=4)
     g.set_gauge(syn.gauge_field(16, Tg, L, L, L))
