@@ -59,7 +59,8 @@ def test_deriv_Sb_against_oracle(dims):
     lat.close()
 
 
-def test_deriv_Sb_split_path_loopback_and_two_t_slabs():
+@pytest.mark.parametrize("world", [2, 3])
+def test_deriv_Sb_split_path_loopback_and_two_t_slabs(world):
     """T-split ranks: the +t neighbours of the last time-slice come from the exchanged t=0 slices of BOTH fields
     (xchange_2fields, deriv_Sb.c:102).  (1) one rank with the exchange looped back onto itself, (2) two contexts holding
     the two halves of the lattice (halo gauge links, global parity offset, peer copies) == the unsplit lattice."""
@@ -67,7 +68,7 @@ def test_deriv_Sb_split_path_loopback_and_two_t_slabs():
     from tmlqcd_amd import Lattice
     from tmlqcd_amd import synthetic as syn
     from tmlqcd_amd.hip import multi_deriv_Sb
-    T, L, world = 2, 4, 2
+    T, L = 2, 4
     Tg = T * world
     kappa, mu, theta = 0.13, 0.02, (1.0, 0.25, 0.0, 0.5)
     g = Oracle(Tg, L, L, L, kappa=kappa, mu=mu, theta=theta, threads=4)

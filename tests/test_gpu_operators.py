@@ -395,15 +395,16 @@ def test_golden_fixture_from_reference_on_gpu():
     lat.close()
 
 
-@pytest.mark.parametrize("T", [2, 4])
-def test_t_split_two_contexts_on_one_gpu(T):
-    """nproc_t = 2 geometry on real hardware: two contexts of this process hold the two slabs (halo gauge
-    links, global parity offset, face pack -> peer copy -> boundary kernels) == the unsplit lattice."""
+@pytest.mark.parametrize("T,world", [(2, 2), (4, 2), (2, 3), (2, 4)])
+def test_t_split_two_contexts_on_one_gpu(T, world):
+    """nproc_t = 2, 3, 4 geometry on real hardware: as many contexts of this process hold the slabs (halo gauge links, global
+    parity offset, face pack -> peer copy -> boundary kernels) == the unsplit lattice.  From three ranks on, the up and the
+    down neighbour are different ranks."""
     from oracle.oraclebind import Oracle
     from tmlqcd_amd import Lattice
     from tmlqcd_amd import synthetic as syn
     from tmlqcd_amd.hip import multi_Hopping_Matrix
-    L, world = 6, 2
+    L = 6
     Tg = T * world
     kappa, theta = 0.13, (1.0, 0.0, 0.0, 0.5)
     g = Oracle(Tg, L, L, L, kappa=kappa, theta=theta, threads=4)
