@@ -303,6 +303,21 @@ def test_clover_drop_in(host):
     assert rel_err(kk, ref[:N]) < TOL
     d.clover_gamma5(1, _p(l), _p(k), _p(j), mu); orc.clover_gamma5(1, ref, k, j, mu)
     assert rel_err(l, ref[:N]) < TOL
+    # D_psi with g_c_sw > 0 (D_psi_body.c:314-316): the site term is (1 + T + i mu g5) from the host's sw array, on both parities
+    lex = random_spinor(14, V); out = np.zeros_like(lex)
+    e2l = orc.eo2lexic()
+    fe, fo, en, on = orc.new_field(), orc.new_field(), orc.new_field(), orc.new_field()
+    fe[:N] = lex[e2l[:N]]; fo[:N] = lex[e2l[N:V]]
+    orc.Msw_full(en, on, fe, fo)
+    expect = np.zeros_like(lex); expect[e2l[:N]] = en[:N]; expect[e2l[N:V]] = on[:N]
+    stub.stub_set_csw(1.0)
+    try:
+        d.D_psi(_p(out), _p(lex))
+    finally:
+        stub.stub_set_csw(0.0)
+    assert rel_err(out, expect) < TOL
+    d.D_psi(_p(out), _p(lex)); plain = np.zeros_like(lex); orc.D_psi(plain, lex)        # and back on the plain branch
+    assert rel_err(out, plain) < TOL and rel_err(expect, plain) > 1e-3
     q = random_spinor(13, N); P = np.zeros_like(q)
     it = d.cg_her(_p(P), _p(q), 2000, 1e-18, 1, N, C.cast(d.Qsw_pm_psi, VP))
     Pref = orc.new_field(); it_ref, _ = orc.cg_her(Pref, q.copy(), 2000, 1e-18, 1, N, "Qsw_pm_psi")

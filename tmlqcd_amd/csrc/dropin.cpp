@@ -238,7 +238,19 @@ void tm_sub_Hopping_Matrix(const int ieo, spinor *const l, spinor *p, spinor *co
   CK(tmhip_tm_sub_hopping_matrix(c, ieo, fl, fp, fk, __real__ cfactor, __imag__ cfactor));
   done(c, l);
 }
-/* operator/D_psi.c:1133-1140 -> D_psi_body.c:266-375 (g_c_sw = 0 branch) */
+/* D_psi_body.c:314-316: with g_c_sw > 0 the site term of D_psi is the clover one, (1 + T(x) + i mu g5) from the host's sw array.
+ * On the two parities of a full field that is Msw_full (clovertm_operators.c:96-110): new = (1 + T + i mu g5) own - H other. */
+extern double g_c_sw __attribute__((weak));   /* global.h:198; a host program without it has no clover term */
+static void ensure_clover(tmhip_ctx *c);
+static void d_psi_core(tmhip_ctx *c, tmhip_field *fp, tmhip_field *fq) {
+  if (&g_c_sw && g_c_sw > 0.) {
+    ensure_clover(c);
+    CK(tmhip_Msw_full(c, tmhip_field_even(fp), tmhip_field_odd(fp), tmhip_field_even(fq), tmhip_field_odd(fq)));
+  } else {
+    CK(tmhip_D_psi(c, fp, fq));
+  }
+}
+/* operator/D_psi.c:1133-1140 -> D_psi_body.c:266-375 */
 void D_psi(spinor *const P, spinor *const Q) {
   if (P == Q) {   /* D_psi_body.c:267-272 */
     printf("Error in D_psi (operator.c):\nArguments must be different spinor fields\nProgram aborted\n");
@@ -246,7 +258,7 @@ void D_psi(spinor *const P, spinor *const Q) {
   }
   tmhip_ctx *c = refresh(true);
   tmhip_field *fq = in(c, Q, TMHIP_FIELD_FULL), *fp = out(c, P, TMHIP_FIELD_FULL);
-  CK(tmhip_D_psi(c, fp, fq));
+  d_psi_core(c, fp, fq);
   done(c, P);
 }
 
@@ -321,13 +333,16 @@ void M_minus_1_timesC(spinor *const En, spinor *const On, spinor *const E, spino
 }
 
 // ------------------------------------------------------------------ clover twisted mass
-static tmhip_ctx *refresh_clover() {
-  tmhip_ctx *c = refresh(true);
+static void ensure_clover(tmhip_ctx *c) {
   if (!g_clover_uploaded) {
     if (!&sw || !&sw_inv || !sw || !sw_inv) die("clover operator called but the host program has no sw / sw_inv (init_sw_fields)");
     CK(tmhip_set_clover(c, &sw[0][0][0], &sw_inv[0][0][0]));
     g_clover_uploaded = true;
   }
+}
+static tmhip_ctx *refresh_clover() {
+  tmhip_ctx *c = refresh(true);
+  ensure_clover(c);
   return c;
 }
 void tmlqcd_hip_update_clover(void) { g_clover_uploaded = false; }
@@ -506,7 +521,7 @@ static void g5_full(tmhip_ctx *c, tmhip_field *l, tmhip_field *k) {
 void Q_psi(spinor *const P, spinor *const Q) {
   tmhip_ctx *c = refresh(true);
   tmhip_field *fq = in(c, Q, TMHIP_FIELD_FULL), *fp = out(c, P, TMHIP_FIELD_FULL);
-  CK(tmhip_D_psi(c, fp, fq)); g5_full(c, fp, fp);
+  d_psi_core(c, fp, fq); g5_full(c, fp, fp);
   done(c, P);
 }
 /* tm_operators.c:486-490 */
@@ -515,7 +530,7 @@ void Q_plus_psi(spinor *const l, spinor *const k) { Q_psi(l, k); }
 void Q_minus_psi(spinor *const l, spinor *const k) {
   tmhip_ctx *c = refresh(true);
   tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL);
-  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, fl, fk)); CK(tmhip_set_mu(c, g_mu));
+  CK(tmhip_set_mu(c, -g_mu)); d_psi_core(c, fl, fk); CK(tmhip_set_mu(c, g_mu));
   g5_full(c, fl, fl);
   done(c, l);
 }
@@ -523,16 +538,16 @@ void Q_minus_psi(spinor *const l, spinor *const k) {
 void M_minus_psi(spinor *const l, spinor *const k) {
   tmhip_ctx *c = refresh(true);
   tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL);
-  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, fl, fk)); CK(tmhip_set_mu(c, g_mu));
+  CK(tmhip_set_mu(c, -g_mu)); d_psi_core(c, fl, fk); CK(tmhip_set_mu(c, g_mu));
   done(c, l);
 }
 /* tm_operators.c:380-388 : Q_+ Q_- on the full lattice */
 void Q_pm_psi(spinor *const l, spinor *const k) {
   tmhip_ctx *c = refresh(true);
   tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL), *tmp = full_tmp(c);
-  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, fl, fk));
+  CK(tmhip_set_mu(c, -g_mu)); d_psi_core(c, fl, fk);
   g5_full(c, tmp, fl);
-  CK(tmhip_set_mu(c, g_mu)); CK(tmhip_D_psi(c, fl, tmp));
+  CK(tmhip_set_mu(c, g_mu)); d_psi_core(c, fl, tmp);
   g5_full(c, fl, fl);
   done(c, l);
 }
@@ -540,9 +555,9 @@ void Q_pm_psi(spinor *const l, spinor *const k) {
 void Q_pm_psi2(spinor *const l, spinor *const k) {
   tmhip_ctx *c = refresh(true);
   tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL), *tmp = full_tmp(c);
-  CK(tmhip_set_mu(c, -10. * g_mu)); CK(tmhip_D_psi(c, fl, fk));
+  CK(tmhip_set_mu(c, -10. * g_mu)); d_psi_core(c, fl, fk);
   g5_full(c, tmp, fl);
-  CK(tmhip_set_mu(c, g_mu)); CK(tmhip_D_psi(c, fl, tmp));
+  CK(tmhip_set_mu(c, g_mu)); d_psi_core(c, fl, tmp);
   g5_full(c, fl, fl);
   done(c, l);
 }
@@ -589,9 +604,9 @@ void Q_pm_psi_gpu(spinor *const l, spinor *const k) {
   tmhip_ctx *c = refresh(true);
   tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL), *tmp = full_tmp(c);
   g5_full(c, fk, fk);
-  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, fl, fk));
+  CK(tmhip_set_mu(c, -g_mu)); d_psi_core(c, fl, fk);
   g5_full(c, tmp, fl);
-  CK(tmhip_set_mu(c, g_mu)); CK(tmhip_D_psi(c, fl, tmp));
+  CK(tmhip_set_mu(c, g_mu)); d_psi_core(c, fl, tmp);
   done(c, k); done(c, l);
 }
 /* tm_operators.c:476-483 */
@@ -599,7 +614,7 @@ void Q_minus_psi_gpu(spinor *const l, spinor *const k) {
   tmhip_ctx *c = refresh(true);
   tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL);
   g5_full(c, fk, fk);
-  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, fl, fk)); CK(tmhip_set_mu(c, g_mu));
+  CK(tmhip_set_mu(c, -g_mu)); d_psi_core(c, fl, fk); CK(tmhip_set_mu(c, g_mu));
   g5_full(c, fl, fl);
   done(c, k); done(c, l);
 }
@@ -608,7 +623,7 @@ void D_dagg_psi(spinor *const l, spinor *const k) {
   tmhip_ctx *c = refresh(true);
   tmhip_field *fk = in(c, k, TMHIP_FIELD_FULL), *fl = out(c, l, TMHIP_FIELD_FULL), *tmp = full_tmp(c);
   g5_full(c, fl, fk);
-  CK(tmhip_set_mu(c, -g_mu)); CK(tmhip_D_psi(c, tmp, fl)); CK(tmhip_set_mu(c, g_mu));
+  CK(tmhip_set_mu(c, -g_mu)); d_psi_core(c, tmp, fl); CK(tmhip_set_mu(c, g_mu));
   g5_full(c, fl, tmp);
   done(c, l);
 }
