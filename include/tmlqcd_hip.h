@@ -53,6 +53,8 @@ int tmhip_set_boundary(tmhip_ctx *ctx, double kappa, const double theta[4]);
 int tmhip_set_ka(tmhip_ctx *ctx, const double ka[8]);
 /* g_mu (global.h:198; = 2 kappa mu); read by the twisted-mass operators at call time */
 int tmhip_set_mu(tmhip_ctx *ctx, double mu);
+int tmhip_set_mu3(tmhip_ctx *ctx, double mu3);   /* g_mu3 (global.h:197), default 0: Qsw_plus/minus/pm_psi and Msw_plus/minus_psi twist their odd-odd
+                                                  * clover term with +-(mu + mu3) (clovertm_operators.c:208,216,238,243,258,265) */
 
 /* Upload g_gauge_field (host, su3[VOLUMEPLUSRAND][4], halo links included when
  * nproc_t > 1) and re-sort it into the device gauge copy.  Replaces

@@ -30,6 +30,7 @@ def _lib():
         lib.tmo_get_threads.restype = i
         lib.tmo_boundary.argtypes = [vp, d, vp]
         lib.tmo_set_mu.argtypes = [vp, d]
+        lib.tmo_set_mu3.argtypes = [vp, d]
         lib.tmo_set_gauge.argtypes = [vp, vp]
         lib.tmo_index.restype = i
         lib.tmo_index.argtypes = [vp, i, i, i, i]
@@ -145,6 +146,10 @@ class Oracle:
     def set_mu(self, mu):
         self.mu = mu
         self.lib.tmo_set_mu(self.h, mu)
+
+    def set_mu3(self, mu3):
+        """g_mu3: enters the odd-odd clover term of Qsw_plus/minus/pm_psi and Msw_plus/minus_psi as g_mu + g_mu3."""
+        self.lib.tmo_set_mu3(self.h, mu3)
 
     def set_gauge(self, g):
         assert g.shape == (self.VPR, 4, 3, 3, 2)

@@ -167,6 +167,7 @@ void tmo_boundary(tmo_lattice *lat, double kappa, const double theta[4]) {
   }
 }
 void tmo_set_mu(tmo_lattice *lat, double mu) { lat->mu = mu; }
+void tmo_set_mu3(tmo_lattice *lat, double mu3) { lat->mu3 = mu3; }
 void tmo_set_gauge(tmo_lattice *lat, const tmo_su3 *g) { lat->gauge = g; lat->gauge_dirty = 1; }
 
 /* update_backward_gauge.c:185-242 (plain _GAUGE_COPY layout [V+RAND][8]) */
@@ -621,24 +622,24 @@ void tmo_clover(tmo_lattice *lat, int ieo, tmo_spinor *l, const tmo_spinor *k, c
   tmo_clover_generic(lat, ieo, l, k, j, mu, 0);
 }
 
-/* operator/clovertm_operators.c:233-245 (g_mu3 = 0) */
+/* operator/clovertm_operators.c:233-245 */
 void tmo_Qsw_pm_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
   tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
   tmo_clover_inv(lat, lat->scratch[1], -1, lat->mu);
   tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
-  tmo_clover_gamma5(lat, OE, lat->scratch[0], k, lat->scratch[0], -lat->mu);
+  tmo_clover_gamma5(lat, OE, lat->scratch[0], k, lat->scratch[0], -(lat->mu + lat->mu3));
   tmo_Hopping_Matrix(lat, EO, l, lat->scratch[0]);
   tmo_clover_inv(lat, l, +1, lat->mu);
   tmo_Hopping_Matrix(lat, OE, lat->scratch[1], l);
-  tmo_clover_gamma5(lat, OE, l, lat->scratch[0], lat->scratch[1], +lat->mu);
+  tmo_clover_gamma5(lat, OE, l, lat->scratch[0], lat->scratch[1], +(lat->mu + lat->mu3));
 }
-/* the rest of the e/o clover family, operator/clovertm_operators.c:201-268 (g_mu3 = 0): which = 0 Qsw_psi (mu = 0 in the
+/* the rest of the e/o clover family, operator/clovertm_operators.c:201-268: which = 0 Qsw_psi (mu = 0 in the
  * diagonal term), +1 Qsw_plus_psi / Msw_plus_psi, -1 Qsw_minus_psi / Msw_minus_psi; g5 selects clover_gamma5 vs clover */
 static void tmo_sw_hat(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k, int which, int g5) {
   tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
   tmo_clover_inv(lat, lat->scratch[1], which < 0 ? -1 : +1, lat->mu);
   tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
-  tmo_clover_generic(lat, OE, l, k, lat->scratch[0], which * lat->mu, g5);
+  tmo_clover_generic(lat, OE, l, k, lat->scratch[0], which * (lat->mu + lat->mu3), g5);   /* +-(g_mu + g_mu3), :208,216,258,265 */
 }
 void tmo_Qsw_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) { tmo_sw_hat(lat, l, k, 0, 1); }          /* :201-206 */
 void tmo_Qsw_minus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) { tmo_sw_hat(lat, l, k, -1, 1); }   /* :209-214 */
@@ -709,7 +710,7 @@ void tmo_Msw_plus_psi(tmo_lattice *lat, tmo_spinor *l, tmo_spinor *k) {
   tmo_Hopping_Matrix(lat, EO, lat->scratch[1], k);
   tmo_clover_inv(lat, lat->scratch[1], +1, lat->mu);
   tmo_Hopping_Matrix(lat, OE, lat->scratch[0], lat->scratch[1]);
-  tmo_clover(lat, OE, l, k, lat->scratch[0], +lat->mu);
+  tmo_clover(lat, OE, l, k, lat->scratch[0], +(lat->mu + lat->mu3));
 }
 
 /* ---------------------------------------------------------------- clover term and its inverse (host-side inputs in

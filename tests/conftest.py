@@ -36,6 +36,7 @@ def host_stub():
     stub.stub_set_mu.argtypes = [C.c_double]
     stub.stub_get_mu.restype = C.c_double
     stub.stub_set_csw.argtypes = [C.c_double]
+    stub.stub_set_mu3.argtypes = [C.c_double]
     import tmlqcd_amd
     tmlqcd_amd.load_library()
     dropin = C.CDLL(os.path.join(ROOT, "tmlqcd_amd", "lib", "libtmlqcd_dropin.so"), mode=C.RTLD_GLOBAL)

@@ -38,6 +38,8 @@ void stub_boundary(double kappa, double x0, double x1, double x2, double x3) {
 void stub_set_mu(double mu) { g_mu = mu; }
 double stub_get_mu(void) { return g_mu; }
 double g_c_sw = 0.0;                         /* global.h:198 */
+double g_mu3 = 0.0;                          /* global.h:197 */
+void stub_set_mu3(double mu3) { g_mu3 = mu3; }
 void stub_set_csw(double c_sw) { g_c_sw = c_sw; }
 void stub_mark_gauge_dirty(void) { g_update_gauge_copy = 1; }
 int stub_gauge_flag(void) { return g_update_gauge_copy; }

@@ -88,6 +88,20 @@ def test_clover_site_ops_and_fused_operator(setup8):
     for name in ("Qsw_psi", "Qsw_plus_psi", "Qsw_minus_psi", "Qsw_sq_psi", "Msw_psi", "Msw_minus_psi"):
         orc.op(name, ref, k.copy()); lat.op(name, dl, dk)
         assert rel_err(dl.download(), ref[:N]) < TOL, name
+    # g_mu3 != 0: the odd-odd clover term twists with mu + mu3 (clovertm_operators.c:208,216,238,243,258,265), the even-even inverse
+    # stays the one built for mu; cg_her on Qsw_pm_psi takes its scalar products out of the same epilogues
+    orc.set_mu3(0.07); lat.set_mu3(0.07)
+    for name in ("Qsw_pm_psi", "Qsw_psi", "Qsw_plus_psi", "Qsw_minus_psi", "Qsw_sq_psi", "Msw_psi", "Msw_plus_psi", "Msw_minus_psi"):
+        orc.op(name, ref, k.copy()); lat.op(name, dl, dk)
+        assert rel_err(dl.download(), ref[:N]) < TOL, name + " with mu3"
+    orc.op("Qsw_plus_psi", ref, k.copy()); orc.set_mu3(0.0); chk = orc.new_field(); orc.op("Qsw_plus_psi", chk, k.copy()); orc.set_mu3(0.07)
+    assert rel_err(ref[:N], chk[:N]) > 1e-3                            # mu3 really changes the operator
+    Pm = orc.new_field(); itm, _ = orc.cg_her(Pm, j.copy(), 2000, 1e-18, 1, N, "Qsw_pm_psi")
+    dpm = lat.field(); itd, _ = lat.cg_her(dpm, dj, 2000, 1e-18, 1, N, op="Qsw_pm_psi")
+    assert abs(itd - itm) <= max(1, itm // 100) and rel_err(dpm.download(), Pm[:N]) < 1e-7
+    itx, _ = lat.mixed_cg_her(dpm, dj, 2000, 1e-18, 1, N, op="Qsw_pm_psi")           # fp32 inner operator with the same twist
+    assert rel_err(dpm.download(), Pm[:N]) < 1e-7
+    orc.set_mu3(0.0); lat.set_mu3(0.0)
     ref[:N] = k; orc.op("Qsw_minus_psi", ref, ref)
     dl.upload(k); lat.op("Qsw_minus_psi", dl, dl)                      # in place, invert_clover_eo.c:128
     assert rel_err(dl.download(), ref[:N]) < TOL

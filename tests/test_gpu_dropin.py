@@ -298,6 +298,12 @@ def test_clover_drop_in(host):
     l = np.zeros_like(k); ref = orc.new_field()
     d.Qsw_pm_psi(_p(l), _p(k)); orc.op("Qsw_pm_psi", ref, k.copy())
     assert rel_err(l, ref[:N]) < TOL
+    stub.stub_set_mu3(0.05); orc.set_mu3(0.05)                        # g_mu3 is read at call time like g_mu
+    try:
+        d.Qsw_pm_psi(_p(l), _p(k)); orc.op("Qsw_pm_psi", ref, k.copy())
+    finally:
+        stub.stub_set_mu3(0.0); orc.set_mu3(0.0)
+    assert rel_err(l, ref[:N]) < TOL
     kk = k.copy(); ref[:N] = k
     d.clover_inv(_p(kk), -1, mu); orc.clover_inv(ref, -1, mu)
     assert rel_err(kk, ref[:N]) < TOL

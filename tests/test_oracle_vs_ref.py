@@ -93,6 +93,10 @@ o.set_clover(sw, swi); o.set_mu(0.02)          # tmref_clover left g_mu = 0.02 i
 for name in ("Qsw_pm_psi", "Qsw_psi", "Qsw_plus_psi", "Qsw_minus_psi", "Qsw_sq_psi", "Msw_psi", "Msw_plus_psi", "Msw_minus_psi"):
     fn = getattr(lib, name); fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = None
     o.op(name, q, k); fn(sp(3), sp(0)); same(q, 3, name)
+C.c_double.in_dll(lib, "g_mu3").value = 0.07; o.set_mu3(0.07)     # odd-odd twist g_mu + g_mu3 (clovertm_operators.c:208,216,238,243,258,265)
+for name in ("Qsw_pm_psi", "Qsw_psi", "Qsw_plus_psi", "Qsw_minus_psi", "Qsw_sq_psi", "Msw_psi", "Msw_plus_psi", "Msw_minus_psi"):
+    o.op(name, q, k); getattr(lib, name)(sp(3), sp(0)); same(q, 3, name + " with g_mu3")
+C.c_double.in_dll(lib, "g_mu3").value = 0.0; o.set_mu3(0.0)
 b = o.new_field(); b[:N] = k
 o.op("Qsw_minus_psi", b, b); lib.assign(sp(4), sp(0), N); lib.Qsw_minus_psi(sp(4), sp(4)); same(b, 4, "Qsw_minus_psi in place (invert_clover_eo.c:128)")
 for name in ("assign_mul_one_sw_pm_imu", "assign_mul_one_sw_pm_imu_inv"):

@@ -818,16 +818,17 @@ int tmhip_H_eo_sw_inv_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int ie
   if (!ctx->clover_set) TMHIP_FAIL("H_eo_sw_inv_psi called before tmhip_set_clover");
   return tmhip_launch_hopping(ctx, ieo, l->d, k->d, nullptr, EPI_CLOVER_INV, 0, 0, true, swinv(ctx, tau3sign, mu));
 }
-/* clovertm_operators.c:233-245 (g_mu3 = 0): 4 stencil launches with the clover blocks applied in the epilogues */
+/* clovertm_operators.c:233-245: 4 stencil launches with the clover blocks applied in the epilogues; the odd-odd term twists
+ * with mu + mu3 (:238,243), the even-even inverse is the one sw_invert built for mu */
 int tmhip_Qsw_pm_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
   if (need64(l, "Qsw_pm_psi") || need64(k, "Qsw_pm_psi")) return 1;
   if (!ctx->clover_set) TMHIP_FAIL("Qsw_pm_psi called before tmhip_set_clover");
-  const double mu = ctx->mu;
+  const double mu = ctx->mu, muo = ctx->mu + ctx->mu3;
   v2d *s0 = ctx->scratch[0]->d, *s1 = ctx->scratch[1]->d;
   return tmhip_launch_hopping(ctx, TMHIP_EO, s1, k->d, nullptr, EPI_CLOVER_INV, 0, 0, true, swinv(ctx, -1, mu)) ||
-         tmhip_launch_hopping(ctx, TMHIP_OE, s0, s1, k->d, EPI_CLOVER_G5, 0, -mu, true, swpar(ctx, TMHIP_OE)) ||
+         tmhip_launch_hopping(ctx, TMHIP_OE, s0, s1, k->d, EPI_CLOVER_G5, 0, -muo, true, swpar(ctx, TMHIP_OE)) ||
          tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_CLOVER_INV, 0, 0, true, swinv(ctx, +1, mu)) ||
-         tmhip_launch_hopping(ctx, TMHIP_OE, l->d, s1, s0, EPI_CLOVER_G5, 0, +mu, true, swpar(ctx, TMHIP_OE));
+         tmhip_launch_hopping(ctx, TMHIP_OE, l->d, s1, s0, EPI_CLOVER_G5, 0, +muo, true, swpar(ctx, TMHIP_OE));
 }
 /* clovertm_operators.c:256-261 */
 int tmhip_Msw_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
@@ -836,9 +837,9 @@ int tmhip_Msw_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
   const double mu = ctx->mu;
   v2d *s1 = ctx->scratch[1]->d;
   return tmhip_launch_hopping(ctx, TMHIP_EO, s1, k->d, nullptr, EPI_CLOVER_INV, 0, 0, true, swinv(ctx, +1, mu)) ||
-         tmhip_launch_hopping(ctx, TMHIP_OE, l->d, s1, k->d, EPI_CLOVER, 0, +mu, true, swpar(ctx, TMHIP_OE));
+         tmhip_launch_hopping(ctx, TMHIP_OE, l->d, s1, k->d, EPI_CLOVER, 0, +(mu + ctx->mu3), true, swpar(ctx, TMHIP_OE));   /* :258 */
 }
-/* The rest of the e/o clover family (clovertm_operators.c:201-268, g_mu3 = 0), two launches each, clover blocks in the epilogues:
+/* The rest of the e/o clover family (clovertm_operators.c:201-268), two launches each, clover blocks in the epilogues:
  * which = 0: mu = 0 in the diagonal term (Qsw_psi / Msw_psi), +-1: Qsw_plus/minus_psi, Msw_plus/minus_psi.  l may alias k
  * (invert_clover_eo.c:128 calls Qm(Odd_new, Odd_new)): k enters the last launch only through the element-wise epilogue. */
 static int sw_hat(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int which, int epi, const char *who) {
@@ -847,7 +848,7 @@ static int sw_hat(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int which, int
   const double mu = ctx->mu;
   v2d *s1 = ctx->scratch[1]->d;
   return tmhip_launch_hopping(ctx, TMHIP_EO, s1, k->d, nullptr, EPI_CLOVER_INV, 0, 0, true, swinv(ctx, which < 0 ? -1 : +1, mu)) ||
-         tmhip_launch_hopping(ctx, TMHIP_OE, l->d, s1, k->d, epi, 0, which * mu, true, swpar(ctx, TMHIP_OE));
+         tmhip_launch_hopping(ctx, TMHIP_OE, l->d, s1, k->d, epi, 0, which * (mu + ctx->mu3), true, swpar(ctx, TMHIP_OE));   /* +-(g_mu + g_mu3), :208,216,265 */
 }
 int tmhip_Qsw_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) { return sw_hat(ctx, l, k, 0, EPI_CLOVER_G5, "Qsw_psi"); }               /* :201-206 */
 int tmhip_Qsw_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) { return sw_hat(ctx, l, k, -1, EPI_CLOVER_G5, "Qsw_minus_psi"); }  /* :209-214 */
@@ -893,9 +894,9 @@ int tmhip_Qsw_pm_psi_32(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
   const v2f *wim = ctx->sw_inv32 + (size_t)(fabs(mu) > 0 ? 1 : 0) * 72 * gs, *wip = ctx->sw_inv32, *wo = ctx->sw32 + (size_t)54 * gs;
   v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
   return tmhip_launch_hopping32(ctx, TMHIP_EO, s1, k->d32, nullptr, EPI_CLOVER_INV, 0, 0, true, wim) ||
-         tmhip_launch_hopping32(ctx, TMHIP_OE, s0, s1, k->d32, EPI_CLOVER_G5, 0, -mu, true, wo) ||
+         tmhip_launch_hopping32(ctx, TMHIP_OE, s0, s1, k->d32, EPI_CLOVER_G5, 0, -(mu + ctx->mu3), true, wo) ||
          tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_CLOVER_INV, 0, 0, true, wip) ||
-         tmhip_launch_hopping32(ctx, TMHIP_OE, l->d32, s1, s0, EPI_CLOVER_G5, 0, +mu, true, wo);
+         tmhip_launch_hopping32(ctx, TMHIP_OE, l->d32, s1, s0, EPI_CLOVER_G5, 0, +(mu + ctx->mu3), true, wo);
 }
 
 }  // extern "C"

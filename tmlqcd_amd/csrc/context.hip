@@ -266,6 +266,7 @@ int tmhip_set_ka(tmhip_ctx *ctx, const double ka[8]) {
 }
 
 int tmhip_set_mu(tmhip_ctx *ctx, double mu) { ctx->mu = mu; return 0; }
+int tmhip_set_mu3(tmhip_ctx *ctx, double mu3) { ctx->mu3 = mu3; return 0; }
 
 int tmhip_gauge_su3_deviation(tmhip_ctx *ctx, double *maxdev) {
   if (!ctx->gauge_set) TMHIP_FAIL("tmhip_gauge_su3_deviation called before tmhip_set_gauge");

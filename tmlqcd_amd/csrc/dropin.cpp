@@ -21,6 +21,7 @@ extern int g_proc_coords[4];                                      /* global.h:20
 extern su3 **g_gauge_field;                                       /* global.h:176 */
 extern int g_update_gauge_copy;                                   /* global.h:73  */
 extern double g_mu;                                               /* global.h:198 */
+extern double g_mu3 __attribute__((weak));                        /* global.h:197: odd-odd twist of the e/o clover operators is g_mu + g_mu3 */
 extern TM_COMPLEX ka0, ka1, ka2, ka3;                             /* boundary.h:25 */
 extern su3 ***sw __attribute__((weak));                           /* clovertm_operators.c:58 */
 extern su3 ***sw_inv __attribute__((weak));                       /* clovertm_operators.c:59 */
@@ -85,6 +86,7 @@ tmhip_ctx *refresh(bool need_gauge) {
                         __real__ ka2, __imag__ ka2, __real__ ka3, __imag__ ka3};
   CK(tmhip_set_ka(c, ka));
   CK(tmhip_set_mu(c, g_mu));
+  CK(tmhip_set_mu3(c, &g_mu3 ? g_mu3 : 0.));
   if (need_gauge && (g_update_gauge_copy || !g_gauge_uploaded)) {   /* Hopping_Matrix.c:135-139 */
     if (update_backward_gauge) update_backward_gauge(g_gauge_field);  // host copy + flag, as the reference
     else g_update_gauge_copy = 0;

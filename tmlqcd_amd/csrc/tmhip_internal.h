@@ -61,6 +61,7 @@ struct tmhip_ctx {
   int gs;              // padded gauge stride
   int VPR;             // host VOLUMEPLUSRAND
   double kappa, mu, theta[4];
+  double mu3;          // g_mu3 (global.h:197): the odd-odd clover term of the e/o clover operators twists with mu + mu3
   double ka[4][2];     // ka0..ka3 (re, im)
   hipStream_t stream, comm_stream;
   hipEvent_t ev_pack, ev_comm, ev_slots[16];

@@ -45,6 +45,7 @@ def load_library():
         "tmhip_sync": [vp],
         "tmhip_set_boundary": [vp, d, pd],
         "tmhip_set_mu": [vp, d],
+        "tmhip_set_mu3": [vp, d],
         "tmhip_set_gauge": [vp, vp],
         "tmhip_field_alloc": [vp, i, C.POINTER(vp)],
         "tmhip_field_upload": [vp, vp, vp, i],
@@ -250,6 +251,9 @@ class Lattice:
     def set_mu(self, mu):
         self.mu = mu
         _ck(self.lib.tmhip_set_mu(self.h, mu), "tmhip_set_mu")
+
+    def set_mu3(self, mu3):
+        _ck(self.lib.tmhip_set_mu3(self.h, mu3), "tmhip_set_mu3")
 
     def set_gauge(self, g):
         if g.shape != (self.VPR, 4, 3, 3, 2):
