@@ -8,7 +8,10 @@
  *
  * The library reads these tmLQCD globals AT CALL TIME (never cached across calls):
  *   T, LX, LY, LZ, VOLUME, RAND (global.h:82-84), g_nproc_t/x/y/z, g_proc_coords (global.h:206-207),
- *   g_gauge_field, g_update_gauge_copy (global.h:176,73), ka0..ka3 (boundary.h:25), g_mu (global.h:198).
+ *   g_gauge_field, g_update_gauge_copy (global.h:176,73), ka0..ka3 (boundary.h:25), g_mu (global.h:198),
+ *   and -- weak references, a host program without them gets 0 / the plain branch -- g_mu3 (clover odd-odd twist,
+ *   global.h:197), g_c_sw (clover branch of D_psi, global.h:198), sw / sw_inv (clovertm_operators.c:58-59),
+ *   mixcg_innereps, mixcg_maxinnersolverit (read_input.h:112-113), g_prec_sequence_d_dagger_d, g_precWS, update_backward_gauge.
  *
  * Residency (SURVEY §7 "hard parts"): the reference API passes host pointers.  Two modes:
  *   COHERENT (default) every call uploads its inputs and downloads its outputs: always
