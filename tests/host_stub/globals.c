@@ -49,9 +49,15 @@ int stub_gauge_flag(void) { return g_update_gauge_copy; }
 su3 ***sw = NULL, ***sw_inv = NULL;
 static su3 *sw_block = NULL, *swinv_block = NULL;
 static su3 **sw1 = NULL, **swinv1 = NULL;
+static int sw_volume = 0;   /* the lattice the clover arrays were allocated for: tests re-initialise the stub with other sizes */
 su3 *stub_init_clover(int which) {
   const int V = VOLUME;
+  if (sw && sw_volume != V) {
+    free(sw); free(sw_inv); free(sw1); free(swinv1); free(sw_block); free(swinv_block);
+    sw = NULL; sw_inv = NULL;
+  }
   if (!sw) {
+    sw_volume = V;
     sw = (su3 ***)calloc(V, sizeof(su3 **)); sw_inv = (su3 ***)calloc(V, sizeof(su3 **));
     sw1 = (su3 **)calloc(3 * (size_t)V, sizeof(su3 *)); swinv1 = (su3 **)calloc(4 * (size_t)V, sizeof(su3 *));
     sw_block = (su3 *)calloc(6 * (size_t)V + 1, sizeof(su3)); swinv_block = (su3 *)calloc(8 * (size_t)V + 1, sizeof(su3));
