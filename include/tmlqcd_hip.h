@@ -217,6 +217,9 @@ int tmhip_diag32_host(tmhip_ctx *ctx, void *l, const void *k, const void *j, dou
  * (default_input_values.h:193-194: 5.0e-5, 5000).  *iters = the reference's return value (-1: not converged). */
 int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N,
                        int op, double innereps, int max_inner_it, int *iters, int *outer_iters);
+/* Restart points of the last tmhip_mixed_cg_her: inner_iters[i] = the reference's j of outer iteration i
+ * (mixed_cg_her.c:152), at most `cap` of them; *n_outer = number of outer iterations run. */
+int tmhip_mixed_cg_restarts(tmhip_ctx *ctx, int *inner_iters, int cap, int *n_outer);
 /* solver/rg_mixed_cg_her.c:180-347: fp32 CG with reliable updates (restart when the iterated residual fell by `delta`
  * relative to its maximum since the last update) and an fp64 fail-safe.  *iters = iter_out + iter_in_sp + iter_in_dp
  * as the reference returns it, or -1; the three counters are reported separately when the pointers are non-NULL. */
@@ -228,6 +231,10 @@ int tmhip_rg_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int ma
 #define TMHIP_UNIQUE_ID_BYTES 128
 int tmhip_comm_get_unique_id(char id[TMHIP_UNIQUE_ID_BYTES]);             /* rank 0, then broadcast by the host program */
 int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]); /* ring of nproc_t ranks along T over RCCL */
+/* tmhip_comm_init builds TWO communicators over the same ranks: one for the half-spinor faces (second HIP stream), one
+ * (ncclCommSplit of the first) for the scalar all-reduces of the linalg (MPI_Allreduce in linalg/square_norm.c:314) and the
+ * force halos on the main stream.  Ranks in each as RCCL reports them (ncclCommCount); 0, 0 before tmhip_comm_init. */
+int tmhip_comm_count(tmhip_ctx *ctx, int *nranks_faces, int *nranks_reduce);
 /* Single-GPU self-test of the split-phase path: faces are packed, "exchanged"
  * with this rank itself and consumed by the boundary kernel.  on = 1: device-to-device
  * copies; on = 2: through a one-rank RCCL communicator (ncclSend/ncclRecv to self). */

@@ -174,6 +174,35 @@ def gen_rg(T, L, full):
     print("rg", tag, scal)
 
 
+def gen_mixed(T, L, full):
+    """solver/mixed_cg_her.c:65-202 restated over the reference's own objects (oracle/mixed_cg_ref.py): return value, inner
+    iteration count of every outer iteration and the true residual after each, for the default mixcg_innereps and a loose
+    one; the 4^4 solution."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle.mixed_cg_ref import mixed_cg_her
+    from oracle.refbind import RefLattice
+    kappa, mu = 0.125, 0.01
+    r = RefLattice(T, L, L, L, kappa=kappa, mu=mu, nfields=16, hs=True)
+    r.random_fields(123456)
+    lib, N = r.lib, r.V // 2
+    lib.tmref_convert_gauge_32()
+    scal = {"T": T, "L": L, "kappa": kappa, "mu": mu, "seed": 123456, "eps_sq": 1e-20, "rel_prec": 1, "runs": []}
+    arrs = {}
+    for innereps, max_inner in ((5.0e-5, 5000), (1.0e-2, 5000), (5.0e-5, 7)):   # default; frequent restarts; inner loop cut by max_inner_it
+        it, js, res = mixed_cg_her(r, 1, 0, 2000, 1e-20, 1, innereps, max_inner)
+        lib.Qtm_pm_psi(r.sp(2), r.sp(1)); lib.diff(r.sp(2), r.sp(0), r.sp(2), N)
+        tr = lib.square_norm(r.sp(2), N, 0) / lib.square_norm(r.sp(0), N, 0)
+        scal["runs"].append({"innereps": innereps, "max_inner_it": max_inner, "iters": it, "inner_iters": js, "outer_res_sq": res, "true_rel_res_sq": tr})
+        if full:
+            arrs["solution_innereps_%g_maxinner_%d" % (innereps, max_inner)] = r.spinor(1, N).copy()
+    tag = "%dx%d" % (T, L)
+    json.dump(scal, open(os.path.join(GOLD, "ref_mixed_scalars_%s.json" % tag), "w"), indent=1)
+    if full:
+        np.savez_compressed(os.path.join(GOLD, "ref_mixed_fields_%s.npz" % tag), **arrs)
+    print("mixed", tag, scal)
+
+
 def gen_hs(T, L):
     """Default (half-spinor) build of the reference: fp64 cross-check + fp32 twins of the mixed-precision CG."""
     sys.path.insert(0, ROOT)
@@ -205,6 +234,8 @@ if __name__ == "__main__":
         gen_hs(int(sys.argv[1]), int(sys.argv[2]))
     elif len(sys.argv) == 4 and sys.argv[3] in ("rg", "rgfull"):
         gen_rg(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "rgfull")
+    elif len(sys.argv) == 4 and sys.argv[3] in ("mixed", "mixedfull"):
+        gen_mixed(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "mixedfull")
     elif len(sys.argv) == 4 and sys.argv[3] == "force":
         gen_force(int(sys.argv[1]), int(sys.argv[2]))
     elif len(sys.argv) == 4 and sys.argv[3] == "sym":
@@ -220,5 +251,7 @@ if __name__ == "__main__":
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "force"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "rgfull"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "8", "8", "rg"])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "mixedfull"])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "8", "8", "mixed"])
         for T, L, full in ((4, 4, 1), (8, 8, 0), (6, 4, 0)):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), str(T), str(L), str(full)])

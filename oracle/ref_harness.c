@@ -70,6 +70,20 @@ int tmref_init(int T_, int LX_, int LY_, int LZ_, double kappa, double mu,
   g_spinor_field = (spinor **)calloc(nfields, sizeof(spinor *));
   if (!tmref_spinor_base || !g_spinor_field) return 3;
   for (int i = 0; i < nfields; i++) g_spinor_field[i] = tmref_spinor_base + (size_t)i * VOLUMEPLUSRAND;
+#ifdef TM_USE_OMP
+  /* first touch inside an OpenMP region with the static partition the stencil loops use (Hopping_Matrix.c / hopping_body_dbl.c:
+   * "#pragma omp for" over [0, VOLUME/2)): every thread's share of each field lands on its own NUMA node.  calloc'ed pages
+   * are not resident until written, so this is where they are placed; the gauge copy is placed the same way by the
+   * reference's own parallel update_backward_gauge. */
+  for (int i = 0; i < nfields; i++) {
+    spinor *f = g_spinor_field[i];
+    for (int half = 0; half < 2; half++) {
+      spinor *h = f + (size_t)half * (VOLUME / 2);
+#pragma omp parallel for schedule(static)
+      for (int ix = 0; ix < VOLUME / 2; ix++) memset(h + ix, 0, sizeof(spinor));
+    }
+  }
+#endif
   geometry();
   boundary(g_kappa);
 #ifdef _USE_HALFSPINOR

@@ -110,6 +110,56 @@ def test_fp32_site_diagonal_twists_on_blocks_of_any_length(host):
     d.mul_one_pm_imu_inv_32(_p(k), 1.0, 0)                      # N = 0: nothing happens
 
 
+def test_linalg_on_any_site_count_and_the_reference_known_answers(host):
+    """The reference's linalg loops over ANY N (its own unit test, tests/test_linalg_spinor.c, uses N = 2 and N = 1000 on arrays
+    that are no lattice fields at all): the drop-in symbols take 0 <= N <= VOLUME, and reproduce the literal known answers."""
+    import json, os
+    stub, d, orc, g, (T, L, V) = host
+    ka = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "linalg_known_answers.json")))
+    d.diff.argtypes = [VP, VP, VP, C.c_int]
+    d.assign.argtypes = [VP, VP, C.c_int]
+    d.assign_mul_add_r.argtypes = [VP, C.c_double, VP, C.c_int]
+    d.assign_mul_add_r_and_square.restype = C.c_double; d.assign_mul_add_r_and_square.argtypes = [VP, C.c_double, VP, C.c_int, C.c_int]
+    d.gamma5.argtypes = [VP, VP, C.c_int]
+    EPS = 1e-12
+
+    def sp(rows):
+        return np.ascontiguousarray(np.array(rows, dtype=np.float64).reshape(len(rows), 4, 3, 2))
+    R, S = sp(ka["R"]), sp(ka["S"])
+    assert abs(d.scalar_prod_r(_p(R), _p(S), 2, 0) - ka["scalar_prod_r_R_S"]) < EPS            # test_linalg_spinor.c:75-77
+    assert abs(d.square_norm(_p(R), 2, 0) - ka["square_norm_R"]) < EPS                         # :157-160
+    Q = np.zeros_like(R); d.diff(_p(Q), _p(R), _p(S), 2)                                       # :241-247
+    assert abs(d.square_norm(_p(Q), 2, 0) - ka["diff_R_minus_S_norm"]) < EPS
+    assert abs(Q[0, 0, 0, 0] - ka["diff_Q0_s0c0_re"]) < EPS and abs(Q[1, 2, 1, 1] - ka["diff_Q1_s2c1_im"]) < EPS
+    A = R.copy(); d.assign_add_mul_r(_p(A), _p(S), ka["c"], 2)                                 # :328-334
+    assert abs(d.square_norm(_p(A), 2, 0) - ka["assign_add_mul_r_norm"]) < EPS
+    assert abs(A[0, 0, 0, 0] - ka["assign_add_mul_r_R0_s0c0_re"]) < EPS and abs(A[1, 2, 1, 1] - ka["assign_add_mul_r_R1_s2c1_im"]) < EPS
+    B = R.copy(); d.assign_mul_add_r(_p(B), ka["c"], _p(S), 2)                                 # :414-420
+    assert abs(d.square_norm(_p(B), 2, 0) - ka["assign_mul_add_r_norm"]) < EPS
+    assert abs(B[0, 0, 0, 0] - ka["assign_mul_add_r_R0_s0c0_re"]) < EPS and abs(B[1, 2, 1, 1] - ka["assign_mul_add_r_R1_s2c1_im"]) < EPS
+    # the timing half of the reference's test: N = 1000 random spinors; and a prefix longer than VOLUME/2; the SAME host buffer
+    # with a different N right after (a mirror of another length must not be reused)
+    rng = np.random.default_rng(5)
+    for N in (1000, V // 2 + 100, 1, V - 1):
+        a, b = rng.random((N, 4, 3, 2)), rng.random((N, 4, 3, 2))
+        assert abs(d.scalar_prod_r(_p(a), _p(b), N, 0) - (a * b).sum()) <= 1e-13 * (a * b).sum()
+        assert abs(d.square_norm(_p(a), N, 0) - (a * a).sum()) <= 1e-13 * (a * a).sum()
+        assert abs(d.square_norm(_p(a), N // 2 + 1, 0) - (a[:N // 2 + 1] ** 2).sum()) <= 1e-13 * (a * a).sum()
+        c = a.copy(); d.assign_add_mul_r(_p(c), _p(b), -0.3, N)
+        assert rel_err(c, a - 0.3 * b) < TOL
+        q = np.zeros((N + 1, 4, 3, 2)); q[N] = 7.0
+        d.diff(_p(q), _p(a), _p(b), N)
+        assert np.array_equal(q[:N], a - b) and np.all(q[N] == 7.0)                           # nothing written past N
+        e = a.copy(); n2 = d.assign_mul_add_r_and_square(_p(e), 0.5, _p(b), N, 0)
+        assert rel_err(e, 0.5 * a + b) < TOL and abs(n2 - (e * e).sum()) <= 1e-13 * n2
+        g5 = np.zeros_like(a); d.gamma5(_p(g5), _p(a), N)
+        assert np.array_equal(g5[:, :2], a[:, :2]) and np.array_equal(g5[:, 2:], -a[:, 2:])
+    z = rng.random((4, 4, 3, 2)); z0 = z.copy()
+    assert d.square_norm(_p(z), 0, 0) == 0.0 and d.scalar_prod_r(_p(z), _p(z), 0, 0) == 0.0    # N = 0: empty loops
+    d.assign_add_mul_r(_p(z), _p(z), 2.0, 0); d.diff(_p(z), _p(z), _p(z), 0)
+    assert np.array_equal(z, z0)
+
+
 def test_mirror_registry_is_bounded(host):
     """Ever new host addresses (work fields allocated per solve, solver/solver_field.c): the registry drops the least recently
     used mirrors whose host copy is current instead of growing; results are unaffected."""

@@ -152,7 +152,7 @@ template <int WHICH>
 __device__ __forceinline__ void cg_scalar_update(CgState *st, const double *sum, double *hist, int hist_len) {
   if (WHICH == 0) {
     st->pro = *sum;
-    if (st->inner == 2) st->alpha = (double)((float)st->normsq / (float)st->pro);   // float alpha, rg_mixed_cg_her.c:126
+    if (st->inner == 2 || st->inner == 1) st->alpha = (double)((float)st->normsq / (float)st->pro);   // float pro, alpha_cg: rg_mixed_cg_her.c:126, mixed_cg_her.c:67-69,127-128
     else st->alpha = st->normsq / st->pro;
     st->x_pending = 1;
   } else if (st->inner >= 2) {
@@ -183,7 +183,7 @@ __device__ __forceinline__ void cg_scalar_update(CgState *st, const double *sum,
     }
     if (stop) { st->done = 1; st->iters = st->it; }
   } else {
-    const double err = *sum;
+    const double err = st->inner ? (double)(float)*sum : *sum;   // mixed_cg_her.c:67-69: err, beta_cg, sqnrm2 are floats in the inner loop
     st->err = err;
     st->it += 1;
     if (hist && st->it - 1 < hist_len) hist[st->it - 1] = err;
@@ -194,7 +194,7 @@ __device__ __forceinline__ void cg_scalar_update(CgState *st, const double *sum,
     else
       conv = ((err <= st->eps_sq) && (st->rel_prec == 0)) || ((err <= st->eps_sq * st->squarenorm) && (st->rel_prec == 1));
     if (conv) { st->done = 1; st->iters = st->it; }
-    else { st->beta = err / st->normsq; st->normsq = err; }
+    else { st->beta = st->inner ? (double)((float)err / (float)st->normsq) : err / st->normsq; st->normsq = err; }
   }
 }
 
@@ -287,7 +287,7 @@ static int cg_her_sync(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_i
 
 static int cg_allreduce(tmhip_ctx *ctx, double *x) {
   if (tmhip_reduce_over_ranks(ctx))
-    TMHIP_NCCL_CHECK(ncclAllReduce(x, x, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    TMHIP_NCCL_CHECK(ncclAllReduce(x, x, 1, ncclDouble, ncclSum, ctx->comm_red, ctx->stream));
   return 0;
 }
 
@@ -321,6 +321,7 @@ static int cg_enqueue_fused_qtm(tmhip_ctx *ctx, bool fp32, tmhip_field *x, tmhip
   const dim3 g = la_grid(N);
   const size_t gs = ctx->gs;
   int n1 = 0, n2 = 0;
+  if (clover && fabs(mu) > 0 && ctx->sw_inv_sets < 2) TMHIP_FAIL("Qsw_pm_psi with mu != 0 needs both sets of sw_inv (sw_invert with the current mu)");
   if (fp32) {
     v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
     if (clover) {   // Qsw_pm_psi_32 (clovertm_operators_32.c): clover_inv / clover_gamma5 epilogues instead of the twists
@@ -431,6 +432,7 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
     TMHIP_CHECK(hipMemcpyAsync(err_host, &st->err, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     done = *flag;
+    if (tmhip_check_async_error(ctx)) return 1;   // T-split rank: a halo exchange that never completed must not yield a result
     near = *err_host <= 1.0e3 * target;
   }
   TMHIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -475,6 +477,7 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
   const bool fused = ctx->opt_cg_fused_dot && tmhip_fused_dot32_ok(ctx) && (!split || ctx->opt_cg_fused_dot >= 2);   // the older mode-0 fusion is unsplit only
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   int iter = 0;
+  ctx->mixed_trace_n = 0;
   for (int i = 0; i < N_outer; i++) {
     tmhip_field *sf0 = ctx->sf32[0], *sf1 = ctx->sf32[1], *sf2 = ctx->sf32[2], *stmp;
     if (tmhip_field_zero(ctx, x)) return 1;
@@ -528,12 +531,14 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
       TMHIP_CHECK(hipMemcpyAsync(err_host, &st->err, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
       TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
       done = *flag;
+    if (tmhip_check_async_error(ctx)) return 1;   // T-split rank: a halo exchange that never completed must not yield a result
       near = *err_host <= 1.0e3 * tgt;
     }
     TMHIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (!h.done) TMHIP_FAIL("mixed_cg_her: inner loop did not terminate");
     iter += h.iters - 1;                                             /* "iter += j" with j = completed iterations - 1 */
+    if (ctx->mixed_trace_n < (int)(sizeof(ctx->mixed_trace) / sizeof(int))) ctx->mixed_trace[ctx->mixed_trace_n++] = h.iters - 1;
     /* defect in double precision (mixed_cg_her.c:157-162) */
     if (tmhip_add_from_32(ctx, P, x, N)) return 1;
     if (tmhip_apply_op(ctx, op, y, P)) return 1;
@@ -548,6 +553,14 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
   }
   *iters = -1;
   if (outer_iters) *outer_iters = N_outer;
+  return 0;
+}
+
+/* restart points of the last tmhip_mixed_cg_her: the reference's j (mixed_cg_her.c:152 "iter += j") of every outer iteration */
+extern "C" int tmhip_mixed_cg_restarts(tmhip_ctx *ctx, int *inner_iters, int cap, int *n_outer) {
+  const int n = ctx->mixed_trace_n < cap ? ctx->mixed_trace_n : cap;
+  for (int i = 0; i < n; i++) inner_iters[i] = ctx->mixed_trace[i];
+  *n_outer = ctx->mixed_trace_n;
   return 0;
 }
 
@@ -628,6 +641,7 @@ static int rg_inner_loop(tmhip_ctx *ctx, int op, bool fp32, bool fused, RgFields
     TMHIP_CHECK(hipMemcpyAsync(err_host, &st->err, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     done = *flag;
+    if (tmhip_check_async_error(ctx)) return 1;   // T-split rank: a halo exchange that never completed must not yield a result
     near = *err_host <= 1.0e3 * tgt;
     if (!done && enq > max_iter + batch) TMHIP_FAIL("rg_mixed_cg_her: inner loop did not terminate");
   }

@@ -496,8 +496,15 @@ static int need64(const tmhip_field *f, const char *who) {
   if (!f || f->kind != TMHIP_FIELD_EO || f->prec != 0) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity fp64 field\n", who); return 1; }
   return 0;
 }
+// nullptr (with a message) when the -mu set is wanted but the last tmhip_sw_invert / tmhip_set_clover built the +mu set only:
+// every caller hands the pointer to a launcher that refuses a null clover array
 static inline const v2d *swinv(tmhip_ctx *ctx, int tau3sign, double mu) {   /* clovertm_operators.c:298-300 */
-  return ctx->sw_inv + (size_t)((tau3sign < 0 && fabs(mu) > 0) ? 1 : 0) * 72 * ctx->gs;
+  const int set = (tau3sign < 0 && fabs(mu) > 0) ? 1 : 0;
+  if (set >= ctx->sw_inv_sets) {
+    fprintf(stderr, "[tmlqcd_hip] clover operator needs the -mu set of sw_inv, but sw_inv holds %d set(s): call sw_invert with the current mu\n", ctx->sw_inv_sets);
+    return nullptr;
+  }
+  return ctx->sw_inv + (size_t)set * 72 * ctx->gs;
 }
 static inline const v2d *swpar(tmhip_ctx *ctx, int ieo) { return ctx->sw + (size_t)(ieo ? 1 : 0) * 54 * ctx->gs; }
 
@@ -725,10 +732,10 @@ int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_
   const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
   const size_t n = (size_t)32 * ctx->g.LX * ctx->g.LY * ctx->g.LZ;   // doubles per slab
   TMHIP_NCCL_CHECK(ncclGroupStart());
-  TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo, n, ncclDouble, up, ctx->comm, ctx->stream));            // our t = T slab  -> up neighbour's t = 0
-  TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo + n, n, ncclDouble, dn, ctx->comm, ctx->stream));        // our t = -1 slab -> down neighbour's t = T-1
-  TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv, n, ncclDouble, dn, ctx->comm, ctx->stream));       // the down neighbour's t = T slab is our t = 0
-  TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv + n, n, ncclDouble, up, ctx->comm, ctx->stream));   // the up neighbour's t = -1 slab is our t = T-1
+  TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo, n, ncclDouble, up, ctx->comm_red, ctx->stream));            // our t = T slab  -> up neighbour's t = 0
+  TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo + n, n, ncclDouble, dn, ctx->comm_red, ctx->stream));        // our t = -1 slab -> down neighbour's t = T-1
+  TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv, n, ncclDouble, dn, ctx->comm_red, ctx->stream));       // the down neighbour's t = T slab is our t = 0
+  TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv + n, n, ncclDouble, up, ctx->comm_red, ctx->stream));   // the up neighbour's t = -1 slab is our t = T-1
   TMHIP_NCCL_CHECK(ncclGroupEnd());
   return sw_all_add_received(ctx);
 }
@@ -789,8 +796,10 @@ int tmhip_get_swpm(tmhip_ctx *ctx, void *swm_host, void *swp_host) {
 int tmhip_clover_inv(tmhip_ctx *ctx, tmhip_field *l, int tau3sign, double mu) {
   if (need64(l, "clover_inv")) return 1;
   if (!ctx->clover_set) TMHIP_FAIL("clover_inv called before tmhip_set_clover");
+  const v2d *wi = swinv(ctx, tau3sign, mu);
+  if (!wi) return 1;
   hipLaunchKernelGGL(clover_site_kernel<0>, dim3((ctx->Vh + 255) / 256), dim3(256), 0, ctx->stream, l->d, (const v2d *)l->d, (const v2d *)nullptr,
-                     swinv(ctx, tau3sign, mu), l->ns, ctx->gs, ctx->Vh, 0.0);
+                     wi, l->ns, ctx->gs, ctx->Vh, 0.0);
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -95,6 +95,15 @@ __global__ __launch_bounds__(256) void gauge_recon_dev_kernel(const v2d *__restr
 }
 
 // ------------------------------------------------------------------ helpers
+int tmhip_check_async_error(tmhip_ctx *ctx) {
+  if (!ctx->hop_seq) return 0;  // no split-phase stencil has run: nothing can have timed out
+  unsigned int err = 0;        // set by a bounded cross-stream spin that gave up (flag_wait_kernel, block_wait_flag, fused face blocks)
+  TMHIP_CHECK(hipMemcpyAsync(&err, ctx->sync_flags + 2, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (err) TMHIP_FAIL("cross-stream flag wait timed out: the halo exchange did not complete, results since the last check are invalid");
+  return 0;
+}
+
 int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes) {
   if (ctx->stage_bytes >= bytes) return 0;
   if (ctx->stage) { TMHIP_CHECK(hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
@@ -221,7 +230,7 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->force_recv) (void)hipFree(ctx->force_recv);
   if (ctx->deriv_halo) (void)hipFree(ctx->deriv_halo);
   if (ctx->deriv_halo_recv) (void)hipFree(ctx->deriv_halo_recv);
-  if (ctx->comm_ready) ncclCommDestroy(ctx->comm);
+  if (ctx->comm_ready) { ncclCommDestroy(ctx->comm_red); ncclCommDestroy(ctx->comm); }
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
   (void)hipFree(ctx->sync_flags);
@@ -238,12 +247,7 @@ void tmhip_destroy(tmhip_ctx *ctx) {
 int tmhip_sync(tmhip_ctx *ctx) {
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->comm_stream));
-  if (ctx->hop_seq) {  // a bounded cross-stream spin gave up (hopping.hip flag_wait_kernel)
-    unsigned int err = 0;
-    TMHIP_CHECK(hipMemcpy(&err, ctx->sync_flags + 2, sizeof(err), hipMemcpyDeviceToHost));
-    if (err) TMHIP_FAIL("cross-stream flag wait timed out: halo exchange did not complete");
-  }
-  return 0;
+  return tmhip_check_async_error(ctx);
 }
 
 /* boundary.c:40-55 */
@@ -272,19 +276,20 @@ int tmhip_gauge_su3_deviation(tmhip_ctx *ctx, double *maxdev) {
   if (!ctx->gauge_set) TMHIP_FAIL("tmhip_gauge_su3_deviation called before tmhip_set_gauge");
   const int saved = ctx->opt_recon;
   ctx->opt_recon = 0;                       // measure only, do not toggle the option
-  if (tmhip_check_gauge_recon(ctx)) return 1;
+  const int rc = tmhip_check_gauge_recon(ctx);
   ctx->opt_recon = saved;
+  if (rc) return 1;
   *maxdev = ctx->gauge_recon_dev;
   return 0;
 }
 
 int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "block")) { if (value != 0 && value != 64 && value != 256) TMHIP_FAIL("block must be 0 (automatic), 64 or 256"); ctx->opt_block = value; }
-  else if (!strcmp(name, "minw")) ctx->opt_minw = value;
-  else if (!strcmp(name, "occ")) ctx->opt_occ = value;
-  else if (!strcmp(name, "xcd")) ctx->opt_xcd = value;
+  else if (!strcmp(name, "minw")) { if (value < 0 || value > 8) TMHIP_FAIL("minw must be in [0, 8] waves per SIMD"); ctx->opt_minw = value; }
+  else if (!strcmp(name, "occ")) { if (value < 0 || value > 8) TMHIP_FAIL("occ must be in [0, 8] waves per SIMD (0 = no cap)"); ctx->opt_occ = value; }
+  else if (!strcmp(name, "xcd")) { if (value < 0 || value > 5) TMHIP_FAIL("xcd must be 0 (none), 1 (chunk), 2 (automatic), 3 (slab), 4 (tile) or 5 (brick)"); ctx->opt_xcd = value; }
   else if (!strcmp(name, "nt")) ctx->opt_nt = value;
-  else if (!strcmp(name, "tgrp")) ctx->opt_tgrp = value;
+  else if (!strcmp(name, "tgrp")) { if (value < 0 || value > ctx->g.T) TMHIP_FAIL("tgrp must be in [0, T]"); ctx->opt_tgrp = value; }
   else if (!strcmp(name, "flagsync")) ctx->opt_flagsync = value;
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
   else if (!strcmp(name, "fusedface")) ctx->opt_fusedface = value;
@@ -292,14 +297,14 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "bench_graph")) ctx->opt_bench_graph = value;
   else if (!strcmp(name, "gaux")) ctx->opt_gaux = value;
   else if (!strcmp(name, "gdrop")) ctx->opt_gdrop = value;
-  else if (!strcmp(name, "occ32")) ctx->opt_occ32 = value;
+  else if (!strcmp(name, "occ32")) { if (value < 0 || value > 8) TMHIP_FAIL("occ32 must be in [0, 8]"); ctx->opt_occ32 = value; }
   else if (!strcmp(name, "gauge_recon")) {
     if (value != 12 && value != 18 && value != 0) TMHIP_FAIL("gauge_recon must be 12 or 18");
     ctx->opt_recon = value == 12 ? 12 : 0;
     if (ctx->opt_recon == 12) return tmhip_check_gauge_recon(ctx);
   }
   else if (!strcmp(name, "fp32_pairs")) ctx->opt_fp32_pairs = value;
-  else if (!strcmp(name, "shape")) ctx->opt_shape = value;
+  else if (!strcmp(name, "shape")) { if (value < 0 || value > 16) TMHIP_FAIL("shape must be in [0, 16] x-planes per block"); ctx->opt_shape = value; }
   else if (!strcmp(name, "cg_sync")) ctx->opt_cg_sync = value;
   else if (!strcmp(name, "cg_batch")) ctx->opt_cg_batch = value > 0 ? value : 1;
   else TMHIP_FAIL("unknown option %s", name);
@@ -412,7 +417,7 @@ int tmhip_field_download(tmhip_ctx *ctx, tmhip_field *f, void *host, int nsites)
   TMHIP_CHECK(hipGetLastError());
   TMHIP_CHECK(hipMemcpyAsync(host, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
-  return 0;
+  return tmhip_check_async_error(ctx);
 }
 
 // ------------------------------------------------------------------ stencil entry points
@@ -455,6 +460,7 @@ int tmhip_D_psi(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q) {
 // ------------------------------------------------------------------ e/o compositions (tm_operators.c)
 /* tm_operators.c:508-526 */
 int tmhip_H_eo_tm_inv_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int ieo, double _sign) {
+  if (need_eo(l, "H_eo_tm_inv_psi") || need_eo(k, "H_eo_tm_inv_psi")) return 1;
   const double nrm = 1. / (1. + ctx->mu * ctx->mu), sign = _sign < 0. ? 1. : -1.;
   return tmhip_tm_times_hopping_matrix(ctx, ieo, l, k, nrm, sign * nrm * ctx->mu);
 }
@@ -484,11 +490,13 @@ int tmhip_Qtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
 }
 /* tm_operators.c:245-250 */
 int tmhip_Mtm_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (need_eo(l, "Mtm_plus_psi") || need_eo(k, "Mtm_plus_psi")) return 1;
   if (tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, +1.)) return 1;
   return tmhip_launch_hopping(ctx, TMHIP_OE, l->d, ctx->scratch[1]->d, k->d, EPI_TM_SUB, 1., ctx->mu, true);
 }
 /* tm_operators.c:289-294 */
 int tmhip_Mtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (need_eo(l, "Mtm_minus_psi") || need_eo(k, "Mtm_minus_psi")) return 1;
   if (tmhip_H_eo_tm_inv_psi(ctx, ctx->scratch[1], k, TMHIP_EO, -1.)) return 1;
   return tmhip_launch_hopping(ctx, TMHIP_OE, l->d, ctx->scratch[1]->d, k->d, EPI_TM_SUB, 1., -ctx->mu, true);
 }
@@ -509,18 +517,22 @@ static int sym_core(tmhip_ctx *ctx, tmhip_field *k, double sign) {
 }
 /* tm_operators.c:186-192 */
 int tmhip_Qtm_plus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (need_eo(l, "Qtm_plus_sym_psi") || need_eo(k, "Qtm_plus_sym_psi")) return 1;
   return sym_core(ctx, k, +1.) || tmhip_mul_one_sub_mul_gamma5(ctx, l, k, ctx->scratch[0]);
 }
 /* tm_operators.c:223-229 */
 int tmhip_Qtm_minus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (need_eo(l, "Qtm_minus_sym_psi") || need_eo(k, "Qtm_minus_sym_psi")) return 1;
   return sym_core(ctx, k, -1.) || tmhip_mul_one_sub_mul_gamma5(ctx, l, k, ctx->scratch[0]);
 }
 /* tm_operators.c:259-265 */
 int tmhip_Mtm_plus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (need_eo(l, "Mtm_plus_sym_psi") || need_eo(k, "Mtm_plus_sym_psi")) return 1;
   return sym_core(ctx, k, +1.) || tmhip_diff(ctx, l, k, ctx->scratch[0], ctx->Vh);
 }
 /* tm_operators.c:296-302 */
 int tmhip_Mtm_minus_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (need_eo(l, "Mtm_minus_sym_psi") || need_eo(k, "Mtm_minus_sym_psi")) return 1;
   return sym_core(ctx, k, -1.) || tmhip_diff(ctx, l, k, ctx->scratch[0], ctx->Vh);
 }
 /* tm_operators.c:312-322 : (Mtm_plus_sym)^dagger = 1 - g5 H_oe A_-^-1 H_eo A_-^-1 g5 ; l is used as work space first,
@@ -538,6 +550,7 @@ int tmhip_Mtm_plus_sym_dagg_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) 
  *   l = g5 ( k - A_+^-1 A_-^-1 H_oe A_-^-1 H_eo k ).
  * A drop-in has to return the same field, so that is what is computed here (2 stencils instead of 4). */
 int tmhip_Qtm_pm_sym_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
+  if (need_eo(l, "Qtm_pm_sym_psi") || need_eo(k, "Qtm_pm_sym_psi")) return 1;
   return sym_core(ctx, k, -1.) || tmhip_mul_one_pm_imu_inv(ctx, ctx->scratch[0], +1., ctx->Vh) ||
          tmhip_mul_one_sub_mul_gamma5(ctx, l, k, ctx->scratch[0]);
 }
@@ -564,7 +577,16 @@ int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]) {
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   TMHIP_NCCL_CHECK(ncclCommInitRank(&ctx->comm, ctx->g.nproc_t, u, ctx->g.proc_t));
+  // second communicator over the same ranks for everything issued on the main stream (collective: every rank calls it here)
+  TMHIP_NCCL_CHECK(ncclCommSplit(ctx->comm, 0, ctx->g.proc_t, &ctx->comm_red, nullptr));
   ctx->comm_ready = true;
+  return 0;
+}
+
+int tmhip_comm_count(tmhip_ctx *ctx, int *nranks_faces, int *nranks_reduce) {
+  if (!ctx->comm_ready) { *nranks_faces = *nranks_reduce = 0; return 0; }
+  TMHIP_NCCL_CHECK(ncclCommCount(ctx->comm, nranks_faces));
+  TMHIP_NCCL_CHECK(ncclCommCount(ctx->comm_red, nranks_reduce));
   return 0;
 }
 
@@ -577,6 +599,7 @@ int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
     ncclUniqueId u;
     TMHIP_NCCL_CHECK(ncclGetUniqueId(&u));
     TMHIP_NCCL_CHECK(ncclCommInitRank(&ctx->comm, 1, u, 0));
+    TMHIP_NCCL_CHECK(ncclCommSplit(ctx->comm, 0, 0, &ctx->comm_red, nullptr));
     ctx->comm_ready = true;
   }
   return 0;

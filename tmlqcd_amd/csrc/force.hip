@@ -210,8 +210,8 @@ int tmhip_deriv_Sb(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, doub
     if (!ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
     const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
     TMHIP_NCCL_CHECK(ncclGroupStart());
-    TMHIP_NCCL_CHECK(ncclSend(ctx->force_send, n, ncclDouble, dn, ctx->comm, ctx->stream));
-    TMHIP_NCCL_CHECK(ncclRecv(ctx->force_recv, n, ncclDouble, up, ctx->comm, ctx->stream));
+    TMHIP_NCCL_CHECK(ncclSend(ctx->force_send, n, ncclDouble, dn, ctx->comm_red, ctx->stream));
+    TMHIP_NCCL_CHECK(ncclRecv(ctx->force_recv, n, ncclDouble, up, ctx->comm_red, ctx->stream));
     TMHIP_NCCL_CHECK(ncclGroupEnd());
   }
   return force_launch(ctx, ieo, l, k, factor, ctx->force_recv);

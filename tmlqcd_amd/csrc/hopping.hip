@@ -91,6 +91,9 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipSetDevice(c->device));
     TMHIP_CHECK(hipStreamWaitEvent(c->comm_stream, up->ev_pack, 0));
     TMHIP_CHECK(hipStreamWaitEvent(c->comm_stream, dn->ev_pack, 0));
+    // ... and after this rank's own pack: it sits behind the previous call's boundary kernel in c->stream order, and that
+    // kernel still reads recv_up / recv_dn -- the new faces must not land under it (back-to-back calls, slow ranks)
+    TMHIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
     TMHIP_CHECK(hipMemcpyPeerAsync(c->recv_up, c->device, up->send_dn, up->device, fb, c->comm_stream));
     TMHIP_CHECK(hipMemcpyPeerAsync(c->recv_dn, c->device, dn->send_up, dn->device, fb, c->comm_stream));
     TMHIP_CHECK(hipEventRecord(c->ev_comm, c->comm_stream));

@@ -151,12 +151,12 @@ int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out) 
   hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, nblocks, ctx->result_dev);
   if (parallel && tmhip_reduce_over_ranks(ctx)) {
     // MPI_Allreduce(..., MPI_SUM) of the reference (square_norm.c:314): one double over RCCL
-    TMHIP_NCCL_CHECK(ncclAllReduce(ctx->result_dev, ctx->result_dev, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    TMHIP_NCCL_CHECK(ncclAllReduce(ctx->result_dev, ctx->result_dev, 1, ncclDouble, ncclSum, ctx->comm_red, ctx->stream));
   }
   TMHIP_CHECK(hipMemcpyAsync(ctx->result_host, ctx->result_dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   *out = *ctx->result_host;
-  return 0;
+  return tmhip_check_async_error(ctx);
 }
 
 extern "C" {

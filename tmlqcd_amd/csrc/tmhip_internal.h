@@ -92,7 +92,9 @@ struct tmhip_ctx {
   // (tm_operators_32.c Qtm_pm_psi_32), sf32 = solver_field32[0..3] (mixed_cg_her.c:72-102)
   tmhip_field *scratch32[2]; tmhip_field *sf32[4];
   // halo exchange
-  ncclComm_t comm; bool comm_ready; bool loopback; bool loopback_rccl;
+  // Two communicators over the same ranks: `comm` carries the half-spinor faces on comm_stream, `comm_red` (ncclCommSplit of
+  // `comm`) everything issued on the main stream (scalar all-reduces, force halos) -- no communicator is driven from two streams.
+  ncclComm_t comm, comm_red; bool comm_ready; bool loopback; bool loopback_rccl;
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
   unsigned int *sync_flags; unsigned int hop_seq;  // [0] in-ready, [1] boundary-done, [2] timeout error
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
@@ -101,6 +103,7 @@ struct tmhip_ctx {
   v2d *force_send, *force_recv;   // T-split deriv_Sb: [24][face] t=0 slices of (l, k), ours / the up-neighbour's
   // device-resident CG state (cg.hip)
   void *cg_state; double *cg_hist; int cg_hist_len;
+  int mixed_trace[256]; int mixed_trace_n;   // inner iteration count of every outer iteration of the last tmhip_mixed_cg_her
   // options
   int opt_block, opt_xcd, opt_nt, opt_minw, opt_occ, opt_occ32;        // stencil launch shape (tmhip_set_option, include/tmlqcd_hip.h)
   int opt_tgrp, opt_shape, opt_gaux, opt_gdrop, opt_fp32_pairs;
@@ -149,6 +152,9 @@ int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in,
                                const v2f *cw = nullptr, int chained = 0);
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx);
 int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out);
+// After a host-visible synchronisation of a T-split rank: non-zero (with a message) when a bounded cross-stream flag wait gave up,
+// i.e. the result just synchronised may have been computed from stale faces.  Free when no split-phase stencil has run.
+int tmhip_check_async_error(tmhip_ctx *ctx);
 extern "C" int tmhip_check_gauge_recon(tmhip_ctx *ctx);   // context.hip: unitarity guard of the gauge_recon=12 option
 int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes);
 int tmhip_field_alloc_prec(tmhip_ctx *ctx, int kind, int prec, tmhip_field **out);

@@ -118,10 +118,12 @@ def load_library():
         "tmhip_assign_add_mul_r_32": [vp, vp, vp, C.c_float, i],
         "tmhip_assign_mul_add_r_32": [vp, vp, C.c_float, vp, i],
         "tmhip_mixed_cg_her": [vp, vp, vp, i, d, i, i, i, d, i, C.POINTER(i), C.POINTER(i)],
+        "tmhip_mixed_cg_restarts": [vp, C.POINTER(i), i, C.POINTER(i)],
         "tmhip_rg_mixed_cg_her": [vp, vp, vp, i, d, i, i, i, d, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)],
         "tmhip_comm_get_unique_id": [C.c_char_p],
         "tmhip_comm_init": [vp, C.c_char_p],
         "tmhip_comm_set_loopback": [vp, i],
+        "tmhip_comm_count": [vp, C.POINTER(i), C.POINTER(i)],
         "tmhip_bench_hopping": [vp, vp, vp, vp, i, pd],
         "tmhip_multi_hopping_matrix": [i, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp)],
         "tmhip_event_record": [vp, i],
@@ -408,6 +410,12 @@ class Lattice:
                                         max_inner_it, C.byref(it), C.byref(outer)), "mixed_cg_her")
         return it.value, outer.value
 
+    def mixed_cg_restarts(self):
+        """Inner iteration count (the reference's j, mixed_cg_her.c:152) of every outer iteration of the last mixed_cg_her."""
+        buf, n = (C.c_int * 256)(), C.c_int()
+        _ck(self.lib.tmhip_mixed_cg_restarts(self.h, buf, 256, C.byref(n)), "tmhip_mixed_cg_restarts")
+        return list(buf[:min(n.value, 256)])
+
     def rg_mixed_cg_her(self, P, Q, max_iter, eps_sq, rel_prec, N, delta=5.0e-5, op="Qtm_pm_psi"):
         """solver/rg_mixed_cg_her.c:180 (reliable updates, fp64 fail-safe); delta = solver_params.mcg_delta.
         Returns (iterations as the reference counts them, (iter_out, iter_in_sp, iter_in_dp))."""
@@ -522,6 +530,12 @@ class Lattice:
 
     def comm_init(self, uid):
         _ck(self.lib.tmhip_comm_init(self.h, uid), "tmhip_comm_init")
+
+    def comm_count(self):
+        """(ranks of the face communicator, ranks of the reduction communicator) as RCCL reports them; (0, 0) without one."""
+        a, b = C.c_int(), C.c_int()
+        _ck(self.lib.tmhip_comm_count(self.h, C.byref(a), C.byref(b)), "tmhip_comm_count")
+        return a.value, b.value
 
     def set_loopback(self, on):
         _ck(self.lib.tmhip_comm_set_loopback(self.h, int(on)), "tmhip_comm_set_loopback")
