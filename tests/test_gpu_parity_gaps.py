@@ -206,7 +206,7 @@ def test_mixed_cg_her_restart_points_against_reference_restatement(tag):
     for run in s["runs"]:
         it, outer = lat.mixed_cg_her(dp, dq, 2000, s["eps_sq"], s["rel_prec"], N, innereps=run["innereps"], max_inner_it=run["max_inner_it"])
         js = lat.mixed_cg_restarts()
-        assert it > 0 and len(js) == outer and it == sum(js) + 2 * outer - 1     # :152 iter += j, :196 iter++, :186 return iter + i
+        assert it > 0 and len(js) == outer and it == sum(js) + 2 * (outer - 1)   # :152 iter += j, :196 iter++ after all but the last, :186 return iter + i
         assert abs(outer - len(run["inner_iters"])) <= 1, (run, js)
         assert abs(it - run["iters"]) <= max(3, run["iters"] // 8), (run, it, js)
         for a, b in zip(js[:-1], run["inner_iters"][:-1]):                      # every restart but the last (which depends on the exit taken)
