@@ -257,7 +257,7 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "xcd"   block order: 2 automatic (default; tile order up to L = 32, slab order above), 0 none, 1 one chunk per XCD,
  *           3 slab, 4 tile;  "tgrp" time-slices per tile group (0 = automatic)
  *   "occ" / "occ32"  waves per SIMD allowed by a dynamic-LDS cap for the fp64 / fp32 stencil (3 / 0 = no cap)
- *   "minw" 4: __launch_bounds__(BS, 4);  "shape" n: compact n-x-plane block shape;  "fp32_pairs" 1: two sites per thread in fp32
+ *   "minw" 4: __launch_bounds__(BS, 4);  "shape" n: compact n-x-plane block shape
  *   "flagsync" 1|0 flag kernels vs HIP events on the split path;  "fusedface" -1 (default: on from T_local = 16 up) | 1 | 0: faces in the same launch as the interior;
  *   "facesplit" 0|1 two-kernel split path: one thread per face site (default) vs the face kernel with the eight hops of a site spread over the four waves of a block
  *   "cg_fused_dot" 2 (default: alpha / residual / norm in the stencil epilogues), 1 scalar product only, 0 plain linalg kernels

@@ -222,3 +222,54 @@ def test_slab_block_order_with_uneven_slabs():
     orc.Hopping_Matrix(1, ref, k32.astype(np.float64)); lat.Hopping_Matrix_32(1, l32, d32)     # 512-site blocks: 4.5 per slice -> tile order
     assert rel_err(l32.download().astype(np.float64), ref[:N]) < 2e-6
     lat.close()
+
+
+@pytest.mark.parametrize("dims", [(16, 16, 16, 16), (4, 8, 8, 8), (6, 8, 16, 8), (4, 16, 8, 32), (8, 32, 32, 32)])
+def test_lds_staged_stencil_matches_the_gather_stencil(dims):
+    """"lds" 1: the block's own 256 input spinors are staged in LDS once and every neighbour that falls inside the block is read from
+    there (+-z always, +-y except one edge row per wave).  Same operations in the same order as the gather kernel, for every epilogue, the fp32 twin, the
+    split path and cg_her."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T, LX, LY, LZ = dims
+    kappa, mu, theta = 0.131, 0.02, (1.0, 0.0, 0.4, 0.0)
+    lat = Lattice(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta)
+    g = syn.gauge_field(91, T, LX, LY, LZ)
+    lat.set_gauge(g)
+    lat.set_option("block", 256)
+    N = lat.Vh
+    k, p = syn.spinor_field_eo(92, 1, T, LX, LY, LZ), syn.spinor_field_eo(93, 0, T, LX, LY, LZ)
+    dk, dp, dl = lat.field(k), lat.field(p), lat.field()
+    k32 = lat.field32(k.astype(np.float32)); l32 = lat.field32()
+    lat.mixed_cg_her(dl, dk, 1, 1e-2, 1, N)          # builds the fp32 gauge copy
+
+    def run_all():
+        out = []
+        for ieo in (0, 1):
+            lat.Hopping_Matrix(ieo, dl, dk); out.append(dl.download())
+            lat.tm_times_Hopping_Matrix(ieo, dl, dk, 0.7 - 0.2j); out.append(dl.download())
+            lat.tm_sub_Hopping_Matrix(ieo, dl, dp, dk, 0.7 - 0.2j); out.append(dl.download())
+            lat.Hopping_Matrix_32(ieo, l32, k32); out.append(l32.download())
+        lat.Qtm_pm_psi(dl, dk); out.append(dl.download())
+        dl.zero()
+        it, hist = lat.cg_her(dl, dk, 300, 1e-18, 1, N)
+        out.append(dl.download()); out.append(np.array([it], dtype=np.float64)); out.append(hist.copy())
+        return out
+    for loop in (0, 1):
+        if loop and (T < 4 or (LX * LY * LZ // 2) % 256):
+            continue
+        lat.set_loopback(loop)
+        lat.set_option("lds", 0); lat.set_option("lds32", 0); a = run_all()
+        for mode in (1,):
+            lat.set_option("lds", mode); lat.set_option("lds32", mode); b = run_all()
+            for x, y in zip(a[:-2], b[:-2]):         # same operations on the same values; only FMA contraction may differ between the two instantiations
+                assert rel_err(y.astype(np.float64), x.astype(np.float64)) < (2e-6 if x.dtype == np.float32 else 1e-14), (dims, loop, mode)
+            assert abs(a[-2][0] - b[-2][0]) <= 1 and np.allclose(a[-1][:-2], b[-1][:-2], rtol=1e-6), (dims, loop, mode)
+    if dims == (16, 16, 16, 16):      # and against the oracle
+        orc = Oracle(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta, threads=8)
+        orc.set_gauge(g)
+        ref = orc.new_field(); orc.Hopping_Matrix(0, ref, k)
+        lat.set_loopback(0); lat.Hopping_Matrix(0, dl, dk)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+    lat.close()

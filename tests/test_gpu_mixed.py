@@ -28,12 +28,13 @@ def setup():
     lat.close()
 
 
-@pytest.mark.parametrize("pairs,recon", [(1, 18), (0, 18), (1, 12), (0, 12)])
-def test_fp32_stencil_and_operator(setup, pairs, recon):
-    """pairs=1: two sites per thread (16-byte accesses, LZ % 4 == 0); pairs=0: one site per thread.
-    recon=12: the opt-in 12-real gauge read (third row rebuilt in fp32 registers)."""
+@pytest.mark.parametrize("lds,recon", [(0, 18), (1, 18), (0, 12), (1, 12)])
+def test_fp32_stencil_and_operator(setup, lds, recon):
+    """lds=1: the per-wave LDS-staged instance (block 256); recon=12: the opt-in 12-real gauge read (third row rebuilt in fp32
+    registers).  The fp32 links are read in their packed layout (float4 pairs of elements) in every case."""
     orc, lat = setup
-    lat.set_option("fp32_pairs", pairs)
+    lat.set_option("lds32", lds)
+    lat.set_option("block", 256 if lds else 0)
     lat.set_option("gauge_recon", recon)
     N = orc.Vh
     k32 = random_spinor(1, N).astype(np.float32)
@@ -62,7 +63,7 @@ def test_fp32_stencil_and_operator(setup, pairs, recon):
         assert it > 0 and ((chk[:N] - q) ** 2).sum() / (q ** 2).sum() <= 1e-20
         dq.free(); dp.free()
     lat.set_option("gauge_recon", 18)
-    lat.set_option("fp32_pairs", 0)                      # back to the default (one site per thread)
+    lat.set_option("lds32", 0); lat.set_option("block", 0)
     dk.free(); dl.free()
 
 

@@ -8,6 +8,8 @@
 // are those of the sequential algorithm even though the host polls `done` only every few iterations.
 #include "tmhip_internal.h"
 
+static inline v4f *F4(tmhip_field *f) { return reinterpret_cast<v4f *>(f->d32); }   // fp32 field as six float4 planes
+
 struct CgState {
   double normsq, pro, err, alpha, beta, squarenorm, eps_sq;
   int rel_prec, done, iters, it;
@@ -41,89 +43,91 @@ __device__ __forceinline__ void cg_block_reduce_store(double v, double *partials
   }
 }
 
+// The field kernels are written once for both precisions: V = v2d (fp64 field, twelve planes of complex doubles) or v4f (fp32
+// field, six planes of component pairs); scalars have the element type, sums are accumulated in double.
+__device__ __forceinline__ double la_dot(v2d a, v2d b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ double la_dot(v4f a, v4f b) { return ((double)a.x * b.x + (double)a.y * b.y) + ((double)a.z * b.z + (double)a.w * b.w); }
+
 // pro = <sf2, sf0>   (cg_her.c:93)
-template <class V2>
-__global__ __launch_bounds__(LA_BS) void cg_dot_kernel(const V2 *__restrict__ S, const V2 *__restrict__ R, int ns, int N,
+template <class V>
+__global__ __launch_bounds__(LA_BS) void cg_dot_kernel(const V *__restrict__ S, const V *__restrict__ R, int ns, int N,
                                                        double *partials, const CgState *st) {
   if (st->done) return;
-  const V2 *s = S + (size_t)blockIdx.y * ns, *r = R + (size_t)blockIdx.y * ns;
+  const V *s = S + (size_t)blockIdx.y * ns, *r = R + (size_t)blockIdx.y * ns;
   double acc = 0.0;
   const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
 #pragma unroll
   for (int u = 0; u < LA_UNROLL; u++) {
     const int i = base + u * LA_BS;
-    if (i < N) { const V2 a = s[i], b = r[i]; acc += (double)a.x * (double)b.x + (double)a.y * (double)b.y; }
+    if (i < N) acc += la_dot(s[i], r[i]);
   }
   cg_block_reduce_store(acc, partials);
 }
 
 // P += alpha sf2 ; sf0 = -alpha sf0 + sf1 ; partial |sf0|^2   (cg_her.c:95,101 fused: same bytes, one launch)
-template <class V2>
-__global__ __launch_bounds__(LA_BS) void cg_update_kernel(V2 *__restrict__ P, const V2 *__restrict__ SF2, V2 *__restrict__ SF0,
-                                                          const V2 *__restrict__ SF1, int ns, int N, double *partials,
+template <class V>
+__global__ __launch_bounds__(LA_BS) void cg_update_kernel(V *__restrict__ P, const V *__restrict__ SF2, V *__restrict__ SF0,
+                                                          const V *__restrict__ SF1, int ns, int N, double *partials,
                                                           const CgState *st) {
   if (st->done) return;
-  typedef decltype(V2{}.x) R;
+  typedef decltype(V{}.x) R;
   const R alpha = (R)st->alpha;
   const size_t off = (size_t)blockIdx.y * ns;
-  V2 *p = P + off, *r0 = SF0 + off;
-  const V2 *s2 = SF2 + off, *r1 = SF1 + off;
+  V *p = P + off, *r0 = SF0 + off;
+  const V *s2 = SF2 + off, *r1 = SF1 + off;
   double acc = 0.0;
   const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
 #pragma unroll
   for (int u = 0; u < LA_UNROLL; u++) {
     const int i = base + u * LA_BS;
     if (i < N) {
-      const V2 a = p[i], b = s2[i];
-      p[i] = V2{a.x + alpha * b.x, a.y + alpha * b.y};
-      V2 c = r0[i];
-      const V2 d = r1[i];
-      c = V2{-alpha * c.x + d.x, -alpha * c.y + d.y};
+      p[i] = p[i] + alpha * s2[i];
+      const V c = -alpha * r0[i] + r1[i];
       r0[i] = c;
-      acc += (double)c.x * (double)c.x + (double)c.y * (double)c.y;
+      acc += la_dot(c, c);
     }
   }
   cg_block_reduce_store(acc, partials);
 }
 
 // sf2 = beta sf2 + sf0   (cg_her.c:122)
-template <class V2>
-__global__ __launch_bounds__(LA_BS) void cg_xpay_kernel(V2 *__restrict__ SF2, const V2 *__restrict__ SF0, int ns, int N,
+template <class V>
+__global__ __launch_bounds__(LA_BS) void cg_xpay_kernel(V *__restrict__ SF2, const V *__restrict__ SF0, int ns, int N,
                                                         const CgState *st) {
   if (st->done) return;
-  typedef decltype(V2{}.x) R;
+  typedef decltype(V{}.x) R;
   const R beta = (R)st->beta;
-  V2 *x = SF2 + (size_t)blockIdx.y * ns;
-  const V2 *y = SF0 + (size_t)blockIdx.y * ns;
+  V *x = SF2 + (size_t)blockIdx.y * ns;
+  const V *y = SF0 + (size_t)blockIdx.y * ns;
   const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
 #pragma unroll
   for (int u = 0; u < LA_UNROLL; u++) {
     const int i = base + u * LA_BS;
-    if (i < N) { const V2 a = x[i], b = y[i]; x[i] = V2{beta * a.x + b.x, beta * a.y + b.y}; }
+    if (i < N) x[i] = beta * x[i] + y[i];
   }
 }
 
 // Fused-iteration tail: P += alpha p (cg_her.c:95, owed since alpha became known) and p = beta p + r (cg_her.c:122) in
 // one pass over p.  After convergence the direction update is skipped but the owed P update still happens -- exactly
 // once: the next alpha-kernel clears x_pending when it finds `done` set.
-template <class V2>
-__global__ __launch_bounds__(LA_BS) void cg_xp_kernel(V2 *__restrict__ X, V2 *__restrict__ Pd, const V2 *__restrict__ Rr, int ns, int N,
+template <class V>
+__global__ __launch_bounds__(LA_BS) void cg_xp_kernel(V *__restrict__ X, V *__restrict__ Pd, const V *__restrict__ Rr, int ns, int N,
                                                       const CgState *st) {
   const bool upd_x = st->x_pending != 0, upd_p = !st->done;
   if (!upd_x && !upd_p) return;
-  typedef decltype(V2{}.x) R;
+  typedef decltype(V{}.x) R;
   const R alpha = (R)st->alpha, beta = (R)st->beta;
   const size_t off = (size_t)blockIdx.y * ns;
-  V2 *x = X + off, *p = Pd + off;
-  const V2 *r = Rr + off;
+  V *x = X + off, *p = Pd + off;
+  const V *r = Rr + off;
   const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
 #pragma unroll
   for (int u = 0; u < LA_UNROLL; u++) {
     const int i = base + u * LA_BS;
     if (i < N) {
-      const V2 pv = p[i];
-      if (upd_x) { const V2 a = x[i]; x[i] = V2{a.x + alpha * pv.x, a.y + alpha * pv.y}; }
-      if (upd_p) { const V2 b = r[i]; p[i] = V2{beta * pv.x + b.x, beta * pv.y + b.y}; }
+      const V pv = p[i];
+      if (upd_x) x[i] = x[i] + alpha * pv;
+      if (upd_p) p[i] = beta * pv + r[i];
     }
   }
 }
@@ -318,7 +322,7 @@ static int cg_reduce_update(tmhip_ctx *ctx, int n, CgState *st, double *hist, in
 static int cg_enqueue_fused_qtm(tmhip_ctx *ctx, bool fp32, tmhip_field *x, tmhip_field *p, tmhip_field *r, CgState *st, double *hist,
                                 int hist_len, int N, bool clover = false) {
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
-  const dim3 g = la_grid(N);
+  const dim3 g = fp32 ? la_grid32(N) : la_grid(N);
   const size_t gs = ctx->gs;
   int n1 = 0, n2 = 0;
   if (clover && fabs(mu) > 0 && ctx->sw_inv_sets < 2) TMHIP_FAIL("Qsw_pm_psi with mu != 0 needs both sets of sw_inv (sw_invert with the current mu)");
@@ -339,7 +343,7 @@ static int cg_enqueue_fused_qtm(tmhip_ctx *ctx, bool fp32, tmhip_field *x, tmhip
       if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d32, &st->alpha, nullptr, 1)) return 1;
     }
     if (cg_reduce_update<1>(ctx, n2, st, hist, hist_len)) return 1;
-    hipLaunchKernelGGL(cg_xp_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, x->d32, p->d32, (const v2f *)r->d32, p->ns, N, st);
+    hipLaunchKernelGGL(cg_xp_kernel<v4f>, g, dim3(LA_BS), 0, ctx->stream, F4(x), F4(p), (const v4f *)F4(r), p->ns, N, st);
   } else {
     v2d *s0 = ctx->scratch[0]->d, *s1 = ctx->scratch[1]->d;
     if (clover) {   // Qsw_pm_psi (clovertm_operators.c:233-245)
@@ -469,7 +473,7 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
   sqnrm_d = sourcesquarenorm;
   if (tmhip_assign(ctx, delta, Q, N)) return 1;
   if (tmhip_field_zero(ctx, P)) return 1;
-  const dim3 g = la_grid(N);
+  const dim3 g = la_grid32(N);   // every field kernel of the inner loop works on fp32 fields
   const int nblk = g.x * g.y;
   int *flag = (int *)(ctx->result_host + 2);
   const int batch = ctx->opt_cg_batch > 0 ? ctx->opt_cg_batch : 4;
@@ -506,7 +510,7 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
         }
         if (clover) {
           if (tmhip_Qsw_pm_psi_32(ctx, sf0, sf2)) return 1;
-          hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, ctx->partials, st);
+          hipLaunchKernelGGL(cg_dot_kernel<v4f>, g, dim3(LA_BS), 0, ctx->stream, (const v4f *)F4(sf2), (const v4f *)F4(sf0), sf2->ns, N, ctx->partials, st);
         } else {
         if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, sf2->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
         if (tmhip_launch_hopping32(ctx, TMHIP_OE, s0, s1, sf2->d32, EPI_TM_SUB_G5, 1., -mu, true)) return 1;
@@ -515,14 +519,14 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
           if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, sf0->d32, s1, s0, sf2->d32, 1., mu, &ndot)) return 1;
         } else {
           if (tmhip_launch_hopping32(ctx, TMHIP_OE, sf0->d32, s1, s0, EPI_TM_SUB_G5, 1., mu, true)) return 1;
-          hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, ctx->partials, st);
+          hipLaunchKernelGGL(cg_dot_kernel<v4f>, g, dim3(LA_BS), 0, ctx->stream, (const v4f *)F4(sf2), (const v4f *)F4(sf0), sf2->ns, N, ctx->partials, st);
         }
         }
         if (cg_reduce_update<0>(ctx, ndot, st, (double *)nullptr, 0)) return 1;
-        hipLaunchKernelGGL(cg_update_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, x->d32, (const v2f *)sf2->d32, sf0->d32, (const v2f *)sf1->d32,
+        hipLaunchKernelGGL(cg_update_kernel<v4f>, g, dim3(LA_BS), 0, ctx->stream, F4(x), (const v4f *)F4(sf2), F4(sf0), (const v4f *)F4(sf1),
                            x->ns, N, ctx->partials, st);
         if (cg_reduce_update<1>(ctx, nblk, st, (double *)nullptr, 0)) return 1;
-        hipLaunchKernelGGL(cg_xpay_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, sf2->d32, (const v2f *)sf0->d32, sf2->ns, N, st);
+        hipLaunchKernelGGL(cg_xpay_kernel<v4f>, g, dim3(LA_BS), 0, ctx->stream, F4(sf2), (const v4f *)F4(sf0), sf2->ns, N, st);
         stmp = sf0; sf0 = sf1; sf1 = stmp;
       }
       enq += want;
@@ -570,7 +574,7 @@ extern "C" int tmhip_mixed_cg_restarts(tmhip_ctx *ctx, int *inner_iters, int cap
 struct RgFields { tmhip_field *x, *p, *q, *r; };
 
 static int rg_enqueue_iteration(tmhip_ctx *ctx, int op, bool fp32, bool fused, RgFields &f, CgState *st, int N) {
-  const dim3 g = la_grid(N);
+  const dim3 g = fp32 ? la_grid32(N) : la_grid(N);
   const int nblk = g.x * g.y;
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   int ndot = nblk;
@@ -578,7 +582,7 @@ static int rg_enqueue_iteration(tmhip_ctx *ctx, int op, bool fp32, bool fused, R
   if (fp32) {
     if (op == TMHIP_OP_QSW_PM) {
       if (tmhip_Qsw_pm_psi_32(ctx, f.q, f.p)) return 1;
-      hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)f.p->d32, (const v2f *)f.q->d32, f.p->ns, N, ctx->partials, st);
+      hipLaunchKernelGGL(cg_dot_kernel<v4f>, g, dim3(LA_BS), 0, ctx->stream, (const v4f *)F4(f.p), (const v4f *)F4(f.q), f.p->ns, N, ctx->partials, st);
     } else {
       v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
       if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, f.p->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
@@ -588,7 +592,7 @@ static int rg_enqueue_iteration(tmhip_ctx *ctx, int op, bool fp32, bool fused, R
         if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, f.q->d32, s1, s0, f.p->d32, 1., mu, &ndot)) return 1;
       } else {
         if (tmhip_launch_hopping32(ctx, TMHIP_OE, f.q->d32, s1, s0, EPI_TM_SUB_G5, 1., mu, true)) return 1;
-        hipLaunchKernelGGL(cg_dot_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, (const v2f *)f.p->d32, (const v2f *)f.q->d32, f.p->ns, N, ctx->partials, st);
+        hipLaunchKernelGGL(cg_dot_kernel<v4f>, g, dim3(LA_BS), 0, ctx->stream, (const v4f *)F4(f.p), (const v4f *)F4(f.q), f.p->ns, N, ctx->partials, st);
       }
     }
   } else {
@@ -597,14 +601,14 @@ static int rg_enqueue_iteration(tmhip_ctx *ctx, int op, bool fp32, bool fused, R
   }
   if (cg_reduce_update<0>(ctx, ndot, st, (double *)nullptr, 0)) return 1;
   if (fp32)
-    hipLaunchKernelGGL(cg_update_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, f.x->d32, (const v2f *)f.p->d32, f.q->d32, (const v2f *)f.r->d32,
+    hipLaunchKernelGGL(cg_update_kernel<v4f>, g, dim3(LA_BS), 0, ctx->stream, F4(f.x), (const v4f *)F4(f.p), F4(f.q), (const v4f *)F4(f.r),
                        f.x->ns, N, ctx->partials, st);
   else
     hipLaunchKernelGGL(cg_update_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, f.x->d, (const v2d *)f.p->d, f.q->d, (const v2d *)f.r->d, f.x->ns, N,
                        ctx->partials, st);
   if (cg_reduce_update<1>(ctx, nblk, st, (double *)nullptr, 0)) return 1;
   if (fp32)
-    hipLaunchKernelGGL(cg_xpay_kernel<v2f>, g, dim3(LA_BS), 0, ctx->stream, f.p->d32, (const v2f *)f.q->d32, f.p->ns, N, st);
+    hipLaunchKernelGGL(cg_xpay_kernel<v4f>, g, dim3(LA_BS), 0, ctx->stream, F4(f.p), (const v4f *)F4(f.q), f.p->ns, N, st);
   else
     hipLaunchKernelGGL(cg_xpay_kernel<v2d>, g, dim3(LA_BS), 0, ctx->stream, f.p->d, (const v2d *)f.q->d, f.p->ns, N, st);
   tmhip_field *t = f.q; f.q = f.r; f.r = t;   // the new residual now sits in the former q

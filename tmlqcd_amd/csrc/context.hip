@@ -167,7 +167,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
   ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 2; ctx->opt_fusedface = -1; ctx->opt_gaux = -1;
-  ctx->opt_gdrop = 0; ctx->opt_fp32_pairs = 0; ctx->opt_occ32 = 0; ctx->opt_facesplit = 0; ctx->opt_recon = 0;
+  ctx->opt_gdrop = 0; ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_occ32 = 0; ctx->opt_facesplit = 0; ctx->opt_recon = 0;
   ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
@@ -303,7 +303,19 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
     ctx->opt_recon = value == 12 ? 12 : 0;
     if (ctx->opt_recon == 12) return tmhip_check_gauge_recon(ctx);
   }
-  else if (!strcmp(name, "fp32_pairs")) ctx->opt_fp32_pairs = value;
+  else if (!strcmp(name, "gauge_mem")) {
+    // experiment: where the once-per-call link stream lives -- 0 hipMalloc (default), 1 hipDeviceMallocUncached (not cached in L2),
+    // 2 fine-grained, 3 physically contiguous.  Re-allocates the gauge copy: tmhip_set_gauge has to follow.
+    if (value < 0 || value > 3) TMHIP_FAIL("gauge_mem must be 0 (default), 1 (uncached), 2 (fine-grained) or 3 (contiguous)");
+    TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    TMHIP_CHECK(hipFree(ctx->gauge));
+    ctx->gauge = nullptr; ctx->gauge_set = false;
+    const size_t bytes = (size_t)2 * 72 * ctx->gs * sizeof(v2d);
+    if (value == 0) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge, bytes));
+    else TMHIP_CHECK(hipExtMallocWithFlags((void **)&ctx->gauge, bytes, value == 1 ? hipDeviceMallocUncached : (value == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocContiguous)));
+  }
+  else if (!strcmp(name, "lds32")) { if (value < 0 || value > 1) TMHIP_FAIL("lds32 must be 0 or 1"); ctx->opt_stg32 = value; }
+  else if (!strcmp(name, "lds")) { if (value < 0 || value > 1) TMHIP_FAIL("lds must be 0 (gather kernel) or 1 (per-wave LDS staging of the own-site spinors)"); ctx->opt_stg = value; }
   else if (!strcmp(name, "shape")) { if (value < 0 || value > 16) TMHIP_FAIL("shape must be in [0, 16] x-planes per block"); ctx->opt_shape = value; }
   else if (!strcmp(name, "cg_sync")) ctx->opt_cg_sync = value;
   else if (!strcmp(name, "cg_batch")) ctx->opt_cg_batch = value > 0 ? value : 1;

@@ -21,22 +21,21 @@
 
 namespace hop64 {
 TMHIP_SCALAR_COMPLEX_OPS(v2d, double)
+TMHIP_SPINOR_IO_PLANES
 #define HOP_SITES 1
 #define HOP_CTX_GAUGE(ctx) ((ctx)->gauge)
 #define HOP_CTX_GAUGE_READY(ctx) ((ctx)->gauge_set)
 #define HOP_CTX_OCC(ctx) ((ctx)->opt_occ)
+#define HOP_CTX_STG(ctx) ((ctx)->opt_stg)
 #include "hopping_impl.inc"
 #undef HOP_CTX_OCC
+#undef HOP_CTX_STG
 #undef HOP_CTX_GAUGE
 #undef HOP_CTX_GAUGE_READY
 #undef HOP_SITES
 }  // namespace hop64
 
 TMHIP_DECLARE_HOP32(hop32)
-TMHIP_DECLARE_HOP32(hop32p)
-
-// the two-site fp32 variant needs whole site pairs inside one z-row: LZ/2 even
-static inline bool fp32_pairs(const tmhip_ctx *ctx) { return ctx->opt_fp32_pairs && ((ctx->g.LZ / 2) % 2 == 0); }
 
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
                          double cre, double cim, int comm, const v2d *cw) {
@@ -48,17 +47,15 @@ int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, c
 }
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
                            double cre, double cim, int comm, const v2f *cw) {
-  if (fp32_pairs(ctx)) return hop32p::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
   return hop32::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
 }
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
                                double cre, double cim, int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw, int chained) {
-  if (fp32_pairs(ctx)) return hop32p::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
   return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
 }
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx) {
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
-  const int sites = fp32_pairs(ctx) ? 2 : 1;
+  const int sites = 1;
   const int spb = (split ? 256 : tmhip_hop_block(ctx)) * sites;
   return ctx->Vh % spb == 0 && (!split || (ctx->face % (256 * sites) == 0 && ctx->g.T >= 3));
 }
@@ -99,7 +96,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipEventRecord(c->ev_comm, c->comm_stream));
     hop64::HopArgs a;
     hop64::fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr};
+    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr, c->opt_stg};
     hop64::launch_interior(c, a, EPI_STORE, o);
   }
   for (int r = 0; r < n; r++) {
@@ -108,7 +105,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     hop64::HopArgs a;
     hop64::fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr};
+    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr, c->opt_stg};
     hop64::launch_boundary(c, a, EPI_STORE, o, c->stream);
     TMHIP_CHECK(hipGetLastError());
   }

@@ -12,11 +12,35 @@ typedef int v4i __attribute__((ext_vector_type(4)));
   typedef RTYPE RT;                                                                                              \
   template <bool NT> __device__ __forceinline__ V2T ldc(const ET *p) { if (NT) return __builtin_nontemporal_load(p); return *p; } \
   template <bool NT> __device__ __forceinline__ void stc(ET *p, V2T v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; } \
-  __device__ __forceinline__ V2T ldc2(const ET *p0, const ET *) { return *p0; }                                  \
   __device__ __forceinline__ V2T czero() { return V2T{0, 0}; }                                                   \
   __device__ __forceinline__ V2T cbcast(double re, double im) { return V2T{(RT)re, (RT)im}; }                    \
   __device__ __forceinline__ double cdotd(V2T w, V2T r) { return (double)w.x * (double)r.x + (double)w.y * (double)r.y; }
 
+
+// Spinor-field access of the stencil kernels, one plane per component: field f = [12][stride] complex values (faces: [6][stride]).
+// ld6 / st6 move the six components 6*blk .. 6*blk+5 of site j; the per-wave LDS staging region is [12][64].
+#define TMHIP_SPINOR_IO_PLANES                                                                                                  \
+  template <bool NT> __device__ __forceinline__ void ld6(V2T *s, const ET *f, size_t stride, int j, int blk) {                    \
+    _Pragma("unroll") for (int c = 0; c < 6; c++) s[c] = ldc<NT>(f + (size_t)(6 * blk + c) * stride + j);                         \
+  }                                                                                                                               \
+  template <bool NT> __device__ __forceinline__ void st6(ET *f, size_t stride, int j, int blk, const V2T *s) {                    \
+    _Pragma("unroll") for (int c = 0; c < 6; c++) stc<NT>(f + (size_t)(6 * blk + c) * stride + j, s[c]);                          \
+  }                                                                                                                               \
+  constexpr int HOP_STAGE_BYTES = 12 * 64 * (int)sizeof(V2T); /* per wave */                                                      \
+  __device__ __forceinline__ void stage_put(unsigned char *region, int lid, const ET *f, size_t ns, int i) {                      \
+    V2T *st = reinterpret_cast<V2T *>(region);                                                                                    \
+    _Pragma("unroll") for (int c = 0; c < 12; c++) st[c * 64 + lid] = ldc<false>(f + (size_t)c * ns + i);                         \
+  }                                                                                                                               \
+  __device__ __forceinline__ void stage_get6(V2T *s, const unsigned char *region, int jl, int blk) {                              \
+    const V2T *st = reinterpret_cast<const V2T *>(region);                                                                        \
+    _Pragma("unroll") for (int c = 0; c < 6; c++) s[c] = st[(6 * blk + c) * 64 + jl];                                             \
+  }                                                                                                                             \
+  /* word-wise access for the per-lane choice between the staging region and memory (one word = one component here) */          \
+  constexpr int HOP_SW = 12;                                                                                                      \
+  typedef V2T SWT;                                                                                                                \
+  __device__ __forceinline__ SWT sw_stage(const unsigned char *region, int jl, int w) { return reinterpret_cast<const V2T *>(region)[w * 64 + jl]; } \
+  __device__ __forceinline__ SWT sw_ld(const ET *f, size_t stride, int j, int w) { return ldc<false>(f + (size_t)w * stride + j); } \
+  __device__ __forceinline__ void sw_unpack(V2T *s, int w, SWT v) { s[w] = v; }
 
 // entry points of the fp32 instantiations (defined in hopping32.hip / hopping32p.hip by hopping_impl.inc)
 #define TMHIP_DECLARE_HOP32(NS)                                                                                                \

@@ -15,6 +15,9 @@
 
 typedef double v2d __attribute__((ext_vector_type(2)));  // one complex double: .x = re, .y = im
 typedef float v2f __attribute__((ext_vector_type(2)));   // one complex float (mixed-precision CG)
+// fp32 spinor fields pair their components: [6][ns] of v4f = components (2m, 2m+1) of a site (hopping32.hip); a tmhip_field's
+// d32 pointer keeps the element type v2f (12 * ns of them), the kernels view it as 6 * ns v4f
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define TMHIP_CHECK(expr)                                                                           \
   do {                                                                                              \
@@ -106,7 +109,9 @@ struct tmhip_ctx {
   int mixed_trace[256]; int mixed_trace_n;   // inner iteration count of every outer iteration of the last tmhip_mixed_cg_her
   // options
   int opt_block, opt_xcd, opt_nt, opt_minw, opt_occ, opt_occ32;        // stencil launch shape (tmhip_set_option, include/tmlqcd_hip.h)
-  int opt_tgrp, opt_shape, opt_gaux, opt_gdrop, opt_fp32_pairs;
+  int opt_tgrp, opt_shape, opt_gaux, opt_gdrop;
+  int opt_stg32;                                                        // the same for the fp32 stencil (default 0: measured slower there)
+  int opt_stg;                                                          // 1 = LDS-staged stencil (own-block input spinors staged once, y/z neighbours read from LDS)
   int opt_recon;                                                        // 12 = rebuild the third row of every link in registers (opt-in)
   int opt_flagsync, opt_fusedface, opt_facesplit;                       // split path
   int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot;                      // cg_her
@@ -166,3 +171,4 @@ int tmhip_prepare_clover32(tmhip_ctx *ctx);  // fp32 gauge copy + fp32 scratch /
 #define LA_BS 256
 #define LA_UNROLL 4
 static inline dim3 la_grid(int N) { return dim3((N + LA_BS * LA_UNROLL - 1) / (LA_BS * LA_UNROLL), 12); }
+static inline dim3 la_grid32(int N) { return dim3((N + LA_BS * LA_UNROLL - 1) / (LA_BS * LA_UNROLL), 6); }   // fp32 fields: six float4 planes
