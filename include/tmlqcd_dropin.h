@@ -183,6 +183,17 @@ void tmlqcd_hip_sw_spinor_eo(const int ieo, const spinor *const kk, const spinor
 void tmlqcd_hip_sw_deriv(const int ieo, const double mu);
 void tmlqcd_hip_sw_all(hamiltonian_field_t *const hf, const double kappa, const double c_sw);
 
+/* Molecular-dynamics link update with the links resident in HBM: replaces the call update_gauge(step, hf)
+ * (update_gauge.c:51-110, called from the integrators, integrator.c) -- under its own name because the reference's
+ * update_gauge.o stays on the link line for programs that do not want it.  Coherent mode: hf->gaugefield is current when
+ * the call returns.  Resident mode: the host links stay behind until tmlqcd_hip_sync_gauge_to_host(hf) (call it before
+ * host code reads g_gauge_field: gauge-action force, measurements, I/O).  tmlqcd_hip_update_momenta is update_momenta.c:67-72
+ * for a derivative accumulated on the device only (resident deriv_Sb / tmlqcd_hip_sw_all). */
+void tmlqcd_hip_update_gauge(const double step, hamiltonian_field_t *const hf);
+void tmlqcd_hip_sync_gauge_to_host(hamiltonian_field_t *const hf);
+void tmlqcd_hip_update_momenta(const double step, hamiltonian_field_t *const hf);
+void tmlqcd_hip_sync_momenta_to_host(hamiltonian_field_t *const hf);
+
 /* ---- residency control (additions; not in the reference) ------------------- */
 enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1 };
 /* Device versions of sw_term(g_gauge_field, kappa, c_sw) / sw_invert(ieo, mu) (operator/clover_term.c:88,

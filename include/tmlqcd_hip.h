@@ -226,6 +226,18 @@ int tmhip_mixed_cg_restarts(tmhip_ctx *ctx, int *inner_iters, int cap, int *n_ou
 int tmhip_rg_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_iter, double eps_sq, int rel_prec, int N,
                           int op, double delta, int *iters, int *iter_out, int *iter_in_sp, int *iter_in_dp);
 
+/* ---- molecular-dynamics updates with the links resident in HBM -------------------------------------
+ * tmhip_set_gauge keeps the lexicographic links it received on the device; per MD step the links are then updated in place
+ * (update_gauge.c:51-110: U <- restoresu3(exposu3(step * P)) U), the halo slabs of a T-split rank are refreshed from the
+ * ring neighbours (xchange_gauge) and the stencil's gauge copy is re-sorted (update_backward_gauge.c:185-242) without any
+ * host <-> device copy of the gauge field.  Momenta: su3adj [VOLUME][4] = double [VOLUME][4][8] (hamiltonian_field_t::momenta).
+ * After tmhip_update_gauge the clover blocks are stale: tmhip_sw_term(ctx, NULL, ...) recomputes them from the resident links. */
+int tmhip_momenta_upload(tmhip_ctx *ctx, const void *host_momenta);
+int tmhip_momenta_download(tmhip_ctx *ctx, void *host_momenta);
+int tmhip_update_momenta(tmhip_ctx *ctx, double step);   /* update_momenta.c:67-72 from the device-resident derivative field */
+int tmhip_update_gauge(tmhip_ctx *ctx, double step);     /* update_gauge.c:51-110 */
+int tmhip_gauge_download(tmhip_ctx *ctx, void *host_gauge);   /* [VOLUMEPLUSRAND][4] su3, e.g. at the end of a trajectory */
+
 /* ---- multi-GPU halo exchange (replaces xchange_field / xchange_halffield,
  *      xchange/xchange_field.c:269-470, xchange/xchange_halffield.c:176-263) -- */
 #define TMHIP_UNIQUE_ID_BYTES 128

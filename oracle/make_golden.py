@@ -203,6 +203,26 @@ def gen_mixed(T, L, full):
     print("mixed", tag, scal)
 
 
+def gen_md(T, L):
+    """update_gauge(step, hf) (update_gauge.c:51) of the reference's default build on its RANLUX gauge field with seeded
+    Gaussian momenta: the links after one step."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import numpy as np
+    from oracle.refbind import RefLattice
+    r = RefLattice(T, L, L, L, kappa=0.125, mu=0.01, nfields=8, hs=True)
+    r.random_fields(123456)
+    mom = np.random.default_rng(20260417).standard_normal((r.V, 4, 8))
+    step = 0.0371
+    before = r.gauge().copy()
+    r.lib.tmref_update_gauge.argtypes = [C.c_double, C.c_void_p]
+    r.lib.tmref_update_gauge(step, mom.ctypes.data_as(C.c_void_p))
+    after = r.gauge().copy()
+    assert np.abs(after - before).max() > 1e-3
+    np.savez_compressed(os.path.join(GOLD, "ref_md_%dx%d.npz" % (T, L)), momenta=mom, step=np.float64(step), gauge_after=after)
+    print("md %dx%d: max link change %.3e" % (T, L, np.abs(after - before).max()))
+
+
 def gen_hs(T, L):
     """Default (half-spinor) build of the reference: fp64 cross-check + fp32 twins of the mixed-precision CG."""
     sys.path.insert(0, ROOT)
@@ -236,6 +256,8 @@ if __name__ == "__main__":
         gen_rg(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "rgfull")
     elif len(sys.argv) == 4 and sys.argv[3] in ("mixed", "mixedfull"):
         gen_mixed(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "mixedfull")
+    elif len(sys.argv) == 4 and sys.argv[3] == "md":
+        gen_md(int(sys.argv[1]), int(sys.argv[2]))
     elif len(sys.argv) == 4 and sys.argv[3] == "force":
         gen_force(int(sys.argv[1]), int(sys.argv[2]))
     elif len(sys.argv) == 4 and sys.argv[3] == "sym":
@@ -251,6 +273,7 @@ if __name__ == "__main__":
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "force"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "rgfull"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "8", "8", "rg"])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "md"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "4", "4", "mixedfull"])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "8", "8", "mixed"])
         for T, L, full in ((4, 4, 1), (8, 8, 0), (6, 4, 0)):

@@ -55,6 +55,8 @@ def _lib():
         lib.tmo_sw_spinor_eo.argtypes = [vp, i, vp, vp, vp, vp, d]
         lib.tmo_sw_deriv.argtypes = [vp, i, vp, vp, d]
         lib.tmo_sw_all.argtypes = [vp, vp, vp, vp, d, d]
+        lib.tmo_update_gauge.argtypes = [vp, vp, i, d]
+        lib.tmo_update_momenta.argtypes = [vp, vp, i, d]
         lib.tmo_sw_invert.argtypes = [vp, vp, vp, i, d]
         lib.tmo_sw_invert.restype = i
         lib.tmo_clover_inv.argtypes = [vp, vp, i, d]
@@ -178,6 +180,13 @@ class Oracle:
     def sw_all(self, df, swm, swp, kappa, c_sw):
         assert df.shape == (self.VPR, 4, 8) and df.flags.c_contiguous
         self.lib.tmo_sw_all(self.h, _p(df), _p(swm), _p(swp), kappa, c_sw)
+
+    def update_gauge(self, gauge, mom, step):
+        """update_gauge.c:51-110 in place on gauge [V][4][3][3][2] with momenta [V][4][8] (both host arrays; V from the momenta)."""
+        self.lib.tmo_update_gauge(_p(gauge), _p(mom), mom.shape[0], step)
+
+    def update_momenta(self, mom, deriv, step):
+        self.lib.tmo_update_momenta(_p(mom), _p(deriv), mom.shape[0], step)
 
     def sw_term(self, kappa, c_sw):
         """operator/clover_term.c:88 on the current gauge field -> sw [V][3][2][3][3][2]."""

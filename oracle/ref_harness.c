@@ -99,6 +99,18 @@ int tmref_init(int T_, int LX_, int LY_, int LZ_, double kappa, double mu,
 }
 
 #ifdef _USE_HALFSPINOR
+/* update_gauge(step, hf) (update_gauge.c:51) on g_gauge_field with the momenta handed in as su3adj [VOLUME][4]; only in this
+ * build because the function ends by converting the links into g_gauge_field_32 */
+#include "hamiltonian_field.h"
+#include "update_gauge.h"
+void tmref_update_gauge(double step, su3adj *mom) {
+  hamiltonian_field_t hf;
+  su3adj **mp = malloc((size_t)VOLUMEPLUSRAND * sizeof(su3adj *));
+  for (int i = 0; i < VOLUMEPLUSRAND; i++) mp[i] = mom + 4 * (size_t)i;
+  hf.gaugefield = g_gauge_field; hf.momenta = mp; hf.derivative = NULL; hf.update_gauge_copy = 0; hf.traj_counter = 0;
+  update_gauge(step, &hf);
+  free(mp);
+}
 /* invert.c:299 */
 void tmref_convert_gauge_32(void) { convert_32_gauge_field(g_gauge_field_32, g_gauge_field, VOLUMEPLUSRAND); g_update_gauge_copy_32 = 1; }
 

@@ -1205,3 +1205,80 @@ int tmo_cg_her(tmo_lattice *lat, tmo_spinor *P, tmo_spinor *Q, int max_iter, dou
   if (iteration > max_iter) return -1;
   return iteration;
 }
+
+/* ---------------------------------------------------------------- molecular-dynamics link update (update_gauge.c:51-110)
+ * gauge: g_gauge_field as [V][4] su3 (lexicographic), mom: hf->momenta as [V][4][8] doubles (su3adj d1..d8).
+ * Per link: deriv = step * momentum (su3adj.h:237-245), w = exposu3(deriv) (expo.c:56-97: Cayley-Hamilton recursion, 13
+ * steps), v = restoresu3(w) (expo.c:118-137), U <- v U (su3.h:583-592).  Every expression is written in the order of
+ * the reference so that the result is bit-for-bit the reference's (tests/test_oracle_vs_ref.py). */
+static void tmo_exposu3(tmo_su3 *vr, const double *p /* d1..d8 */) {
+  tmo_su3 v, v2;
+  double fac, r, a, b;
+  double _Complex a0, a1, a2, a1p;
+  const double d1 = p[0], d2 = p[1], d3 = p[2], d4 = p[3], d5 = p[4], d6 = p[5], d7 = p[6], d8 = p[7];
+  /* _make_su3, su3adj.h:45-54 */
+  v.c00 = 0.0 + (0.5773502691896258 * d8 + d3) * I;
+  v.c01 = d2 + d1 * I;
+  v.c02 = d5 + d4 * I;
+  v.c10 = -d2 + d1 * I;
+  v.c11 = 0.0 + (0.5773502691896258 * d8 - d3) * I;
+  v.c12 = d7 + d6 * I;
+  v.c20 = -d5 + d4 * I;
+  v.c21 = -d7 + d6 * I;
+  v.c22 = 0.0 - (1.154700538379252 * d8) * I;
+  m33_mul(&v2, &v, 0, &v, 0, 0);                                               /* expo.c:66 */
+  a = 0.5 * (creal(v2.c00) + creal(v2.c11) + creal(v2.c22));                   /* :68 */
+  b = 0.33333333333333333 * cimag(v.c00 * v2.c00 + v.c01 * v2.c10 + v.c02 * v2.c20 +
+                                  v.c10 * v2.c01 + v.c11 * v2.c11 + v.c12 * v2.c21 +
+                                  v.c20 * v2.c02 + v.c21 * v2.c12 + v.c22 * v2.c22);   /* :70-72 */
+  a0 = 0.16059043836821615e-9;
+  a1 = 0.11470745597729725e-10;
+  a2 = 0.76471637318198165e-12;
+  fac = 0.20876756987868099e-8;
+  r = 12.0;
+  for (int i = 3; i <= 15; ++i) {                                              /* :78-86 */
+    a1p = a0 + a * a2;
+    a0 = fac + b * I * a2;
+    a2 = a1;
+    a1 = a1p;
+    fac *= r;
+    r -= 1.0;
+  }
+  vr->c00 = a0 + a1 * v.c00 + a2 * v2.c00;                                     /* :88-96 */
+  vr->c01 = a1 * v.c01 + a2 * v2.c01;
+  vr->c02 = a1 * v.c02 + a2 * v2.c02;
+  vr->c10 = a1 * v.c10 + a2 * v2.c10;
+  vr->c11 = a0 + a1 * v.c11 + a2 * v2.c11;
+  vr->c12 = a1 * v.c12 + a2 * v2.c12;
+  vr->c20 = a1 * v.c20 + a2 * v2.c20;
+  vr->c21 = a1 * v.c21 + a2 * v2.c21;
+  vr->c22 = a0 + a1 * v.c22 + a2 * v2.c22;
+}
+static void tmo_restoresu3(tmo_su3 *vr, const tmo_su3 *u) {                    /* expo.c:118-137 */
+  const double n0 = 1.0 / sqrt(conj(u->c00) * u->c00 + conj(u->c01) * u->c01 + conj(u->c02) * u->c02);
+  const double n1 = 1.0 / sqrt(conj(u->c10) * u->c10 + conj(u->c11) * u->c11 + conj(u->c12) * u->c12);
+  vr->c00 = n0 * u->c00; vr->c01 = n0 * u->c01; vr->c02 = n0 * u->c02;
+  vr->c10 = n1 * u->c10; vr->c11 = n1 * u->c11; vr->c12 = n1 * u->c12;
+  vr->c20 = conj(vr->c01 * vr->c12 - vr->c02 * vr->c11);
+  vr->c21 = conj(vr->c02 * vr->c10 - vr->c00 * vr->c12);
+  vr->c22 = conj(vr->c00 * vr->c11 - vr->c01 * vr->c10);
+}
+void tmo_update_gauge(tmo_su3 *gauge, const double *mom, int V, double step) {
+#pragma omp parallel for
+  for (int i = 0; i < V; i++)
+    for (int mu = 0; mu < 4; mu++) {
+      double deriv[8];
+      tmo_su3 v, w, *z = gauge + (size_t)4 * i + mu;
+      for (int k = 0; k < 8; k++) deriv[k] = step * mom[((size_t)4 * i + mu) * 8 + k];   /* update_gauge.c:85 */
+      tmo_exposu3(&w, deriv);                                                          /* :86 */
+      tmo_restoresu3(&v, &w);                                                          /* :87 */
+      m33_mul(&w, &v, 0, z, 0, 0);                                                     /* :88 */
+      *z = w;                                                                          /* :89 */
+    }
+}
+/* update_momenta.c:67-72: momenta -= step * derivative, both su3adj [V][4][8] */
+void tmo_update_momenta(double *mom, const double *deriv, int V, double step) {
+#pragma omp parallel for
+  for (int i = 0; i < V; i++)
+    for (int k = 0; k < 32; k++) mom[(size_t)32 * i + k] -= step * deriv[(size_t)32 * i + k];
+}

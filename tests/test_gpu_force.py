@@ -303,3 +303,129 @@ def test_clover_force_through_the_drop_in(host_stub):
     orc.sw_all(ref, swm, swp, kappa, c_sw)
     assert rel_err(df_host, ref[:V]) < 4 * TOL
     d.tmlqcd_hip_finalize()
+
+
+def test_update_gauge_and_momenta_on_the_device_against_reference_fixture():
+    """update_gauge.c:51-110 with the links resident in HBM: fixture = the reference's own update_gauge (+ exposu3 / restoresu3,
+    expo.c) run on the RANLUX gauge field of ref_fields_4x4.npz with seeded Gaussian momenta (oracle/make_golden.py md);
+    the oracle restatement is bit-exact against it (tests/test_oracle_vs_ref.py), the GPU within fp64 tolerance.  Then the
+    stencil must see the new links (gauge copy re-sorted on the device), and update_momenta must match update_momenta.c:67-72."""
+    import os
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    f = np.load(os.path.join(gold, "ref_fields_4x4.npz"))
+    m = np.load(os.path.join(gold, "ref_md_4x4.npz"))
+    g0, mom, step = np.ascontiguousarray(f["gauge"]), np.ascontiguousarray(m["momenta"]), float(m["step"])
+    lat = Lattice(4, 4, 4, 4, kappa=0.125, mu=0.01)
+    orc = Oracle(4, 4, 4, 4, kappa=0.125, mu=0.01)
+    lat.set_gauge(g0)
+    lat.momenta_upload(mom)
+    lat.update_gauge(step)
+    g1 = lat.gauge_download()
+    assert rel_err(g1, m["gauge_after"]) < TOL
+    og = g0.copy(); orc.update_gauge(og, mom, step)
+    assert np.array_equal(og, m["gauge_after"])                                   # (CPU) restatement == reference, bit for bit
+    # the stencil works on the updated links without a new upload
+    orc.set_gauge(m["gauge_after"])
+    k = np.ascontiguousarray(f["in"])
+    ref = orc.new_field(); orc.Hopping_Matrix(0, ref, k)
+    dk, dl = lat.field(k), lat.field()
+    lat.Hopping_Matrix(0, dl, dk)
+    assert rel_err(dl.download(), ref[:lat.Vh]) < TOL
+    # a second step, links still unitary
+    lat.update_gauge(step)
+    orc.update_gauge(og, mom, step)
+    g2 = lat.gauge_download()
+    assert rel_err(g2, og) < TOL
+    u = g2[..., 0] + 1j * g2[..., 1]
+    assert np.abs(np.einsum("nmij,nmkj->nmik", u, u.conj()) - np.eye(3)).max() < 1e-14
+    # momenta: P -= step * derivative with the derivative accumulated on the device by deriv_Sb
+    l = np.ascontiguousarray(f["Heo"])
+    dl2 = lat.field(l)
+    lat.derivative_zero()
+    lat.deriv_Sb(0, dl2, dk, 0.7)
+    df = lat.derivative()
+    lat.update_momenta(0.05)
+    mom2 = lat.momenta_download()
+    exp = mom.copy(); orc.update_momenta(exp, df, 0.05)
+    assert rel_err(mom2, exp) < TOL
+    lat.close()
+
+
+def test_update_gauge_at_scale_keeps_the_links_unitary_and_the_clover_term_follows():
+    """16^4: the device update against the oracle, and sw_term recomputed from the RESIDENT links (gauge = None)."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T = L = 16
+    lat = Lattice(T, L, L, L, kappa=0.13, mu=0.02)
+    orc = Oracle(T, L, L, L, kappa=0.13, mu=0.02, threads=8)
+    g = syn.gauge_field(95, T, L, L, L)
+    mom = np.random.default_rng(96).standard_normal((lat.V, 4, 8))
+    lat.set_gauge(g); lat.momenta_upload(mom)
+    for _ in range(3):
+        lat.update_gauge(0.02); orc.update_gauge(g, mom, 0.02)
+    assert rel_err(lat.gauge_download(), g) < TOL
+    orc.set_gauge(g)
+    lat.sw_term(None, 0.13, 1.7)
+    sw_dev, _ = lat.get_clover(True, False)
+    assert rel_err(sw_dev, orc.sw_term(0.13, 1.7)) < TOL
+    lat.close()
+
+
+def test_update_gauge_drop_in_keeps_the_links_in_hbm(host_stub):
+    """tmlqcd_hip_update_gauge(step, hf): coherent mode = the reference's update_gauge as the host sees it (links updated in
+    hf->gaugefield, flags raised) with no second upload; resident mode = the host links stay behind until
+    tmlqcd_hip_sync_gauge_to_host, while the stencil already works on the new ones."""
+    from oracle.oraclebind import Oracle
+    stub, d = host_stub
+    VP = C.c_void_p
+    T, L = 4, 6
+    kappa, mu = 0.127, 0.01
+    V = T * L ** 3
+    N = V // 2
+    gptr = stub.stub_init(T, L, L, L)
+    g = random_gauge(195, V)
+    C.memmove(gptr, g.ctypes.data_as(VP), g.nbytes)
+    stub.stub_boundary(kappa, 1.0, 0.0, 0.0, 0.0)
+    stub.stub_set_mu(mu)
+    orc = Oracle(T, L, L, L, kappa=kappa, mu=mu, theta=(1.0, 0.0, 0.0, 0.0), threads=4)
+    host_links = np.frombuffer((C.c_double * (V * 72)).from_address(gptr), dtype=np.float64).reshape(V, 4, 3, 3, 2)
+
+    class HF(C.Structure):        # hamiltonian_field.h:26-32
+        _fields_ = [("gaugefield", VP), ("momenta", VP), ("derivative", VP), ("update_gauge_copy", C.c_int), ("traj_counter", C.c_int)]
+    mom = np.random.default_rng(196).standard_normal((V, 4, 8))
+    grows = (VP * V)(*[gptr + 4 * 144 * i for i in range(V)])                       # su3 **gaugefield
+    mrows = (VP * V)(*[mom.ctypes.data + 4 * 8 * 8 * i for i in range(V)])          # su3adj **momenta
+    hf = HF(C.cast(grows, VP), C.cast(mrows, VP), None, 0, 0)
+    for f in ("tmlqcd_hip_update_gauge",):
+        getattr(d, f).argtypes = [C.c_double, C.POINTER(HF)]; getattr(d, f).restype = None
+    d.tmlqcd_hip_sync_gauge_to_host.argtypes = [C.POINTER(HF)]
+    d.tmlqcd_hip_set_residency.argtypes = [C.c_int]
+    d.Hopping_Matrix.argtypes = [C.c_int, VP, VP]
+    k = random_spinor(197, N); l = np.zeros_like(k)
+
+    def check_stencil(links):
+        orc.set_gauge(links)
+        ref = orc.new_field(); orc.Hopping_Matrix(0, ref, k)
+        d.Hopping_Matrix(0, l.ctypes.data_as(VP), k.ctypes.data_as(VP))
+        assert rel_err(l, ref[:N]) < TOL
+    want = g.copy()
+    # coherent mode
+    d.tmlqcd_hip_update_gauge(0.03, C.byref(hf))
+    orc.update_gauge(want, mom, 0.03)
+    assert rel_err(host_links, want) < TOL and hf.update_gauge_copy == 1 and stub.stub_gauge_flag() == 1
+    check_stencil(want)
+    assert stub.stub_gauge_flag() == 0                                              # consumed by the stencil call, like Hopping_Matrix.c:135-139
+    # resident mode: two steps without the host seeing anything
+    d.tmlqcd_hip_set_residency(1)
+    before = host_links.copy()
+    d.tmlqcd_hip_update_gauge(0.03, C.byref(hf)); d.tmlqcd_hip_update_gauge(-0.01, C.byref(hf))
+    orc.update_gauge(want, mom, 0.03); orc.update_gauge(want, mom, -0.01)
+    assert np.array_equal(host_links, before)
+    d.tmlqcd_hip_set_residency(0)
+    check_stencil(want)                                                             # the device is ahead of the host
+    d.tmlqcd_hip_sync_gauge_to_host(C.byref(hf))
+    assert rel_err(host_links, want) < TOL
+    d.tmlqcd_hip_finalize()

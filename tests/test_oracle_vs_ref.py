@@ -131,3 +131,43 @@ def test_oracle_matches_reference_bit_for_bit(dims):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+MD_CHILD = r'''
+import sys, ctypes as C
+sys.path.insert(0, %(root)r)
+import numpy as np
+from oracle.refbind import RefLattice
+from oracle.oraclebind import Oracle
+T, LX, LY, LZ = %(dims)s
+r = RefLattice(T, LX, LY, LZ, kappa=0.125, mu=0.01, nfields=8, hs=True)
+r.random_fields(991)
+o = Oracle(T, LX, LY, LZ)
+mom = np.random.default_rng(5).standard_normal((r.V, 4, 8)) * 3.0      # large momenta: the 13-step recursion far from the identity
+g = r.gauge().copy()
+r.lib.tmref_update_gauge.argtypes = [C.c_double, C.c_void_p]
+for step in (0.0371, -0.2):
+    r.lib.tmref_update_gauge(step, mom.ctypes.data_as(C.c_void_p))
+    o.update_gauge(g, mom, step)
+    assert np.array_equal(g, r.gauge()), "update_gauge step %%g" %% step
+print("OK")
+'''
+
+
+@pytest.mark.skipif(not refbind.ref_available(hs=True), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("dims", [(4, 4, 4, 4), (4, 6, 4, 8)])
+def test_oracle_update_gauge_matches_reference_bit_for_bit(dims):
+    """update_gauge.c:51-110 + expo.c (exposu3, restoresu3), compiled in place into oracle/_ref/libtmref_hs.so, vs tmo_update_gauge."""
+    r = subprocess.run([sys.executable, "-c", MD_CHILD % {"root": ROOT, "dims": repr(dims)}], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout
+
+
+def test_oracle_update_gauge_reproduces_the_committed_fixture():
+    import numpy as np
+    from oracle.oraclebind import Oracle
+    gold = os.path.join(ROOT, "tests", "golden")
+    f, m = np.load(os.path.join(gold, "ref_fields_4x4.npz")), np.load(os.path.join(gold, "ref_md_4x4.npz"))
+    g = np.ascontiguousarray(f["gauge"]).copy()
+    Oracle(4, 4, 4, 4).update_gauge(g, np.ascontiguousarray(m["momenta"]), float(m["step"]))
+    assert np.array_equal(g, m["gauge_after"])

@@ -561,7 +561,7 @@ static int clover_alloc(tmhip_ctx *ctx) {
 /* operator/clover_term.c:88 sw_term(gf, kappa, c_sw): gf is the host gauge field exactly as for tmhip_set_gauge
  * ([VOLUMEPLUSRAND][4] su3, halo slabs filled on T-split ranks).  Result stays in HBM (fetch with tmhip_get_clover). */
 int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_sw) {
-  if (!gauge_host) TMHIP_FAIL("tmhip_sw_term: null gauge field");
+  if (!gauge_host && !(ctx->gauge_raw && ctx->gauge_raw_valid)) TMHIP_FAIL("tmhip_sw_term: null gauge field and no links resident on the device");
   TMHIP_CHECK(hipSetDevice(ctx->device));
   if (clover_alloc(ctx)) return 1;
   const size_t gbytes = (size_t)ctx->VPR * 4 * 9 * sizeof(v2d), fbytes = (size_t)6 * 9 * ctx->V * sizeof(v2d);
@@ -569,7 +569,7 @@ int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c
   if (!ctx->gauge_raw) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge_raw, gbytes));   // kept: the clover force (tmhip_sw_all) walks the same links
   void *raw = ctx->gauge_raw;
   TMHIP_CHECK(hipMalloc(&F, fbytes));
-  TMHIP_CHECK(hipMemcpyAsync(raw, gauge_host, gbytes, hipMemcpyHostToDevice, ctx->stream));
+  if (gauge_host) TMHIP_CHECK(hipMemcpyAsync(raw, gauge_host, gbytes, hipMemcpyHostToDevice, ctx->stream));   // NULL: the links tmhip_set_gauge / tmhip_update_gauge left in HBM
   LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, ctx->g.nproc_t > 1 ? 1 : 0};
   hipLaunchKernelGGL(sw_leaf_kernel, dim3((ctx->V + 127) / 128, 6), dim3(128), 0, ctx->stream, (const v2d *)raw, (v2d *)F, g);
   hipLaunchKernelGGL(sw_assemble_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (const v2d *)F, ctx->sw, ctx->gs, ctx->Vh,

@@ -112,6 +112,19 @@ int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes) {
   return 0;
 }
 
+// the stencil's gauge copy (and everything derived from the links) from the device-resident lexicographic field
+int tmhip_resort_gauge(tmhip_ctx *ctx) {
+  if (!ctx->gauge_raw || !ctx->gauge_raw_valid) TMHIP_FAIL("no lexicographic gauge field on the device");
+  const int toff = ctx->g.proc_t * ctx->g.T;
+  hipLaunchKernelGGL(gauge_sort_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (const v2d *)ctx->gauge_raw, ctx->gauge,
+                     ctx->gs, ctx->Vh, ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, toff, ctx->g.nproc_t > 1 ? 1 : 0);
+  TMHIP_CHECK(hipGetLastError());
+  ctx->gauge_set = true;
+  ctx->gauge32_set = false;       // the fp32 twin is rebuilt lazily from the new links
+  ctx->gauge_recon_dev = -1.0;
+  return 0;
+}
+
 int tmhip_field_alloc_prec(tmhip_ctx *ctx, int kind, int prec, tmhip_field **out) {
   tmhip_field *f = new (std::nothrow) tmhip_field();
   if (!f) TMHIP_FAIL("out of host memory");
@@ -226,6 +239,7 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->swpm) (void)hipFree(ctx->swpm);
   if (ctx->gauge_raw) (void)hipFree(ctx->gauge_raw);
   if (ctx->deriv) (void)hipFree(ctx->deriv);
+  if (ctx->momenta) (void)hipFree(ctx->momenta);
   if (ctx->force_send) (void)hipFree(ctx->force_send);
   if (ctx->force_recv) (void)hipFree(ctx->force_recv);
   if (ctx->deriv_halo) (void)hipFree(ctx->deriv_halo);
@@ -327,20 +341,13 @@ int tmhip_set_gauge(tmhip_ctx *ctx, const void *host) {
   if (!host) TMHIP_FAIL("tmhip_set_gauge: null gauge field");
   TMHIP_CHECK(hipSetDevice(ctx->device));
   const size_t bytes = (size_t)ctx->VPR * 4 * 9 * sizeof(v2d);
-  // the raw copy is only needed during the re-sort: use a temporary, not the persistent staging buffer
-  void *raw = nullptr;
-  TMHIP_CHECK(hipMalloc(&raw, bytes));
-  TMHIP_CHECK(hipMemcpyAsync(raw, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-  const int toff = ctx->g.proc_t * ctx->g.T;
-  hipLaunchKernelGGL(gauge_sort_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (const v2d *)raw, ctx->gauge,
-                     ctx->gs, ctx->Vh, ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, toff, ctx->g.nproc_t > 1 ? 1 : 0);
-  TMHIP_CHECK(hipGetLastError());
+  // The lexicographic links stay on the device (604 MB at 32^4 of 288 GB): the clover term and force walk them (clover.hip) and
+  // the molecular-dynamics update works on them in place (md_update.hip), so a trajectory needs this upload once.
+  if (!ctx->gauge_raw) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge_raw, bytes));
+  TMHIP_CHECK(hipMemcpyAsync(ctx->gauge_raw, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ctx->gauge_raw_valid = true;
+  if (tmhip_resort_gauge(ctx)) return 1;
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
-  TMHIP_CHECK(hipFree(raw));
-  ctx->gauge_set = true;
-  ctx->gauge32_set = false;  // the fp32 twin is rebuilt lazily from the new links
-  ctx->gauge_recon_dev = -1.0;
-  ctx->gauge_raw_valid = false;   // tmhip_sw_all must not combine new links in the stencil with old ones in its leaves
   if (ctx->opt_recon == 12) return tmhip_check_gauge_recon(ctx);
   return 0;
 }

@@ -58,6 +58,9 @@ int g_mode = TMLQCD_HIP_COHERENT;
 int g_dims[6] = {0, 0, 0, 0, 0, 0};
 std::unordered_map<const void *, Mirror> g_reg;
 bool g_gauge_uploaded = false;   // the current context holds a gauge copy
+bool g_dev_links_current = false; // tmlqcd_hip_update_gauge has just brought host and device links to the same state (coherent mode): the next refresh skips the upload
+bool g_dev_links_newer = false;   // resident mode: the device links are ahead of g_gauge_field until tmlqcd_hip_sync_gauge_to_host
+bool g_momenta_resident = false;  // the momenta live on the device (tmlqcd_hip_update_momenta), not re-uploaded by tmlqcd_hip_update_gauge
 bool g_clover_uploaded = false;
 tmhip_field *g_full_tmp = nullptr; // FULL-lattice scratch of Q_pm_psi / D_dagg_psi (tm_operators.c:380-397)
 
@@ -97,7 +100,11 @@ tmhip_ctx *refresh(bool need_gauge) {
   if (need_gauge && (g_update_gauge_copy || !g_gauge_uploaded)) {   /* Hopping_Matrix.c:135-139 */
     if (update_backward_gauge) update_backward_gauge(g_gauge_field);  // host copy + flag, as the reference
     else g_update_gauge_copy = 0;
-    CK(tmhip_set_gauge(c, &g_gauge_field[0][0]));
+    if (!g_dev_links_current) {                                       // (else: the device already holds exactly these links)
+      CK(tmhip_set_gauge(c, &g_gauge_field[0][0]));
+      g_dev_links_newer = false;                                      // the host's links are the truth again
+    }
+    g_dev_links_current = false;
     g_gauge_uploaded = true;
   }
   return c;
@@ -241,6 +248,7 @@ void tmlqcd_hip_finalize(void) {
   g_ctx = nullptr;
   g_gauge_uploaded = false;
   g_clover_uploaded = false;
+  g_dev_links_current = g_dev_links_newer = g_momenta_resident = false;
 }
 
 // ------------------------------------------------------------------ stencil
@@ -906,6 +914,50 @@ void tmlqcd_hip_flush_derivative(hamiltonian_field_t *const hf) {
   if (!g_deriv_pending) return;
   CK(tmhip_derivative_download(ctx(), &hf->derivative[0][0], 1));
   g_deriv_pending = false;
+}
+
+// ------------------------------------------------------------------ molecular dynamics with the links in HBM
+/* update_gauge(step, hf) (update_gauge.c:51-110): U <- restoresu3(exposu3(step P)) U for every link, on the device-resident
+ * links; the stencil's gauge copy is re-sorted there too (update_backward_gauge.c:185-242), so an MD step moves no gauge
+ * field over PCIe.  Coherent mode: hf->gaugefield receives the new links before the call returns and the reference's flags
+ * are raised (update_gauge.c:104-106) -- the next stencil call refreshes the HOST's backward copy if the program has one, but
+ * does not upload again.  Resident mode: g_gauge_field stays behind until tmlqcd_hip_sync_gauge_to_host.
+ * The clover blocks become stale exactly as in the reference (the monomials call sw_term / sw_invert again). */
+void tmlqcd_hip_update_gauge(const double step, hamiltonian_field_t *const hf) {
+  tmhip_ctx *c = refresh(true);                                   // first call of a trajectory: the host's links go up once
+  if (!g_momenta_resident) CK(tmhip_momenta_upload(c, &hf->momenta[0][0]));
+  CK(tmhip_update_gauge(c, step));
+  g_clover_uploaded = false;
+  if (g_mode == TMLQCD_HIP_COHERENT) {
+    CK(tmhip_gauge_download(c, &hf->gaugefield[0][0]));
+    hf->update_gauge_copy = 1;
+    g_update_gauge_copy = 1;
+    g_dev_links_current = true;
+  } else {
+    g_dev_links_newer = true;
+  }
+}
+void tmlqcd_hip_sync_gauge_to_host(hamiltonian_field_t *const hf) {
+  if (!g_dev_links_newer) return;
+  CK(tmhip_gauge_download(ctx(), &hf->gaugefield[0][0]));
+  hf->update_gauge_copy = 1;
+  g_update_gauge_copy = 1;                                        // host-side consumers of the backward copy refresh it
+  g_dev_links_current = true;
+  g_dev_links_newer = false;
+}
+/* update_momenta.c:67-72 for a force that was accumulated on the device only (deriv_Sb / tmlqcd_hip_sw_all in resident mode,
+ * not flushed): P -= step * derivative with both resident; the momenta then stay on the device until
+ * tmlqcd_hip_sync_momenta_to_host.  Contributions other monomials left in hf->derivative are NOT included. */
+void tmlqcd_hip_update_momenta(const double step, hamiltonian_field_t *const hf) {
+  tmhip_ctx *c = refresh(false);
+  if (!g_momenta_resident) { CK(tmhip_momenta_upload(c, &hf->momenta[0][0])); g_momenta_resident = true; }
+  CK(tmhip_update_momenta(c, step));
+  g_deriv_pending = false;                                        // consumed
+}
+void tmlqcd_hip_sync_momenta_to_host(hamiltonian_field_t *const hf) {
+  if (!g_momenta_resident) return;
+  CK(tmhip_momenta_download(ctx(), &hf->momenta[0][0]));
+  g_momenta_resident = false;
 }
 
 // ------------------------------------------------------------------ benchmark helper

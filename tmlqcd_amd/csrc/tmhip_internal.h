@@ -102,6 +102,7 @@ struct tmhip_ctx {
   unsigned int *sync_flags; unsigned int hop_seq;  // [0] in-ready, [1] boundary-done, [2] timeout error
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
   double *deriv;
+  double *momenta;     // hamiltonian_field_t::momenta, su3adj [V][4] = double [V][4][8], resident for tmhip_update_gauge (md_update.hip)
   double *deriv_halo, *deriv_halo_recv;   // T-split sw_all: [2 slabs (t = T, t = -1)][4 mu][8][LX LY LZ] contributions to the neighbours' links / theirs to ours
   v2d *force_send, *force_recv;   // T-split deriv_Sb: [24][face] t=0 slices of (l, k), ours / the up-neighbour's
   // device-resident CG state (cg.hip)
@@ -166,6 +167,7 @@ int tmhip_field_alloc_prec(tmhip_ctx *ctx, int kind, int prec, tmhip_field **out
 int tmhip_halo_exchange(tmhip_ctx *ctx);
 int tmhip_apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k);
 int tmhip_prepare_fp32(tmhip_ctx *ctx);
+int tmhip_resort_gauge(tmhip_ctx *ctx);   // md_update.hip: stencil gauge copy from the device-resident lexicographic links
 int tmhip_prepare_clover32(tmhip_ctx *ctx);  // fp32 gauge copy + fp32 scratch / solver fields
 // launch geometry shared by linalg.hip and cg.hip
 #define LA_BS 256

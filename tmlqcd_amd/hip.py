@@ -84,6 +84,8 @@ def load_library():
         "tmhip_cg_her": [vp, vp, vp, i, d, i, i, i, C.POINTER(i), pd, i],
         "tmhip_set_clover": [vp, vp, vp],
         "tmhip_sw_term": [vp, vp, d, d],
+        "tmhip_momenta_upload": [vp, vp], "tmhip_momenta_download": [vp, vp], "tmhip_update_momenta": [vp, d],
+        "tmhip_update_gauge": [vp, d], "tmhip_gauge_download": [vp, vp],
         "tmhip_gauge_su3_deviation": [vp, pd],
         "tmhip_derivative_zero": [vp],
         "tmhip_swpm_zero": [vp], "tmhip_sw_spinor_eo": [vp, i, vp, vp, d], "tmhip_sw_deriv": [vp, i, d],
@@ -333,10 +335,33 @@ class Lattice:
         return swm, swp
 
     def sw_term(self, gauge, kappa, c_sw):
-        """operator/clover_term.c:88 on the device; `gauge` as for set_gauge ([VPR][4][3][3][2])."""
-        if gauge.shape != (self.VPR, 4, 3, 3, 2):
+        """operator/clover_term.c:88 on the device; `gauge` as for set_gauge ([VPR][4][3][3][2]), or None = the links resident
+        on the device (after set_gauge / update_gauge)."""
+        if gauge is not None and gauge.shape != (self.VPR, 4, 3, 3, 2):
             raise TmHipError("gauge field must be [%d][4][3][3][2]" % self.VPR)
-        _ck(self.lib.tmhip_sw_term(self.h, _hp(gauge), kappa, c_sw), "tmhip_sw_term")
+        _ck(self.lib.tmhip_sw_term(self.h, _hp(gauge) if gauge is not None else None, kappa, c_sw), "tmhip_sw_term")
+
+    # --- molecular dynamics with the links resident in HBM (update_gauge.c, update_momenta.c) ---------------
+    def momenta_upload(self, mom):
+        if mom.shape != (self.V, 4, 8):
+            raise TmHipError("momenta must be [V=%d][4][8]" % self.V)
+        _ck(self.lib.tmhip_momenta_upload(self.h, _hp(mom)), "tmhip_momenta_upload")
+
+    def momenta_download(self):
+        out = np.zeros((self.V, 4, 8))
+        _ck(self.lib.tmhip_momenta_download(self.h, _hp(out)), "tmhip_momenta_download")
+        return out
+
+    def update_momenta(self, step):
+        _ck(self.lib.tmhip_update_momenta(self.h, step), "update_momenta")
+
+    def update_gauge(self, step):
+        _ck(self.lib.tmhip_update_gauge(self.h, step), "update_gauge")
+
+    def gauge_download(self):
+        out = np.zeros((self.VPR, 4, 3, 3, 2))
+        _ck(self.lib.tmhip_gauge_download(self.h, _hp(out)), "tmhip_gauge_download")
+        return out
 
     def sw_invert(self, ieo, mu):
         """operator/clover_invert.c:170 on the device (needs sw_term or set_clover first)."""
