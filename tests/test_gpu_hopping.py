@@ -39,6 +39,7 @@ def test_hopping_matrix_16(setup16, ieo):
 @pytest.mark.parametrize("block,nt,xcd,minw,occ", [(64, 0, 0, 0, 0), (64, 1, 2, 4, 2), (256, 1, 1, 0, 3), (256, 0, 2, 4, 0), (256, 1, 3, 0, 3), (64, 1, 3, 0, 0)])
 def test_kernel_variants_agree(setup16, block, nt, xcd, minw, occ):
     orc, lat = setup16
+    lat.set_option("hopsplit", 0)          # the one-thread-per-site kernels (the automatic choice at 16^4 is the hop-split kernel)
     N = orc.Vh
     k = random_spinor(9, N)
     ref = orc.new_field()
@@ -51,6 +52,7 @@ def test_kernel_variants_agree(setup16, block, nt, xcd, minw, occ):
     assert rel_err(dl.download(), ref[:N]) < TOL
     for name, val in defaults.items():
         lat.set_option(name, val)
+    lat.set_option("hopsplit", -1)
     dk.free(); dl.free()
 
 
@@ -272,4 +274,44 @@ def test_lds_staged_stencil_matches_the_gather_stencil(dims):
         ref = orc.new_field(); orc.Hopping_Matrix(0, ref, k)
         lat.set_loopback(0); lat.Hopping_Matrix(0, dl, dk)
         assert rel_err(dl.download(), ref[:N]) < TOL
+    lat.close()
+
+
+@pytest.mark.parametrize("dims", [(8, 8, 8, 8), (6, 4, 4, 4), (4, 6, 2, 12), (16, 16, 16, 16), (2, 2, 2, 2)])
+def test_hop_split_kernel_on_small_lattices(dims):
+    """"hopsplit" 1: 64 sites per 256-thread block, wave w does the +-mu hops for mu = w, the partial spinors meet in LDS; every
+    component-wise epilogue and the fused CG iteration (four partials per block), against the oracle and against hopsplit 0."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T, LX, LY, LZ = dims
+    kappa, mu, theta = 0.133, 0.015, (1.0, 0.2, 0.0, -0.3)
+    lat = Lattice(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta)
+    orc = Oracle(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta, threads=4)
+    g = syn.gauge_field(101, T, LX, LY, LZ)
+    lat.set_gauge(g); orc.set_gauge(g)
+    N = lat.Vh
+    k, p = syn.spinor_field_eo(102, 1, T, LX, LY, LZ), syn.spinor_field_eo(103, 0, T, LX, LY, LZ)
+    dk, dp, dl = lat.field(k), lat.field(p), lat.field()
+    c = 0.6 + 0.3j
+    res = {}
+    for hs in (1, 0):
+        lat.set_option("hopsplit", hs)
+        out = []
+        for ieo in (0, 1):
+            ref = orc.new_field()
+            lat.Hopping_Matrix(ieo, dl, dk); orc.Hopping_Matrix(ieo, ref, k); out.append(dl.download())
+            assert rel_err(out[-1], ref[:N]) < TOL, (hs, ieo)
+            lat.tm_times_Hopping_Matrix(ieo, dl, dk, c); orc.tm_times_Hopping_Matrix(ieo, ref, k, c); out.append(dl.download())
+            assert rel_err(out[-1], ref[:N]) < TOL, (hs, ieo)
+            lat.tm_sub_Hopping_Matrix(ieo, dl, dp, dk, c); orc.tm_sub_Hopping_Matrix(ieo, ref, p, k, c); out.append(dl.download())
+            assert rel_err(out[-1], ref[:N]) < TOL, (hs, ieo)
+        dl.zero()
+        it, hist = lat.cg_her(dl, dk, 500, 1e-20, 1, N)
+        res[hs] = (out, it, hist.copy(), dl.download())
+    P = orc.new_field()
+    it_ref, hist_ref = orc.cg_her(P, k.copy(), 500, 1e-20, 1, N)
+    for hs in (1, 0):
+        assert abs(res[hs][1] - it_ref) <= 1, (hs, res[hs][1], it_ref)
+        assert rel_err(res[hs][3], P[:N]) < 1e-9, hs
     lat.close()

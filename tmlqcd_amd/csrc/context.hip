@@ -180,7 +180,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
   ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 2; ctx->opt_fusedface = -1; ctx->opt_gaux = -1;
-  ctx->opt_gdrop = 0; ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_occ32 = 0; ctx->opt_facesplit = 0; ctx->opt_recon = 0;
+  ctx->opt_gdrop = 0; ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_facesplit = 0; ctx->opt_recon = 0;
   ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
@@ -195,7 +195,8 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->max_partials = 12 * ((ctx->ns + 1023) / 1024 + 1);
   {
     // fused stencil+reduction: one per wave of the (padded) grid, plus -- on the split path -- four per 64 face sites of the face kernel
-    const int need = 4 * ((ctx->ns + 255) / 256 + 8 + 7 * ctx->g.T) + 8 * ((ctx->face + 63) / 64 + 1);
+    int need = 4 * ((ctx->ns + 255) / 256 + 8 + 7 * ctx->g.T) + 8 * ((ctx->face + 63) / 64 + 1);
+    if (ctx->ns <= 262144 && need < ctx->ns / 16 + 64) need = ctx->ns / 16 + 64;   // hop-split kernel on small lattices: four partials per 64 sites
     if (ctx->max_partials < need) ctx->max_partials = need;
   }
   TMHIP_CHECK(hipMalloc((void **)&ctx->partials, ctx->max_partials * sizeof(double)));
@@ -328,6 +329,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
     if (value == 0) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge, bytes));
     else TMHIP_CHECK(hipExtMallocWithFlags((void **)&ctx->gauge, bytes, value == 1 ? hipDeviceMallocUncached : (value == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocContiguous)));
   }
+  else if (!strcmp(name, "hopsplit")) { if (value < -1 || value > 1) TMHIP_FAIL("hopsplit must be -1 (automatic), 0 or 1"); ctx->opt_hopsplit = value; }
   else if (!strcmp(name, "lds32")) { if (value < 0 || value > 1) TMHIP_FAIL("lds32 must be 0 or 1"); ctx->opt_stg32 = value; }
   else if (!strcmp(name, "lds")) { if (value < 0 || value > 1) TMHIP_FAIL("lds must be 0 (gather kernel) or 1 (per-wave LDS staging of the own-site spinors)"); ctx->opt_stg = value; }
   else if (!strcmp(name, "shape")) { if (value < 0 || value > 16) TMHIP_FAIL("shape must be in [0, 16] x-planes per block"); ctx->opt_shape = value; }
