@@ -275,6 +275,7 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "cg_fused_dot" 2 (default: alpha / residual / norm in the stencil epilogues), 1 scalar product only, 0 plain linalg kernels
  *   "cg_sync" 1: host-side scalars as in the reference loop;  "cg_batch" n: iterations enqueued between two polls of `done`
  *   "bench_graph" 1: tmhip_bench_hopping captures its loop into one hipGraph and replays it (diagnostic: launch floor on small lattices)
+ *   "swall_atomic" 1: tmhip_sw_all in the scatter form of the reference (fp64 atomics) instead of the owner-computes kernel (A/B only)
  *   "gaux" / "gdrop": diagnostics (gauge links through a buffer descriptor / dropped), profiles/r01_diagnostics.md
  * One option changes what is read from memory:
  * "gauge_recon" = 12 makes the twisted-mass stencil launches (fp64 and fp32) fetch only the first two rows of every link and

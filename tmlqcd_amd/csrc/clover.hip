@@ -492,6 +492,269 @@ __global__ __launch_bounds__(64) void sw_all_kernel(const v2d *__restrict__ raw,
   vv2 = m3_dag(v2); vv1 = m3_mul<false, true>(vv2, v1); vv2 = m3_mul<false, true>(vv1, V);   tl_atomic_add(deriv, halo, g, Vh, p0, x, k, c, vv2);
 }
 
+
+// ------------------------------------------------------------------ sw_all, owner-computes (no atomics)
+// The reference walks (site x, plane kl) and scatters sixteen su3adj contributions (clover_accumulate_deriv.c:100-201, the kernel
+// above with 96 fp64 atomics per thread: 4.3 ms at 32^4).  Turned inside out like deriv_Sb: one thread OWNS the link (y, mu) and
+// collects everything that reaches it.  Every contribution of the reference is a closed plaquette loop that starts with U_mu(y)
+// and carries the insertion matrix W_kl(z) = vis[k][l](z) - h.c. (:73-99) at one of its four corners z -- with +W when the loop runs
+// k -> l -> -k -> -l and W^dagger = -W (W is anti-hermitian bit for bit) the other way round; the transports the reference writes
+// as w^dagger (..) w differ from this form by w w^dagger = 1 + O(eps) only.  A link lies in two plaquettes of each of the three
+// planes (mu, nu), so with  A = U_mu(y), B = U_nu(y+mu), C = U_mu(y+nu), D = U_nu(y)  (upper plaquette) and
+// B' = U_nu(y+mu-nu), C' = U_mu(y-nu), D' = U_nu(y-nu)  (lower one), Yu = B C^+ D^+, Yl = B'^+ C'^+ D':
+//   S_nu = +-[ W(y+mu) (Yu - Yl) + (Yu - Yl) W(y) + B (W(y+mu+nu) C^+ + C^+ W(y+nu)) D^+ - B'^+ (W(y+mu-nu) C'^+ + C'^+ W(y-nu)) D' ]
+//   derivative(y, mu) += c * trace_lambda(A (S_nu1 + S_nu2 + S_nu3))                       (+ for mu < nu, - for mu > nu)
+// 43 3x3 products per link instead of the 66 per link of the scatter form, one read-modify-write of the link's eight
+// doubles, all loads coalesced SoA planes (the stencil's gauge copy, forward entries only; swm / swp as they lie in HBM).
+// On a T-split rank the t = 0 and t = T-1 slices need links and insertion matrices of the ring neighbours: they are done by the
+// same code through the raw lexicographic links (halo slabs included, as for sw_term) and the neighbours' swm / swp slices,
+// exchanged before the launch -- instead of exchanging derivative contributions afterwards.
+// Two passes: sw_insertion_kernel builds the six anti-hermitian insertion matrices of every site once, in a compact form
+// (nine reals in five complex planes: 480 B per site instead of the 2 x 144 B per plane that each of a site's users would load from
+// swm / swp), sw_all_gather_kernel then does the loops.
+struct SwSite { int t, x, y, z; };
+__device__ __forceinline__ SwSite sw_shift(SwSite c, int dir, int d) {
+  c.t += dir == 0 ? d : 0; c.x += dir == 1 ? d : 0; c.y += dir == 2 ? d : 0; c.z += dir == 3 ? d : 0;
+  return c;
+}
+// W = X - X^dagger from the compact planes: (W01, W02, W12, (Im W00, Im W11), (Im W22, -))
+__device__ __forceinline__ M3 sw_expand(v2d w01, v2d w02, v2d w12, v2d d01, v2d d2) {
+  M3 W;
+  W.e[0] = v2d{0.0, d01.x}; W.e[1] = w01; W.e[2] = w02;
+  W.e[3] = v2d{-w01.x, w01.y}; W.e[4] = v2d{0.0, d01.y}; W.e[5] = w12;
+  W.e[6] = v2d{-w02.x, w02.y}; W.e[7] = v2d{-w12.x, w12.y}; W.e[8] = v2d{0.0, d2.x};
+  return W;
+}
+#ifndef SW_FAST_MINB
+#define SW_FAST_MINB 2   /* blocks of three waves per CU the fast kernel is compiled for: 2 <=> at most 256 VGPRs (A/B builds override) */
+#endif
+// interior / unsplit lattices: periodic in every direction, SoA arrays in e/o order
+struct SwFastLd {
+  static constexpr int min_blocks = SW_FAST_MINB;
+  const v2d *__restrict__ G; unsigned gs;     // gauge copy [2][8][9][gs]
+  const v2d *__restrict__ W; unsigned ws;     // insertion matrices [6 planes][5][ws], site = parity * Vh + e/o index
+  int T, LX, LY, LZ, Vh;
+  typedef unsigned Loc;                        // e/o index of the site; its parity is wave-uniform and travels separately (`par`)
+  __device__ __forceinline__ Loc locate(SwSite c) const {
+    const int t = c.t < 0 ? c.t + T : (c.t >= T ? c.t - T : c.t), x = c.x < 0 ? c.x + LX : (c.x >= LX ? c.x - LX : c.x);
+    const int y = c.y < 0 ? c.y + LY : (c.y >= LY ? c.y - LY : c.y), z = c.z < 0 ? c.z + LZ : (c.z >= LZ ? c.z - LZ : c.z);
+    return (unsigned)(((t * LX + x) * LY + y) * LZ + z) >> 1;
+  }
+  // every address = wave-uniform 64-bit base + the lane's 32-bit site index
+  __device__ __forceinline__ M3 link(Loc l, int par, int dir) const {
+    const v2d *base = G + (size_t)(unsigned)((par * 8 + 2 * dir) * 9) * gs;
+    M3 r;
+#pragma unroll
+    for (int e = 0; e < 9; e++) { const v2d *pe = base + (size_t)((unsigned)e * gs); r.e[e] = pe[l]; }
+    return r;
+  }
+  __device__ __forceinline__ M3 ins(Loc l, int par, int P) const {
+    const v2d *base = W + (size_t)(unsigned)(P * 5) * ws + (unsigned)(par * Vh);
+    v2d c[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) { const v2d *pe = base + (size_t)((unsigned)e * ws); c[e] = pe[l]; }
+    return sw_expand(c[0], c[1], c[2], c[3], c[4]);
+  }
+};
+// t-faces of a T-split rank: raw lexicographic links [VPR][4][9] with the t = T / t = -1 halo slabs; the insertion matrices of the
+// halo slabs arrive in `halo` [2 slabs][30][XYZ]
+struct SwEdgeLd {
+  static constexpr int min_blocks = 1;         // (two t-slices only: all 512 registers rather than scratch)
+  const v2d *__restrict__ raw; const v2d *__restrict__ W; unsigned ws; const v2d *__restrict__ halo;
+  LexGeom g; int Vh;
+  struct Loc { int ix; const v2d *w; unsigned wst; };   // lexicographic index (halo slabs behind V); base and plane stride of the site's insertion matrices
+  __device__ __forceinline__ Loc locate(SwSite c) const {
+    const int ix = lex_index(g, c.t, c.x, c.y, c.z), XYZ = g.LX * g.LY * g.LZ;
+    if (ix >= g.V) {
+      const int slab = (ix - g.V) / XYZ, sp = (ix - g.V) - slab * XYZ;
+      return Loc{ix, halo + (size_t)slab * 30 * XYZ + sp, (unsigned)XYZ};
+    }
+    const int x = (c.x + g.LX) % g.LX, y = (c.y + g.LY) % g.LY, z = (c.z + g.LZ) % g.LZ;
+    const int par = (c.t + x + y + z) & 1;      // 0 <= c.t < T here
+    return Loc{ix, W + (size_t)par * Vh + (ix >> 1), ws};
+  }
+  __device__ __forceinline__ M3 link(Loc l, int, int dir) const { return m3_load(raw, l.ix, dir); }
+  __device__ __forceinline__ M3 ins(Loc l, int, int P) const {
+    const v2d *p = l.w + (size_t)(unsigned)(P * 5) * l.wst;
+    v2d c[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) c[e] = p[(size_t)((unsigned)e * l.wst)];
+    return sw_expand(c[0], c[1], c[2], c[3], c[4]);
+  }
+};
+// W_kl(z) of plane P = (01, 02, 03, 12, 13, 23) for every site: clover_accumulate_deriv.c:73-99, the same arithmetic as in sw_all_kernel
+//   P: 0 -i(m1+m3), 1 m1-m3, 2 i(m2-m0), 3 i(p2-p0), 4 p3-p1, 5 -i(p1+p3);  W = X - X^dagger
+// thread = (site s = parity * Vh + e/o index, set blockIdx.y: swm -> planes 0..2, swp -> planes 3..5); [2][4][9][V] -> Wc [6][5][ws].
+// Every matrix of swm / swp is read once (1152 B per site in, 480 B out).
+__device__ __forceinline__ void sw_ins_store(v2d *__restrict__ o, size_t ws, const v2d (&X)[9]) {
+  o[0] = X[1] - m3_conj(X[3]);
+  o[ws] = X[2] - m3_conj(X[6]);
+  o[2 * ws] = X[5] - m3_conj(X[7]);
+  o[3 * ws] = v2d{2.0 * X[0].y, 2.0 * X[4].y};      // (X - X^dagger)_ii = 2 i Im X_ii, exactly
+  o[4 * ws] = v2d{2.0 * X[8].y, 0.0};
+}
+__global__ __launch_bounds__(256) void sw_insertion_kernel(v2d *__restrict__ Wc, const v2d *__restrict__ swpm, int V, unsigned ws) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= V) return;
+  const int set = blockIdx.y;
+  const v2d *p = swpm + (size_t)(set * 36) * V + s;
+  v2d m0[9], m1[9], m2[9], m3[9], X[9];
+#pragma unroll
+  for (int e = 0; e < 9; e++) { m0[e] = p[(size_t)e * V]; m1[e] = p[(size_t)(9 + e) * V]; m2[e] = p[(size_t)(18 + e) * V]; m3[e] = p[(size_t)(27 + e) * V]; }
+  v2d *o = Wc + (size_t)(set * 15) * ws + s;
+  // set 0: planes 01, 02, 03 = -i(m1+m3), m1-m3, i(m2-m0);   set 1: planes 12, 13, 23 = i(p2-p0), p3-p1, -i(p1+p3)
+#pragma unroll
+  for (int e = 0; e < 9; e++) { const v2d sum = m1[e] + m3[e]; X[e] = v2d{sum.y, -sum.x}; }
+  sw_ins_store(o + (size_t)(set ? 10 : 0) * ws, ws, X);
+#pragma unroll
+  for (int e = 0; e < 9; e++) X[e] = set ? m3[e] - m1[e] : m1[e] - m3[e];
+  sw_ins_store(o + (size_t)5 * ws, ws, X);
+#pragma unroll
+  for (int e = 0; e < 9; e++) { const v2d dif = m2[e] - m0[e]; X[e] = v2d{-dif.y, dif.x}; }
+  sw_ins_store(o + (size_t)(set ? 0 : 10) * ws, ws, X);
+}
+__device__ __forceinline__ void m3_sub(M3 &a, const M3 &b) {
+#pragma unroll
+  for (int e = 0; e < 9; e++) a.e[e] -= b.e[e];
+}
+// op(a) op(b) with every complex multiply-add as four fused multiply-adds (m3_mul's mul / fma / add form is 1.5x the instructions)
+template <bool AD, bool BD>
+__device__ __forceinline__ M3 m3_mulf(const M3 &a, const M3 &b) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double re = 0.0, im = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const v2d x = AD ? a.e[3 * k + i] : a.e[3 * i + k], y = BD ? b.e[3 * j + k] : b.e[3 * k + j];
+        const double xi = AD ? -x.y : x.y, yi = BD ? -y.y : y.y;
+        re = __builtin_fma(x.x, y.x, re); re = __builtin_fma(-xi, yi, re);
+        im = __builtin_fma(x.x, yi, im);  im = __builtin_fma(xi, y.x, im);
+      }
+      r.e[3 * i + j] = v2d{re, im};
+    }
+  return r;
+}
+#ifndef SW_NOSTEP
+#define SW_STEP() __builtin_amdgcn_sched_barrier(0)   /* keeps the compiler from hoisting the next step's loads over this one: register budget */
+#else
+#define SW_STEP()
+#endif
+// what plane (mu, nu) adds to link (y, mu): out[0..7] = +-c * trace_lambda(A S_nu)
+template <class LD>
+__device__ __forceinline__ void sw_all_plane(double (&out)[8], const LD &ld, SwSite y, int par, int mu, int nu, double c) {
+  const int opp = 1 - par;   // parity of the one-hop neighbours (wave-uniform like par)
+  const int K = mu < nu ? mu : nu, L = mu < nu ? nu : mu;
+  const int P = K == 0 ? L - 1 : (K == 1 ? L + 1 : 5);
+  const SwSite ym = sw_shift(y, mu, 1);
+  const typename LD::Loc ly = ld.locate(y), lym = ld.locate(ym), lyn = ld.locate(sw_shift(y, nu, 1)), lyd = ld.locate(sw_shift(y, nu, -1));
+  const typename LD::Loc lymn = ld.locate(sw_shift(ym, nu, 1)), lymd = ld.locate(sw_shift(ym, nu, -1));
+  M3 Yd, R;
+  {  // upper plaquette  y -> y+mu -> y+mu+nu -> y+nu -> y
+    const M3 C = ld.link(lyn, opp, mu);
+    M3 F = m3_mulf<false, true>(ld.ins(lymn, par, P), C);
+    m3_acc(F, m3_mulf<true, false>(C, ld.ins(lyn, opp, P)));
+    SW_STEP();
+    const M3 D = ld.link(ly, par, nu);
+    const M3 Gu = m3_mulf<false, true>(F, D);
+    const M3 E = m3_mulf<true, true>(C, D);
+    SW_STEP();
+    const M3 B = ld.link(lym, opp, nu);
+    Yd = m3_mulf<false, false>(B, E);
+    R = m3_mulf<false, false>(B, Gu);
+  }
+  SW_STEP();
+  {  // lower plaquette  y -> y+mu -> y+mu-nu -> y-nu -> y
+    const M3 C = ld.link(lyd, opp, mu);
+    M3 F = m3_mulf<false, true>(ld.ins(lymd, par, P), C);
+    m3_acc(F, m3_mulf<true, false>(C, ld.ins(lyd, opp, P)));
+    SW_STEP();
+    const M3 D = ld.link(lyd, opp, nu);
+    const M3 Gl = m3_mulf<false, false>(F, D);
+    const M3 E = m3_mulf<true, false>(C, D);
+    SW_STEP();
+    const M3 B = ld.link(lymd, par, nu);
+    m3_sub(Yd, m3_mulf<true, false>(B, E));
+    m3_sub(R, m3_mulf<true, false>(B, Gl));
+  }
+  SW_STEP();
+  m3_acc(R, m3_mulf<false, false>(ld.ins(lym, opp, P), Yd));
+  m3_acc(R, m3_mulf<false, false>(Yd, ld.ins(ly, par, P)));
+  SW_STEP();
+  const M3 a = m3_mulf<false, false>(ld.link(ly, par, mu), R);
+  const double cs = mu < nu ? c : -c;
+  // su3adj.h:164-172 (_trace_lambda_mul_add_assign)
+  out[0] = cs * (-a.e[3].y - a.e[1].y);
+  out[1] = cs * (+a.e[3].x - a.e[1].x);
+  out[2] = cs * (-a.e[0].y + a.e[4].y);
+  out[3] = cs * (-a.e[6].y - a.e[2].y);
+  out[4] = cs * (+a.e[6].x - a.e[2].x);
+  out[5] = cs * (-a.e[7].y - a.e[5].y);
+  out[6] = cs * (+a.e[7].x - a.e[5].x);
+  out[7] = cs * ((-a.e[0].y - a.e[4].y + 2.0 * a.e[8].y) * 0.577350269189625);
+}
+// block = 64 sites of one parity x 4 waves: wave w owns the links (site, mu = w), walks the three planes through them one after the
+// other (one body with RUN-TIME directions: twelve compile-time instances measured the same, at twelve times the code) and does the
+// link's one read-modify-write.  Sites: e/o index in [i_begin, i_end) of either parity.
+// Block order: blocks b, b + 8, .. share an XCD (and its L2); each XCD gets a contiguous chunk of the site blocks (or, slab order,
+// its eighth of every time-slice) and runs the two parities of a site block back to back, so the links and insertion matrices
+// around those 64 + 64 sites are fetched once and re-used out of L2.
+template <class LD>
+__global__ __launch_bounds__(256, LD::min_blocks) void sw_all_gather_kernel(const LD ld, double *__restrict__ deriv, int LX, int LY, int LZ, int Vh,
+                                                               int i_begin, int i_end, int chunk, int slab, int nbt, double c) {
+  const int lane = threadIdx.x & 63;
+  const int mu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform, in a scalar register
+  const int q = blockIdx.x >> 3;
+  int sb;
+  if (slab > 0) {    // slab order: XCD j owns the j-th eighth of EVERY time-slice (nbt site blocks each) and marches through t
+    const int r = q >> 1, tt = r / slab, rr = (blockIdx.x & 7) * slab + (r - tt * slab);
+    if (rr >= nbt) return;
+    sb = tt * nbt + rr;
+  } else {
+    sb = (blockIdx.x & 7) * chunk + (q >> 1);
+  }
+  const int par = q & 1;
+  const int i = i_begin + sb * 64 + lane;
+  if (i >= i_end) return;
+  const int LZh = LZ / 2;
+  SwSite s;
+  {
+    int r = i / LZh;
+    const int k = i - r * LZh;
+    s.y = r % LY; r /= LY;
+    s.x = r % LX; s.t = r / LX;
+    s.z = 2 * k + ((s.t + s.x + s.y + par) & 1);
+  }
+  // the running su3adj sum lives in LDS (a private column per thread, no synchronisation): eight doubles too many for the 256-register budget
+  __shared__ double acc[8][256];
+  double o[8];
+  sw_all_plane(o, ld, s, par, mu, mu == 0 ? 1 : 0, c);                // nu = the first, second, third direction other than mu
+#pragma unroll
+  for (int m = 0; m < 8; m++) acc[m][threadIdx.x] = o[m];
+  SW_STEP();
+  sw_all_plane(o, ld, s, par, mu, mu <= 1 ? 2 : 1, c);
+#pragma unroll
+  for (int m = 0; m < 8; m++) acc[m][threadIdx.x] += o[m];
+  SW_STEP();
+  sw_all_plane(o, ld, s, par, mu, mu <= 2 ? 3 : 2, c);
+  double *d = deriv + ((size_t)par * 32 + (size_t)mu * 8) * Vh + i;
+#pragma unroll
+  for (int m = 0; m < 8; m++) d[(size_t)m * Vh] += acc[m][threadIdx.x] + o[m];
+}
+// the t = 0 / t = T-1 slices of the insertion matrices for the ring neighbours: out[w][30][XYZ], w = 0: our t = 0, w = 1: our t = T-1
+__global__ __launch_bounds__(256) void sw_pack_slabs_kernel(v2d *__restrict__ out, const v2d *__restrict__ Wc, unsigned ws, LexGeom g, int Vh) {
+  const int XYZ = g.LX * g.LY * g.LZ;
+  const int sp = blockIdx.x * 256 + threadIdx.x;
+  if (sp >= XYZ) return;
+  const int w = blockIdx.y, t = w ? g.T - 1 : 0;
+  const int z = sp % g.LZ, y = (sp / g.LZ) % g.LY, x = sp / (g.LZ * g.LY);
+  const size_t s = (size_t)((t + x + y + z) & 1) * Vh + ((t * XYZ + sp) >> 1);
+#pragma unroll 6
+  for (int m = 0; m < 30; m++) out[((size_t)w * 30 + m) * XYZ + sp] = Wc[(size_t)m * ws + s];
+}
+
 static int need64(const tmhip_field *f, const char *who) {
   if (!f || f->kind != TMHIP_FIELD_EO || f->prec != 0) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity fp64 field\n", who); return 1; }
   return 0;
@@ -569,7 +832,10 @@ int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c
   if (!ctx->gauge_raw) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge_raw, gbytes));   // kept: the clover force (tmhip_sw_all) walks the same links
   void *raw = ctx->gauge_raw;
   TMHIP_CHECK(hipMalloc(&F, fbytes));
-  if (gauge_host) TMHIP_CHECK(hipMemcpyAsync(raw, gauge_host, gbytes, hipMemcpyHostToDevice, ctx->stream));   // NULL: the links tmhip_set_gauge / tmhip_update_gauge left in HBM
+  if (gauge_host) {   // NULL: the links tmhip_set_gauge / tmhip_update_gauge left in HBM
+    TMHIP_CHECK(hipMemcpyAsync(raw, gauge_host, gbytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->gauge_copy_current = false;   // (re-sorted when the clover force next needs the stencil's copy of these links)
+  }
   LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, ctx->g.nproc_t > 1 ? 1 : 0};
   hipLaunchKernelGGL(sw_leaf_kernel, dim3((ctx->V + 127) / 128, 6), dim3(128), 0, ctx->stream, (const v2d *)raw, (v2d *)F, g);
   hipLaunchKernelGGL(sw_assemble_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (const v2d *)F, ctx->sw, ctx->gs, ctx->Vh,
@@ -693,22 +959,69 @@ static int sw_all_prepare(tmhip_ctx *ctx, const void *gauge_host) {
     if (!ctx->gauge_raw) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge_raw, gbytes));
     TMHIP_CHECK(hipMemcpyAsync(ctx->gauge_raw, gauge_host, gbytes, hipMemcpyHostToDevice, ctx->stream));
     ctx->gauge_raw_valid = true;
+    ctx->gauge_copy_current = false;
   } else if (!ctx->gauge_raw_valid) {
     TMHIP_FAIL("sw_all: no lexicographic gauge field on the device (pass the host field, or call tmhip_sw_term after tmhip_set_gauge)");
   }
   if (!ctx->deriv && tmhip_derivative_zero(ctx)) return 1;
+  const size_t XYZ = (size_t)ctx->g.LX * ctx->g.LY * ctx->g.LZ;
+  if (ctx->opt_swall_atomic) {
+    if (ctx->g.nproc_t > 1) {
+      const size_t hb = (size_t)2 * 32 * XYZ * sizeof(double);
+      if (!ctx->deriv_halo) TMHIP_CHECK(hipMalloc((void **)&ctx->deriv_halo, hb));
+      if (!ctx->deriv_halo_recv) TMHIP_CHECK(hipMalloc((void **)&ctx->deriv_halo_recv, hb));
+      TMHIP_CHECK(hipMemsetAsync(ctx->deriv_halo, 0, hb, ctx->stream));
+    }
+    return 0;
+  }
+  // owner-computes form: the interior (or the whole unsplit lattice) reads the stencil's gauge copy -- it must come from the same links
+  if (!ctx->gauge_copy_current && (ctx->g.nproc_t == 1 || ctx->g.T > 2) && tmhip_resort_gauge(ctx)) return 1;
+  // pass 1: the six insertion matrices of every site, compact (30 complex planes)
+  const unsigned ws = (unsigned)ctx->V;
+  if (!ctx->sw_ins) TMHIP_CHECK(hipMalloc((void **)&ctx->sw_ins, (size_t)30 * ws * sizeof(v2d)));
+  hipLaunchKernelGGL(sw_insertion_kernel, dim3((ctx->V + 255) / 256, 2), dim3(256), 0, ctx->stream, ctx->sw_ins, (const v2d *)ctx->swpm, ctx->V, ws);
+  TMHIP_CHECK(hipGetLastError());
   if (ctx->g.nproc_t > 1) {
-    const size_t hb = (size_t)2 * 32 * ctx->g.LX * ctx->g.LY * ctx->g.LZ * sizeof(double);
-    if (!ctx->deriv_halo) TMHIP_CHECK(hipMalloc((void **)&ctx->deriv_halo, hb));
-    if (!ctx->deriv_halo_recv) TMHIP_CHECK(hipMalloc((void **)&ctx->deriv_halo_recv, hb));
-    TMHIP_CHECK(hipMemsetAsync(ctx->deriv_halo, 0, hb, ctx->stream));
+    const size_t hb = (size_t)2 * 30 * XYZ * sizeof(v2d);
+    if (!ctx->swpm_halo_send) TMHIP_CHECK(hipMalloc((void **)&ctx->swpm_halo_send, hb));
+    if (!ctx->swpm_halo_recv) TMHIP_CHECK(hipMalloc((void **)&ctx->swpm_halo_recv, hb));
+    LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, 1};
+    hipLaunchKernelGGL(sw_pack_slabs_kernel, dim3((unsigned)((XYZ + 255) / 256), 2), dim3(256), 0, ctx->stream, ctx->swpm_halo_send, (const v2d *)ctx->sw_ins, ws, g, ctx->Vh);
+    TMHIP_CHECK(hipGetLastError());
   }
   return 0;
 }
 static int sw_all_launch(tmhip_ctx *ctx, double kappa, double c_sw) {
   LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, ctx->g.nproc_t > 1 ? 1 : 0};
-  hipLaunchKernelGGL(sw_all_kernel, dim3((ctx->V + 63) / 64, 6), dim3(64), 0, ctx->stream, (const v2d *)ctx->gauge_raw, (const v2d *)ctx->swpm, ctx->deriv,
-                     ctx->deriv_halo, g, ctx->Vh, -2. * (kappa * c_sw / 8.));
+  const double c = -2. * (kappa * c_sw / 8.);
+  if (ctx->opt_swall_atomic) {
+    hipLaunchKernelGGL(sw_all_kernel, dim3((ctx->V + 63) / 64, 6), dim3(64), 0, ctx->stream, (const v2d *)ctx->gauge_raw, (const v2d *)ctx->swpm, ctx->deriv,
+                       ctx->deriv_halo, g, ctx->Vh, c);
+    TMHIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  const bool split = ctx->g.nproc_t > 1;
+  const int ib = split ? ctx->face : 0, ie = split ? ctx->Vh - ctx->face : ctx->Vh;      // sites whose plaquettes stay on this rank
+  if (ie > ib && (!split || ctx->g.T > 2)) {
+    const SwFastLd ld{ctx->gauge, (unsigned)ctx->gs, ctx->sw_ins, (unsigned)ctx->V, ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->Vh};
+    int chunk = ((ie - ib + 63) / 64 + 7) / 8, slab = 0, nbt = 0, grid = chunk * 16;
+    if (ctx->opt_swall_order != 0 && ctx->face % 64 == 0 && ctx->face / 64 >= 8) {      // default: slab order (32^4: 1.92 vs 2.01 ms)
+      nbt = ctx->face / 64; slab = (nbt + 7) / 8;
+      grid = 8 * slab * ((ie - ib) / ctx->face) * 2;
+    }
+    hipLaunchKernelGGL((sw_all_gather_kernel<SwFastLd>), dim3(grid), dim3(256), 0, ctx->stream, ld, ctx->deriv, ctx->g.LX,
+                       ctx->g.LY, ctx->g.LZ, ctx->Vh, ib, ie, chunk, slab, nbt, c);
+  }
+  if (split) {     // the two t-faces, after the neighbours' swm / swp slices have arrived (same stream)
+    const SwEdgeLd ld{(const v2d *)ctx->gauge_raw, (const v2d *)ctx->sw_ins, (unsigned)ctx->V, (const v2d *)ctx->swpm_halo_recv, g, ctx->Vh};
+    const int nface = ctx->g.T > 1 ? 2 : 1;
+    for (int w = 0; w < nface; w++) {
+      const int fb = w ? ctx->Vh - ctx->face : 0;
+      const int chunk = ((ctx->face + 63) / 64 + 7) / 8;
+      hipLaunchKernelGGL((sw_all_gather_kernel<SwEdgeLd>), dim3(chunk * 16), dim3(256), 0, ctx->stream, ld, ctx->deriv, ctx->g.LX,
+                         ctx->g.LY, ctx->g.LZ, ctx->Vh, fb, fb + ctx->face, chunk, 0, 0, c);
+    }
+  }
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -722,39 +1035,65 @@ static int sw_all_add_received(tmhip_ctx *ctx) {
 
 /* operator/clover_accumulate_deriv.c:58 sw_all(hf, kappa, c_sw): adds the clover-leaf derivatives to the device-resident derivative
  * field (the one tmhip_deriv_Sb accumulates into).  gauge_field: host links as for tmhip_set_gauge (with the halo slabs on a
- * T-split rank), or NULL to reuse the copy kept by the last tmhip_sw_term.  On T-split ranks the leaves next to the t-faces reach
- * links of both ring neighbours: those contributions are collected per slab and exchanged over RCCL (the job of xchange_deri.c,
- * which ships one direction only and marks the other as missing for the clover case, :88-89), then added to the own links. */
+ * T-split rank), or NULL to reuse the links resident in HBM.  Every link is owned by one thread that gathers its 24 contributions
+ * (sw_all_gather_kernel).  On T-split ranks the plaquettes next to the t-faces contain links and insertion matrices of both ring
+ * neighbours: the links are in the halo slabs, the neighbours' t-slices of swm / swp are exchanged over RCCL first (what
+ * xchange_deri.c does for the derivative in one direction only, :88-89, is not needed: nothing is computed for foreign links).
+ * Option "swall_atomic" 1 selects the scatter form of the reference instead (atomics, derivative halos exchanged afterwards). */
 int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_sw) {
-  if (sw_all_prepare(ctx, gauge_host) || sw_all_launch(ctx, kappa, c_sw)) return 1;
-  if (ctx->g.nproc_t == 1) return 0;
-  if (!ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
+  if (sw_all_prepare(ctx, gauge_host)) return 1;
   const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
-  const size_t n = (size_t)32 * ctx->g.LX * ctx->g.LY * ctx->g.LZ;   // doubles per slab
-  TMHIP_NCCL_CHECK(ncclGroupStart());
-  TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo, n, ncclDouble, up, ctx->comm_red, ctx->stream));            // our t = T slab  -> up neighbour's t = 0
-  TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo + n, n, ncclDouble, dn, ctx->comm_red, ctx->stream));        // our t = -1 slab -> down neighbour's t = T-1
-  TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv, n, ncclDouble, dn, ctx->comm_red, ctx->stream));       // the down neighbour's t = T slab is our t = 0
-  TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv + n, n, ncclDouble, up, ctx->comm_red, ctx->stream));   // the up neighbour's t = -1 slab is our t = T-1
-  TMHIP_NCCL_CHECK(ncclGroupEnd());
-  return sw_all_add_received(ctx);
+  if (np > 1 && !ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
+  if (ctx->opt_swall_atomic) {
+    if (sw_all_launch(ctx, kappa, c_sw)) return 1;
+    if (np == 1) return 0;
+    const size_t n = (size_t)32 * ctx->g.LX * ctx->g.LY * ctx->g.LZ;   // doubles per slab
+    TMHIP_NCCL_CHECK(ncclGroupStart());
+    TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo, n, ncclDouble, up, ctx->comm_red, ctx->stream));            // our t = T slab  -> up neighbour's t = 0
+    TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo + n, n, ncclDouble, dn, ctx->comm_red, ctx->stream));        // our t = -1 slab -> down neighbour's t = T-1
+    TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv, n, ncclDouble, dn, ctx->comm_red, ctx->stream));       // the down neighbour's t = T slab is our t = 0
+    TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv + n, n, ncclDouble, up, ctx->comm_red, ctx->stream));   // the up neighbour's t = -1 slab is our t = T-1
+    TMHIP_NCCL_CHECK(ncclGroupEnd());
+    return sw_all_add_received(ctx);
+  }
+  if (np > 1) {
+    const size_t n = (size_t)2 * 30 * ctx->g.LX * ctx->g.LY * ctx->g.LZ;   // doubles per slice of insertion matrices
+    double *snd = (double *)ctx->swpm_halo_send, *rcv = (double *)ctx->swpm_halo_recv;
+    TMHIP_NCCL_CHECK(ncclGroupStart());
+    TMHIP_NCCL_CHECK(ncclSend(snd, n, ncclDouble, dn, ctx->comm_red, ctx->stream));            // our t = 0 slice is the down neighbour's t = T
+    TMHIP_NCCL_CHECK(ncclSend(snd + n, n, ncclDouble, up, ctx->comm_red, ctx->stream));        // our t = T-1 slice is the up neighbour's t = -1
+    TMHIP_NCCL_CHECK(ncclRecv(rcv, n, ncclDouble, up, ctx->comm_red, ctx->stream));            // slab 0 = t = T
+    TMHIP_NCCL_CHECK(ncclRecv(rcv + n, n, ncclDouble, dn, ctx->comm_red, ctx->stream));        // slab 1 = t = -1
+    TMHIP_NCCL_CHECK(ncclGroupEnd());
+  }
+  return sw_all_launch(ctx, kappa, c_sw);
 }
 /* The same on a T-split lattice held by n contexts of one process (peer copies instead of RCCL), as tmhip_multi_deriv_Sb. */
 int tmhip_multi_sw_all(int n, tmhip_ctx **ctxs, double kappa, double c_sw) {
   if (n < 2) TMHIP_FAIL("tmhip_multi_sw_all needs >= 2 contexts");
+  const bool atomic = ctxs[0]->opt_swall_atomic != 0;
   for (int r = 0; r < n; r++) {
     tmhip_ctx *c = ctxs[r];
     if (c->g.nproc_t != n || c->g.proc_t != r) TMHIP_FAIL("context %d is not rank %d of a %d-way T split", r, r, n);
-    if (sw_all_prepare(c, nullptr) || sw_all_launch(c, kappa, c_sw)) return 1;
+    if ((c->opt_swall_atomic != 0) != atomic) TMHIP_FAIL("tmhip_multi_sw_all: the contexts disagree on the swall_atomic option");
+    if (sw_all_prepare(c, nullptr)) return 1;
+    if (atomic && sw_all_launch(c, kappa, c_sw)) return 1;
   }
   for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
-  const size_t sb = (size_t)32 * ctxs[0]->g.LX * ctxs[0]->g.LY * ctxs[0]->g.LZ * sizeof(double);
+  const size_t XYZ = (size_t)ctxs[0]->g.LX * ctxs[0]->g.LY * ctxs[0]->g.LZ;
+  const size_t sb = atomic ? (size_t)32 * XYZ * sizeof(double) : (size_t)30 * XYZ * sizeof(v2d);
   for (int r = 0; r < n; r++) {
     tmhip_ctx *c = ctxs[r], *up = ctxs[(r + 1) % n], *dn = ctxs[(r + n - 1) % n];
     TMHIP_CHECK(hipSetDevice(c->device));
-    TMHIP_CHECK(hipMemcpyPeerAsync(c->deriv_halo_recv, c->device, dn->deriv_halo, dn->device, sb, c->stream));
-    TMHIP_CHECK(hipMemcpyPeerAsync((char *)c->deriv_halo_recv + sb, c->device, (char *)up->deriv_halo + sb, up->device, sb, c->stream));
-    if (sw_all_add_received(c)) return 1;
+    if (atomic) {
+      TMHIP_CHECK(hipMemcpyPeerAsync(c->deriv_halo_recv, c->device, dn->deriv_halo, dn->device, sb, c->stream));
+      TMHIP_CHECK(hipMemcpyPeerAsync((char *)c->deriv_halo_recv + sb, c->device, (char *)up->deriv_halo + sb, up->device, sb, c->stream));
+      if (sw_all_add_received(c)) return 1;
+    } else {
+      TMHIP_CHECK(hipMemcpyPeerAsync(c->swpm_halo_recv, c->device, up->swpm_halo_send, up->device, sb, c->stream));                                  // t = T  <- up's t = 0
+      TMHIP_CHECK(hipMemcpyPeerAsync((char *)c->swpm_halo_recv + sb, c->device, (char *)dn->swpm_halo_send + sb, dn->device, sb, c->stream));        // t = -1 <- down's t = T-1
+      if (sw_all_launch(c, kappa, c_sw)) return 1;
+    }
   }
   for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
   return 0;

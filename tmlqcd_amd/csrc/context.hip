@@ -120,6 +120,7 @@ int tmhip_resort_gauge(tmhip_ctx *ctx) {
                      ctx->gs, ctx->Vh, ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, toff, ctx->g.nproc_t > 1 ? 1 : 0);
   TMHIP_CHECK(hipGetLastError());
   ctx->gauge_set = true;
+  ctx->gauge_copy_current = true;
   ctx->gauge32_set = false;       // the fp32 twin is rebuilt lazily from the new links
   ctx->gauge_recon_dev = -1.0;
   return 0;
@@ -180,7 +181,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
   ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 2; ctx->opt_fusedface = -1; ctx->opt_gaux = -1;
-  ctx->opt_gdrop = 0; ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_facesplit = 0; ctx->opt_recon = 0;
+  ctx->opt_gdrop = 0; ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_facesplit = 0; ctx->opt_recon = 0; ctx->opt_swall_order = 1;
   ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
@@ -245,6 +246,9 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->force_recv) (void)hipFree(ctx->force_recv);
   if (ctx->deriv_halo) (void)hipFree(ctx->deriv_halo);
   if (ctx->deriv_halo_recv) (void)hipFree(ctx->deriv_halo_recv);
+  if (ctx->sw_ins) (void)hipFree(ctx->sw_ins);
+  if (ctx->swpm_halo_send) (void)hipFree(ctx->swpm_halo_send);
+  if (ctx->swpm_halo_recv) (void)hipFree(ctx->swpm_halo_recv);
   if (ctx->comm_ready) { ncclCommDestroy(ctx->comm_red); ncclCommDestroy(ctx->comm); }
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
@@ -310,6 +314,8 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "fusedface")) ctx->opt_fusedface = value;
   else if (!strcmp(name, "facesplit")) ctx->opt_facesplit = value;
   else if (!strcmp(name, "bench_graph")) ctx->opt_bench_graph = value;
+  else if (!strcmp(name, "swall_atomic")) ctx->opt_swall_atomic = value != 0;
+  else if (!strcmp(name, "swall_order")) { if (value < 0 || value > 1) TMHIP_FAIL("swall_order must be 0 (chunk per XCD) or 1 (slab order, default)"); ctx->opt_swall_order = value; }
   else if (!strcmp(name, "gaux")) ctx->opt_gaux = value;
   else if (!strcmp(name, "gdrop")) ctx->opt_gdrop = value;
   else if (!strcmp(name, "occ32")) { if (value < 0 || value > 8) TMHIP_FAIL("occ32 must be in [0, 8]"); ctx->opt_occ32 = value; }

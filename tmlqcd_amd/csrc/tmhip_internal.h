@@ -79,6 +79,7 @@ struct tmhip_ctx {
   v2d *swpm;           // clover-force accumulators swm / swp (clover_leaf.c:141-172): [2][4][9][V], site = parity * Vh + e/o index
   v2d *gauge_raw;      // lexicographic gauge field [VPR][4][9] kept from the last tmhip_sw_term for tmhip_sw_all; gauge_raw_valid
   bool gauge_raw_valid;
+  bool gauge_copy_current;   // the stencil's gauge copy was sorted from the links now in gauge_raw
   int *sw_fail;        // device counter of near-singular pivots met by tmhip_sw_invert
   v2f *sw32, *sw_inv32; bool clover32_set;
   v2f *gauge32;        // fp32 twin of the gauge copy (g_gauge_field_copy_32), built on first use
@@ -104,6 +105,8 @@ struct tmhip_ctx {
   double *deriv;
   double *momenta;     // hamiltonian_field_t::momenta, su3adj [V][4] = double [V][4][8], resident for tmhip_update_gauge (md_update.hip)
   double *deriv_halo, *deriv_halo_recv;   // T-split sw_all: [2 slabs (t = T, t = -1)][4 mu][8][LX LY LZ] contributions to the neighbours' links / theirs to ours
+  v2d *sw_ins;         // sw_all: the six anti-hermitian insertion matrices of every site, compact [6][5][V] (clover.hip, sw_insertion_kernel)
+  v2d *swpm_halo_send, *swpm_halo_recv;   // T-split sw_all (owner-computes): [2 slices][30][LX LY LZ] our t = 0 / T-1 slices of sw_ins / the neighbours' t = T, -1
   v2d *force_send, *force_recv;   // T-split deriv_Sb: [24][face] t=0 slices of (l, k), ours / the up-neighbour's
   // device-resident CG state (cg.hip)
   void *cg_state; double *cg_hist; int cg_hist_len;
@@ -118,6 +121,8 @@ struct tmhip_ctx {
   int opt_flagsync, opt_fusedface, opt_facesplit;                       // split path
   int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot;                      // cg_her
   int opt_bench_graph;
+  int opt_swall_order;                                                  // block order of the owner-computes sw_all: 0 one contiguous chunk per XCD, 1 slab order
+  int opt_swall_atomic;                                                 // 1 = sw_all in the reference's scatter form (fp64 atomics), A/B only
   double gauge_recon_dev;   // max |U_row2 - conj(row0 x row1)| over all links of the resident gauge field (-1: not measured)
 };
 

@@ -20,7 +20,8 @@ class TmHipError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libtmlqcd_hip.so")
+    # TMLQCD_HIP_LIB: another build of the same library (A/B runs of kernel variants, tools/)
+    return os.environ.get("TMLQCD_HIP_LIB") or os.path.join(_HERE, "lib", "libtmlqcd_hip.so")
 
 
 class _Geom(C.Structure):
