@@ -215,6 +215,26 @@ void tmlqcd_hip_forget(spinor *field);             /* host memory is being freed
 void tmlqcd_hip_set_device(int device);            /* before the first call; default: $TMLQCD_HIP_DEVICE or 0 */
 void tmlqcd_hip_comm_init(const char unique_id[128]); /* ranks along T: id from tmhip_comm_get_unique_id, MPI_Bcast by the host */
 void tmlqcd_hip_finalize(void);
+/* ---- ILDG gauge configurations: replaces io/gauge_read.o and io/gauge_write.o of libio.a -- */
+typedef struct { unsigned int suma, sumb; } DML_Checksum;                        /* io/dml.h:34-37 */
+typedef struct {                                                                 /* io/params.h:98-104 */
+  double plaquetteEnergy;
+  int gaugeRead;
+  DML_Checksum checksum;
+  char *xlfInfo;
+  char *ildg_data_lfn;
+} paramsGaugeInfo;
+typedef struct {                                                                 /* io/params.h:71-88 */
+  char date[64];
+  char package_version[32];
+  double beta, c2_rec, epsilonbar, kappa, mu, mubar, plaq;
+  int counter;
+  long int time;
+} paramsXlfInfo;
+extern paramsGaugeInfo GaugeInfo;                                                /* io/gauge_read.c:27 */
+/* reads gauge_precision_read_flag and g_disable_IO_checks at call time (both optional: weak references, defaults 64 / checks on) */
+int read_gauge_field(char *filename, su3 **const gf);                            /* io/gauge.h, io/gauge_read.c:28 */
+int write_gauge_field(char *filename, const int prec, paramsXlfInfo const *xlfInfo);   /* io/gauge_write.c:22 */
 /* benchmark.c:291-300 on device-resident mirrors; returns seconds for `iters` x {H(0,f1,f0); H(1,f2,f1)} */
 double tmlqcd_hip_benchmark_loop(spinor *f0, spinor *f1, spinor *f2, int iters);
 

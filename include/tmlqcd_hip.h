@@ -238,6 +238,27 @@ int tmhip_update_momenta(tmhip_ctx *ctx, double step);   /* update_momenta.c:67-
 int tmhip_update_gauge(tmhip_ctx *ctx, double step);     /* update_gauge.c:51-110 */
 int tmhip_gauge_download(tmhip_ctx *ctx, void *host_gauge);   /* [VOLUMEPLUSRAND][4] su3, e.g. at the end of a trajectory */
 
+/* ---- ILDG gauge configurations (io/gauge_read.c:28-198, io/gauge_read_binary.c:140-200, io/gauge_write.c:22-59,
+ *      io/gauge_write_binary.c:150-175, io/dml.c:49-60).  The "ildg-binary-data" record travels to / from the device as it lies in
+ *      the file; byte swap, 32 <-> 64 bit conversion, site and link re-ordering and the SciDAC checksum happen in HBM (ildg.hip). -- */
+typedef struct {
+  int gauge_read;                       /* GaugeInfo.gaugeRead */
+  unsigned suma, sumb;                  /* checksum calculated over the record (GaugeInfo.checksum) */
+  unsigned suma_stored, sumb_stored;    /* ... and as stored in the "scidac-checksum" record */
+  int prec, lx, ly, lz, lt;             /* "ildg-format" record */
+  char xlf_info[1024];                  /* GaugeInfo.xlfInfo */
+  char ildg_data_lfn[512];              /* GaugeInfo.ildg_data_lfn */
+} tmhip_gauge_info;
+/* this rank's part of the record (T LZ LY LX sites, x fastest; per site links x, y, z, t; big-endian; prec 64 | 32) -> resident links +
+ * stencil gauge copy as after tmhip_set_gauge; sums[2] = SciDAC checksum A, B of this rank's sites (XOR over ranks = the file's) */
+int tmhip_gauge_unpack_ildg(tmhip_ctx *ctx, const void *file_bytes, int prec, unsigned *sums);
+int tmhip_gauge_pack_ildg(tmhip_ctx *ctx, void *file_bytes, int prec, unsigned *sums);
+/* read_gauge_field(filename, gf) / write_gauge_field(filename, prec, xlfInfo) of one rank, LIME framing included; the reader returns 0
+ * or -1 with the reference's messages (io_checks = !g_disable_IO_checks; prec_expected = gauge_precision_read_flag);
+ * host_gauge (may be NULL): the host's g_gauge_field to fill as well; xlf_info: the formatted "xlf-info" message or NULL */
+int tmhip_read_gauge_field(tmhip_ctx *ctx, const char *filename, int prec_expected, int io_checks, void *host_gauge, tmhip_gauge_info *info);
+int tmhip_write_gauge_field(tmhip_ctx *ctx, const char *filename, int prec, const char *xlf_info, unsigned *sums);
+
 /* ---- multi-GPU halo exchange (replaces xchange_field / xchange_halffield,
  *      xchange/xchange_field.c:269-470, xchange/xchange_halffield.c:176-263) -- */
 #define TMHIP_UNIQUE_ID_BYTES 128

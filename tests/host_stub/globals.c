@@ -69,3 +69,8 @@ su3 *stub_init_clover(int which) {
   }
   return which ? swinv_block : sw_block;
 }
+
+/* input-parser globals the ILDG reader looks at (read_input.l: GaugeConfigReadPrecision; global.h:74) */
+int gauge_precision_read_flag = 64;
+int g_disable_IO_checks = 0;
+void stub_set_io(int prec, int disable_checks) { gauge_precision_read_flag = prec; g_disable_IO_checks = disable_checks; }

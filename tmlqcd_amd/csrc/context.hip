@@ -247,6 +247,7 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->deriv_halo) (void)hipFree(ctx->deriv_halo);
   if (ctx->deriv_halo_recv) (void)hipFree(ctx->deriv_halo_recv);
   if (ctx->sw_ins) (void)hipFree(ctx->sw_ins);
+  if (ctx->io_sums) (void)hipFree(ctx->io_sums);
   if (ctx->swpm_halo_send) (void)hipFree(ctx->swpm_halo_send);
   if (ctx->swpm_halo_recv) (void)hipFree(ctx->swpm_halo_recv);
   if (ctx->comm_ready) { ncclCommDestroy(ctx->comm_red); ncclCommDestroy(ctx->comm); }

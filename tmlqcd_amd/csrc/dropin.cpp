@@ -30,6 +30,11 @@ extern int mixcg_maxinnersolverit __attribute__((weak));          /* read_input.
 // Present in a full tmLQCD link (update_backward_gauge.c, libhmc.a); refreshes the HOST gauge
 // copy that deriv_Sb.c:405-408,472 still reads, and clears g_update_gauge_copy.
 void update_backward_gauge(su3 **const gf) __attribute__((weak));
+// ILDG I/O (io/gauge_read.c, io/gauge_write.c): the reader's precision switch and the IO-check switch are owned by the input parser
+extern int gauge_precision_read_flag __attribute__((weak));       /* read_input.l; default 64 */
+extern int g_disable_IO_checks __attribute__((weak));             /* global.h:74 */
+extern int T_global __attribute__((weak));                        /* global.h:82 */
+extern int L __attribute__((weak));
 }
 
 namespace {
@@ -958,6 +963,60 @@ void tmlqcd_hip_sync_momenta_to_host(hamiltonian_field_t *const hf) {
   if (!g_momenta_resident) return;
   CK(tmhip_momenta_download(ctx(), &hf->momenta[0][0]));
   g_momenta_resident = false;
+}
+
+// ------------------------------------------------------------------ ILDG gauge configurations
+/* io/gauge_read.c:26-27: the record read_gauge_field fills (defined by the object this library replaces) */
+paramsGaugeInfo GaugeInfo = {0., 0, {0, 0}, NULL, NULL};
+
+/* io/gauge_read.c:28-198 read_gauge_field(filename, gf): LIME records walked on the host, the binary record unpacked and
+ * check-summed in HBM; gf (the host's g_gauge_field) is filled, GaugeInfo set, g_update_gauge_copy raised; returns 0 or -1 with the
+ * reference's messages.  The device keeps the links it has just unpacked, so the refresh that g_update_gauge_copy triggers at the
+ * next operator call does not upload them again (gf == g_gauge_field only). */
+int read_gauge_field(char *filename, su3 **const gf) {
+  tmhip_ctx *c = ctx();
+  if (c == nullptr || (g_nproc_t > 1)) die("read_gauge_field: single-rank reader (T-split ranks: tmhip_gauge_unpack_ildg on their part of the record)");
+  g_calls++;
+  static tmhip_gauge_info info;
+  const int prec = &gauge_precision_read_flag && gauge_precision_read_flag == 32 ? 32 : 64;
+  const int checks = !(&g_disable_IO_checks && g_disable_IO_checks);
+  GaugeInfo.gaugeRead = 0;
+  const int rc = tmhip_read_gauge_field(c, filename, prec, checks, &gf[0][0], &info);
+  if (rc == -1) return -1;
+  if (rc != 0) die("tmhip_read_gauge_field");
+  GaugeInfo.gaugeRead = info.gauge_read;
+  GaugeInfo.checksum.suma = info.suma; GaugeInfo.checksum.sumb = info.sumb;
+  if (info.xlf_info[0]) { free(GaugeInfo.xlfInfo); GaugeInfo.xlfInfo = strdup(info.xlf_info); }
+  if (info.ildg_data_lfn[0]) { free(GaugeInfo.ildg_data_lfn); GaugeInfo.ildg_data_lfn = strdup(info.ildg_data_lfn); }
+  g_update_gauge_copy = 1;                                          /* gauge_read.c:190 */
+  g_clover_uploaded = false;
+  if (gf == g_gauge_field && info.gauge_read) { g_gauge_uploaded = true; g_dev_links_current = true; g_dev_links_newer = false; }
+  return 0;
+}
+
+/* io/gauge_write.c:22-59 write_gauge_field(filename, prec, xlfInfo): the records of the reference in its order; the binary record and
+ * its checksum come from the links in HBM (uploaded from g_gauge_field first unless the device copy is the current one) */
+int write_gauge_field(char *filename, const int prec, paramsXlfInfo const *xlfInfo) {
+  if (g_nproc_t > 1) die("write_gauge_field: single-rank writer (T-split ranks: tmhip_gauge_pack_ildg for their part of the record)");
+  tmhip_ctx *c = ctx();
+  g_calls++;
+  if (!g_dev_links_newer) { CK(tmhip_set_gauge(c, &g_gauge_field[0][0])); g_gauge_uploaded = true; g_clover_uploaded = false; }
+  char msg[1024];
+  msg[0] = 0;
+  if (xlfInfo) {                                                    /* io/utils_write_xlf_xml.c:30-63 */
+    if (xlfInfo->kappa != 0.0)
+      snprintf(msg, sizeof(msg), "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<xlf-info>\n  <plaquette>%14.12f</plaquette>\n  <trajectory>%d</trajectory>\n"
+               "  <beta>%.12f</beta>\n  <kappa>%.12f</kappa>\n  <mu>%.12f</mu>\n  <c2_rec>%f</c2_rec>\n  <time>%ld</time>\n  <hmcversion>%s</hmcversion>\n"
+               "  <mubar>%.12f</mubar>\n  <epsilonbar>%.12f</epsilonbar>\n  <date>%s</date>\n</xlf-info>",
+               xlfInfo->plaq, xlfInfo->counter, xlfInfo->beta, xlfInfo->kappa, xlfInfo->mu, xlfInfo->c2_rec, xlfInfo->time, xlfInfo->package_version,
+               xlfInfo->mubar, xlfInfo->epsilonbar, xlfInfo->date);
+    else
+      snprintf(msg, sizeof(msg), "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<xlf-info>\n  <plaquette>%e</plaquette>\n  <trajectory>%d</trajectory>\n"
+               "  <beta>%.12f</beta>\n  <kappa>%.12f</kappa>\n  <2kappamu>%.12f</2kappamu>\n  <c2_rec>%f</c2_rec>\n  <date>%s</date>\n</xlf-info>",
+               xlfInfo->plaq, xlfInfo->counter, xlfInfo->beta, xlfInfo->kappa, xlfInfo->mu, xlfInfo->c2_rec, xlfInfo->date);
+  }
+  unsigned cs[2];
+  return tmhip_write_gauge_field(c, filename, prec, msg[0] ? msg : nullptr, cs) ? -1 : 0;
 }
 
 // ------------------------------------------------------------------ benchmark helper

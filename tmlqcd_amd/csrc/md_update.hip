@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void update_momenta_kernel(double *__restrict_
 }
 
 // t = 0 and t = T-1 slices of the lexicographic field -> the neighbours' halo slabs (xchange_gauge, geometry_eo.c:292-299)
-int exchange_gauge_halo(tmhip_ctx *ctx) {
+}  // namespace
+int tmhip_exchange_gauge_halo(tmhip_ctx *ctx) {
   if (ctx->g.nproc_t < 2) return 0;
   if (!ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
   const size_t XYZ = (size_t)ctx->g.LX * ctx->g.LY * ctx->g.LZ, n = XYZ * 36 * 2;   // doubles per slice
@@ -117,7 +118,6 @@ int exchange_gauge_halo(tmhip_ctx *ctx) {
   TMHIP_NCCL_CHECK(ncclGroupEnd());
   return 0;
 }
-}  // namespace
 
 extern "C" {
 
@@ -160,7 +160,7 @@ int tmhip_update_gauge(tmhip_ctx *ctx, double step) {
   const size_t nlinks = (size_t)ctx->V * 4;
   hipLaunchKernelGGL(update_gauge_kernel, dim3((unsigned)((nlinks + 255) / 256)), dim3(256), 0, ctx->stream, ctx->gauge_raw, (const double *)ctx->momenta, nlinks, step);
   TMHIP_CHECK(hipGetLastError());
-  if (exchange_gauge_halo(ctx)) return 1;
+  if (tmhip_exchange_gauge_halo(ctx)) return 1;
   // clover blocks belong to the old links: tmhip_sw_term (gauge = NULL: from the resident links) / tmhip_sw_invert again
   ctx->sw_set = false; ctx->clover_set = false; ctx->clover32_set = false;
   return tmhip_resort_gauge(ctx);

@@ -80,6 +80,7 @@ struct tmhip_ctx {
   v2d *gauge_raw;      // lexicographic gauge field [VPR][4][9] kept from the last tmhip_sw_term for tmhip_sw_all; gauge_raw_valid
   bool gauge_raw_valid;
   bool gauge_copy_current;   // the stencil's gauge copy was sorted from the links now in gauge_raw
+  unsigned *io_sums;   // SciDAC checksum words A, B accumulated by the ILDG pack / unpack kernels (ildg.hip)
   int *sw_fail;        // device counter of near-singular pivots met by tmhip_sw_invert
   v2f *sw32, *sw_inv32; bool clover32_set;
   v2f *gauge32;        // fp32 twin of the gauge copy (g_gauge_field_copy_32), built on first use
@@ -173,6 +174,7 @@ int tmhip_field_alloc_prec(tmhip_ctx *ctx, int kind, int prec, tmhip_field **out
 int tmhip_halo_exchange(tmhip_ctx *ctx);
 int tmhip_apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k);
 int tmhip_prepare_fp32(tmhip_ctx *ctx);
+int tmhip_exchange_gauge_halo(tmhip_ctx *ctx);   // md_update.hip: t = 0 / T-1 slices of the resident links -> the ring neighbours' halo slabs
 int tmhip_resort_gauge(tmhip_ctx *ctx);   // md_update.hip: stencil gauge copy from the device-resident lexicographic links
 int tmhip_prepare_clover32(tmhip_ctx *ctx);  // fp32 gauge copy + fp32 scratch / solver fields
 // launch geometry shared by linalg.hip and cg.hip

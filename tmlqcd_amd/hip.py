@@ -24,6 +24,13 @@ def library_path():
     return os.environ.get("TMLQCD_HIP_LIB") or os.path.join(_HERE, "lib", "libtmlqcd_hip.so")
 
 
+class GaugeInfo(C.Structure):
+    """tmhip_gauge_info (include/tmlqcd_hip.h): what the reference keeps in GaugeInfo after read_gauge_field."""
+    _fields_ = [("gauge_read", C.c_int), ("suma", C.c_uint), ("sumb", C.c_uint), ("suma_stored", C.c_uint), ("sumb_stored", C.c_uint),
+                ("prec", C.c_int), ("lx", C.c_int), ("ly", C.c_int), ("lz", C.c_int), ("lt", C.c_int),
+                ("xlf_info", C.c_char * 1024), ("ildg_data_lfn", C.c_char * 512)]
+
+
 class _Geom(C.Structure):
     _fields_ = [("T", C.c_int), ("LX", C.c_int), ("LY", C.c_int), ("LZ", C.c_int),
                 ("nproc_t", C.c_int), ("proc_t", C.c_int)]
@@ -87,6 +94,9 @@ def load_library():
         "tmhip_sw_term": [vp, vp, d, d],
         "tmhip_momenta_upload": [vp, vp], "tmhip_momenta_download": [vp, vp], "tmhip_update_momenta": [vp, d],
         "tmhip_update_gauge": [vp, d], "tmhip_gauge_download": [vp, vp],
+        "tmhip_gauge_unpack_ildg": [vp, vp, i, C.POINTER(C.c_uint)], "tmhip_gauge_pack_ildg": [vp, vp, i, C.POINTER(C.c_uint)],
+        "tmhip_read_gauge_field": [vp, C.c_char_p, i, i, vp, C.POINTER(GaugeInfo)],
+        "tmhip_write_gauge_field": [vp, C.c_char_p, i, C.c_char_p, C.POINTER(C.c_uint)],
         "tmhip_gauge_su3_deviation": [vp, pd],
         "tmhip_derivative_zero": [vp],
         "tmhip_swpm_zero": [vp], "tmhip_sw_spinor_eo": [vp, i, vp, vp, d], "tmhip_sw_deriv": [vp, i, d],
@@ -363,6 +373,40 @@ class Lattice:
         out = np.zeros((self.VPR, 4, 3, 3, 2))
         _ck(self.lib.tmhip_gauge_download(self.h, _hp(out)), "tmhip_gauge_download")
         return out
+
+    # ---- ILDG gauge configurations (io/gauge_read.c, io/gauge_write.c; ildg.hip)
+    def gauge_unpack_ildg(self, file_bytes, prec):
+        """This rank's part of an "ildg-binary-data" record (bytes / uint8 array) -> resident links; returns (suma, sumb)."""
+        buf = np.frombuffer(file_bytes, dtype=np.uint8) if not isinstance(file_bytes, np.ndarray) else file_bytes
+        want = self.V * 4 * 9 * (16 if prec == 64 else 8)
+        if buf.size != want:
+            raise TmHipError("gauge_unpack_ildg: %d bytes, expected %d" % (buf.size, want))
+        buf = np.ascontiguousarray(buf)
+        sums = (C.c_uint * 2)()
+        _ck(self.lib.tmhip_gauge_unpack_ildg(self.h, buf.ctypes.data_as(C.c_void_p), prec, sums), "tmhip_gauge_unpack_ildg")
+        return int(sums[0]), int(sums[1])
+
+    def gauge_pack_ildg(self, prec):
+        """The resident links as the bytes of this rank's part of the record; returns (uint8 array, (suma, sumb))."""
+        out = np.zeros(self.V * 4 * 9 * (16 if prec == 64 else 8), dtype=np.uint8)
+        sums = (C.c_uint * 2)()
+        _ck(self.lib.tmhip_gauge_pack_ildg(self.h, out.ctypes.data_as(C.c_void_p), prec, sums), "tmhip_gauge_pack_ildg")
+        return out, (int(sums[0]), int(sums[1]))
+
+    def read_gauge_field(self, filename, prec=64, io_checks=True, want_host=True):
+        """read_gauge_field(filename, gf) (io/gauge_read.c:28): returns (status 0 | -1, host field or None, GaugeInfo)."""
+        info = GaugeInfo()
+        out = np.zeros((self.VPR, 4, 3, 3, 2)) if want_host else None
+        rc = self.lib.tmhip_read_gauge_field(self.h, str(filename).encode(), prec, 1 if io_checks else 0, _hp(out) if want_host else None, C.byref(info))
+        if rc not in (0, -1):
+            raise TmHipError("tmhip_read_gauge_field failed (rc=%d)" % rc)
+        return rc, out, info
+
+    def write_gauge_field(self, filename, prec=64, xlf_info=None):
+        """write_gauge_field(filename, prec, xlfInfo) (io/gauge_write.c:22) from the resident links; returns (suma, sumb)."""
+        sums = (C.c_uint * 2)()
+        _ck(self.lib.tmhip_write_gauge_field(self.h, str(filename).encode(), prec, xlf_info.encode() if xlf_info else None, sums), "tmhip_write_gauge_field")
+        return int(sums[0]), int(sums[1])
 
     def sw_invert(self, ieo, mu):
         """operator/clover_invert.c:170 on the device (needs sw_term or set_clover first)."""
