@@ -1,6 +1,9 @@
 // Shared prelude of the three stencil translation units (hopping.hip: fp64, hopping32.hip: fp32, hopping32p.hip: fp32 with two
 // sites per thread).  Each includes hopping_impl.inc once inside its own namespace; splitting them lets make compile them in parallel.
 #pragma once
+#ifndef HOP_GAUGE_NT
+#define HOP_GAUGE_NT true   /* gauge links loaded non-temporally (A/B builds: -DHOP_GAUGE_NT=false) */
+#endif
 #include "tmhip_internal.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
