@@ -37,6 +37,11 @@ for rnd in range(2):
     t0 = time.perf_counter(); lat.sw_term(g, kappa, c_sw); lat.sync(); t1 = time.perf_counter()
     lat.sw_invert(0, mu); lat.sync(); t2 = time.perf_counter()
     print("sw_term (incl. H2D of the gauge field) %8.1f ms   sw_invert(EE, mu) %8.2f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
+# ... and from the links already resident in HBM (what an MD step costs after tmhip_update_gauge): kernels only
+for rnd in range(2):
+    t0 = time.perf_counter(); lat.sw_term(None, kappa, c_sw); lat.sync(); t1 = time.perf_counter()
+    print("sw_term from the resident links %8.2f ms" % ((t1 - t0) * 1e3), flush=True)
+lat.sw_invert(0, mu)
 del g
 
 src = syn.spinor_field_eo(2, 1, L, L, L, L)
@@ -49,7 +54,10 @@ timed("deriv_Sb", lambda: lat.deriv_Sb(1, a, b, 0.5), 20, 2048, 2 * Vh)
 lat.swpm_zero()
 timed("sw_spinor_eo", lambda: lat.sw_spinor_eo(1, a, b, 0.5), 20, 384 + 2 * 1152, Vh)
 timed("sw_deriv(EE, mu)", lambda: lat.sw_deriv(0, mu), 20, 2 * 1152 + 2 * 1152, Vh)
-timed("sw_all (96 atomic su3adj adds per site)", lambda: lat.sw_all(kappa, c_sw), 5)
+timed("sw_all (owner-computes)", lambda: lat.sw_all(kappa, c_sw), 5)
+lat.momenta_upload(__import__("numpy").zeros((lat.V, 4, 8)))
+timed("update_gauge (exp(step P) U, halo, re-sort)", lambda: lat.update_gauge(0.01), 5)
+timed("update_momenta", lambda: lat.update_momenta(0.01), 5)
 for name in ("Qtm_pm_psi", "Mtm_plus_psi", "Mtm_plus_sym_psi", "Qtm_plus_sym_psi", "Mtm_plus_sym_dagg_psi", "Qsw_pm_psi"):
     timed(name, lambda n=name: lat.op(n, c, a), 20)
 
