@@ -195,7 +195,14 @@ void tmlqcd_hip_update_momenta(const double step, hamiltonian_field_t *const hf)
 void tmlqcd_hip_sync_momenta_to_host(hamiltonian_field_t *const hf);
 
 /* ---- residency control (additions; not in the reference) ------------------- */
-enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1 };
+/* COHERENT (default): every call uploads its inputs and downloads its outputs -- exact drop-in, PCIe-bound.
+ * RESIDENT: outputs stay in HBM until tmlqcd_hip_sync_to_host; the host program says when it touches a field.
+ * LAZY: as RESIDENT, but the library finds out by itself: the pages of a host array whose current copy is in HBM are made
+ *   inaccessible, the host's first load from one of them faults and fetches that page (or, if it keeps reading or stores, the field);
+ *   arrays the device has read are write-protected, so a host store invalidates the mirror.  An UNMODIFIED host program then runs its
+ *   stencil / operator loops at the HBM rate (also: environment TMLQCD_HIP_RESIDENCY=lazy).  Opt-in because system calls do not
+ *   fault: a field passed to write(2) / MPI while its host copy is stale must be synchronised first (tmlqcd_hip_sync_to_host). */
+enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1, TMLQCD_HIP_LAZY = 2 };
 /* Device versions of sw_term(g_gauge_field, kappa, c_sw) / sw_invert(ieo, mu) (operator/clover_term.c:88,
  * operator/clover_invert.c:170).  They carry their own names because the reference keeps other, unrelated functions in
  * the same objects (six_det, sw_invert_nd, sw_trace ...), so those objects stay on the link line; replace the two calls
@@ -203,6 +210,8 @@ enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1 };
 void tmlqcd_hip_sw_term(const double kappa, const double c_sw);
 void tmlqcd_hip_sw_invert(const int ieo, const double mu);
 void tmlqcd_hip_set_residency(int mode);
+/* lazy mode counters: page faults served, pages fetched one by one, whole-field fetches, host stores noticed */
+void tmlqcd_hip_lazy_stats(unsigned long out[4]);
 /* Upper bound on the number of device mirrors kept for host arrays (default 64, also TMLQCD_HIP_MAX_MIRRORS): beyond it the
  * least recently used mirror whose host copy is current is freed.  Host programs that allocate work fields per solve
  * (solver/solver_field.c) hand in ever new addresses; mirrors holding device-only data (resident mode) are never dropped. */

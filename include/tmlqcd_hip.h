@@ -69,6 +69,11 @@ void tmhip_field_free(tmhip_ctx *ctx, tmhip_field *f);
  * geometry_eo.c:869-885.  FULL fields: nsites = V, lexicographic order. */
 int tmhip_field_upload(tmhip_ctx *ctx, tmhip_field *f, const void *host_spinors, int nsites);
 int tmhip_field_download(tmhip_ctx *ctx, tmhip_field *f, void *host_spinors, int nsites);
+/* sites [first, first + count) of a one-parity fp64 field -> host_spinors[0 .. count) (page-wise synchronisation of the drop-in's lazy mode) */
+int tmhip_field_download_range(tmhip_ctx *ctx, tmhip_field *f, void *host_spinors, int first, int count);
+/* page-locked host buffers (hipHostMalloc): staging for callers that keep the runtime away from their own pages */
+int tmhip_pinned_alloc(unsigned long bytes, void **out);
+int tmhip_pinned_free(void *p);
 int tmhip_field_zero(tmhip_ctx *ctx, tmhip_field *f);
 /* FULL field <-> its two parities (linalg/convert_eo_to_lexic.c) -- views, no copy */
 tmhip_field *tmhip_field_even(tmhip_field *full);

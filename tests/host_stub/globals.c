@@ -74,3 +74,46 @@ su3 *stub_init_clover(int which) {
 int gauge_precision_read_flag = 64;
 int g_disable_IO_checks = 0;
 void stub_set_io(int prec, int disable_checks) { gauge_precision_read_flag = prec; g_disable_IO_checks = disable_checks; }
+
+/* benchmark.c:291-300 as an UNMODIFIED host program runs it: two stencil calls per iteration through the reference's symbol, and
+ * the host reads one number of the last output after each iteration (the reference's guard against the loop being optimised away) */
+typedef struct { double _Complex c[12]; } stub_spinor;
+double stub_benchmark_loop(void (*hop)(int, void *, void *), stub_spinor *f0, stub_spinor *f1, stub_spinor *f2, int iters) {
+  double antioptaway = 0.0;
+  for (int j = 0; j < iters; j++) {
+    hop(0, f1, f0);
+    hop(1, f2, f1);
+    antioptaway += creal(f2[0].c[0]);
+  }
+  return antioptaway;
+}
+/* host code between device calls: scale one spinor in place (a store to a mirrored array) and sum a strided sample of another */
+void stub_host_scale(stub_spinor *f, int site, double a) { for (int k = 0; k < 12; k++) f[site].c[k] *= a; }
+double stub_host_sample(const stub_spinor *f, int n, int stride) {
+  double s = 0.0;
+  for (int i = 0; i < n; i += stride) s += creal(f[i].c[3]) + cimag(f[i].c[7]);
+  return s;
+}
+
+/* host threads reading one array at the same time (an OpenMP loop of the host program over a field): nthreads contiguous chunks */
+#include <pthread.h>
+typedef struct { const stub_spinor *f; int lo, hi; double s; } stub_job;
+static void *stub_sum_job(void *p) {
+  stub_job *j = (stub_job *)p;
+  double s = 0.0;
+  for (int i = j->lo; i < j->hi; i++) for (int k = 0; k < 12; k++) s += creal(j->f[i].c[k]) - cimag(j->f[i].c[k]);
+  j->s = s;
+  return NULL;
+}
+double stub_host_sum_threads(const stub_spinor *f, int n, int nthreads) {
+  pthread_t th[16];
+  stub_job job[16];
+  if (nthreads > 16) nthreads = 16;
+  for (int t = 0; t < nthreads; t++) {
+    job[t].f = f; job[t].lo = (int)((long)n * t / nthreads); job[t].hi = (int)((long)n * (t + 1) / nthreads); job[t].s = 0.0;
+    pthread_create(&th[t], NULL, stub_sum_job, &job[t]);
+  }
+  double s = 0.0;
+  for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); s += job[t].s; }
+  return s;
+}

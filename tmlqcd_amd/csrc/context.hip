@@ -448,6 +448,37 @@ int tmhip_field_download(tmhip_ctx *ctx, tmhip_field *f, void *host, int nsites)
   return tmhip_check_async_error(ctx);
 }
 
+/* page-locked host memory for callers that must keep the runtime away from their own pages (the drop-in's lazy mode: user arrays
+ * whose protection changes must never be registered with the driver) */
+int tmhip_pinned_alloc(unsigned long bytes, void **out) {
+  if (!out) TMHIP_FAIL("tmhip_pinned_alloc: null argument");
+  TMHIP_CHECK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return 0;
+}
+int tmhip_pinned_free(void *p) {
+  if (p) TMHIP_CHECK(hipHostFree(p));
+  return 0;
+}
+// sites [first, first + count) of a one-parity field in the host's AoS layout (the drop-in's page-wise lazy synchronisation)
+__global__ __launch_bounds__(256) void soa_to_aos_range_kernel(const v2d *__restrict__ soa, v2d *__restrict__ aos, int ns, int first, int n) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  if (tid >= 12 * n) return;
+  const int site = tid / 12, c = tid % 12;
+  aos[tid] = soa[(size_t)c * ns + first + site];
+}
+int tmhip_field_download_range(tmhip_ctx *ctx, tmhip_field *f, void *host, int first, int count) {
+  if (!f || !host || f->kind != TMHIP_FIELD_EO || f->prec != 0) TMHIP_FAIL("tmhip_field_download_range: needs a one-parity fp64 field and a host buffer");
+  if (first < 0 || count <= 0 || first + count > ctx->Vh) TMHIP_FAIL("tmhip_field_download_range: sites [%d, %d) outside [0, %d)", first, first + count, ctx->Vh);
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)count * 12 * sizeof(v2d);
+  if (tmhip_stage_reserve(ctx, bytes)) return 1;
+  hipLaunchKernelGGL(soa_to_aos_range_kernel, dim3((12 * count + 255) / 256), dim3(256), 0, ctx->stream, (const v2d *)f->d, (v2d *)ctx->stage, f->ns, first, count);
+  TMHIP_CHECK(hipGetLastError());
+  TMHIP_CHECK(hipMemcpyAsync(host, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------------ stencil entry points
 static int need_eo(const tmhip_field *f, const char *who) {
   if (!f || f->kind != TMHIP_FIELD_EO || f->prec != 0) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity (EO) field\n", who); return 1; }

@@ -13,6 +13,14 @@
 #include <unordered_map>
 #include <vector>
 
+#include <atomic>
+#include <pthread.h>
+#include <signal.h>
+#include <stdint.h>
+#include <sys/mman.h>
+#include <ucontext.h>
+#include <unistd.h>
+
 extern "C" {
 // ---- globals owned by the host program (global.h, boundary.h) ----
 extern int T, LX, LY, LZ, VOLUME, RAND, VOLUMEPLUSRAND;         /* global.h:82-84 */
@@ -52,7 +60,13 @@ struct Mirror {
   bool dev_valid = false;   // device copy holds the current data
   bool host_valid = true;   // host copy holds the current data
   unsigned long long last_use = 0;
+  // lazy mode (TMLQCD_HIP_LAZY): the host array's pages are protected so that the host's own loads and stores say when a copy is needed
+  size_t bytes = 0;         // extent of the host array this mirror stands for
+  int prot = 0;             // P_RW: untouched; P_RO: both copies current, a host store must be noticed; P_NONE: the host copy is stale
+  std::vector<unsigned char> page_ok;   // P_NONE: pages of the span already brought up to date one by one
+  int faults = 0;           // page-wise read synchronisations since the device last wrote the field
 };
+enum { P_RW = 0, P_RO = 1, P_NONE = 2 };
 unsigned long long g_tick = 0;
 size_t g_mirror_cap = 64;   // TMLQCD_HIP_MAX_MIRRORS: host programs that allocate work fields per solve (solver_field.c) would otherwise
                             // grow the registry without bound; mirrors whose host copy is current can be dropped at any time
@@ -75,6 +89,7 @@ tmhip_field *g_full_tmp = nullptr; // FULL-lattice scratch of Q_pm_psi / D_dagg_
 }
 #define CK(call) do { if ((call) != 0) die(#call); } while (0)
 
+void install_lazy_handler();
 tmhip_ctx *ctx() {
   if (!g_ctx) {
     if (g_nproc_x != 1 || g_nproc_y != 1 || g_nproc_z != 1)
@@ -83,6 +98,9 @@ tmhip_ctx *ctx() {
       const char *e = getenv("TMLQCD_HIP_DEVICE");
       g_device = e ? atoi(e) : 0;
     }
+    const char *r = getenv("TMLQCD_HIP_RESIDENCY");       // unmodified executables: TMLQCD_HIP_RESIDENCY=lazy ./benchmark
+    if (r && !strcmp(r, "lazy") && g_mode == TMLQCD_HIP_COHERENT) { install_lazy_handler(); g_mode = TMLQCD_HIP_LAZY; }
+    else if (r && !strcmp(r, "resident") && g_mode == TMLQCD_HIP_COHERENT) g_mode = TMLQCD_HIP_RESIDENT;
     tmhip_geom g = {T, LX, LY, LZ, g_nproc_t < 1 ? 1 : g_nproc_t, g_proc_coords[0]};
     CK(tmhip_create(&g, g_device, &g_ctx));
     g_dims[0] = T; g_dims[1] = LX; g_dims[2] = LY; g_dims[3] = LZ; g_dims[4] = g.nproc_t; g_dims[5] = g.proc_t;
@@ -115,6 +133,76 @@ tmhip_ctx *refresh(bool need_gauge) {
   return c;
 }
 
+// ------------------------------------------------------------------ lazy coherence (TMLQCD_HIP_LAZY)
+// An UNMODIFIED host program keeps its fields in HBM: after a device operation wrote a field, the pages of the host array are made
+// inaccessible; the host's first load from one of them faults, the handler brings that page up to date from the device mirror (a few
+// microseconds: 21 spinors) and lets the load go on -- or the whole field once the host keeps reading (more than LAZY_PAGE_FAULTS pages)
+// or stores to it.  After an upload the pages are read-only, so a host store invalidates the mirror.  benchmark.c's loop (it reads one
+// number of the output per iteration, :291-300) then runs at the resident rate with no source change.  Limits, hence opt-in: the
+// kernel does not raise SIGSEGV for its own accesses -- a field handed to write(2) / MPI while its host copy is stale fails with
+// EFAULT instead of being synchronised (tmlqcd_hip_sync_to_host first); pages shared with neighbouring data are handled, at the price
+// of a synchronisation when that data is touched.
+#define LAZY_PAGE_FAULTS 8
+uintptr_t g_page = 4096;
+struct sigaction g_old_segv;
+bool g_handler_installed = false;
+volatile int g_in_handler = 0;
+unsigned long g_lazy_stats[4] = {0, 0, 0, 0};   // faults served, pages fetched one by one, whole-field fetches, stores noticed (tmlqcd_hip_lazy_stats)
+
+inline uintptr_t span_lo(const void *h) { return (uintptr_t)h & ~(g_page - 1); }
+inline uintptr_t span_hi(const void *h, size_t bytes) { return ((uintptr_t)h + bytes + g_page - 1) & ~(g_page - 1); }
+inline int prot_flags(int p) { return p == P_RW ? (PROT_READ | PROT_WRITE) : (p == P_RO ? PROT_READ : PROT_NONE); }
+// what mirror m asks for page `page` of its span
+inline int page_want(const void *host, const Mirror &m, uintptr_t page) {
+  if (m.prot != P_NONE) return m.prot;
+  const size_t idx = (page - span_lo(host)) / g_page;
+  return idx < m.page_ok.size() && m.page_ok[idx] ? P_RO : P_NONE;
+}
+// the strictest protection any mirror asks for this page (pages at the edge of a field are shared with its neighbours)
+int page_need(uintptr_t page, const std::unordered_map<const void *, Mirror> &reg) {
+  int need = P_RW;
+  for (auto &kv : reg) {
+    const Mirror &m = kv.second;
+    if (m.prot == P_RW || !m.bytes) continue;
+    if (page < span_lo(kv.first) || page >= span_hi(kv.first, m.bytes)) continue;
+    const int w = page_want(kv.first, m, page);
+    if (w > need) need = w;
+  }
+  return need;
+}
+// (re)apply the protection of one mirror's span; interior pages belong to it alone, the two edge pages are negotiated
+void apply_prot(const void *host, Mirror &m, const std::unordered_map<const void *, Mirror> &reg) {
+  if (!m.bytes) return;
+  const uintptr_t lo = span_lo(host), hi = span_hi(host, m.bytes);
+  for (uintptr_t pg = lo; pg < hi; pg += g_page) {
+    const bool edge = pg < (uintptr_t)host || pg + g_page > (uintptr_t)host + m.bytes;
+    if (edge) { mprotect((void *)pg, g_page, prot_flags(page_need(pg, reg))); continue; }
+    // run of interior pages with the same wish
+    const int w = page_want(host, m, pg);
+    uintptr_t end = pg + g_page;
+    while (end < hi && end + g_page <= (uintptr_t)host + m.bytes && page_want(host, m, end) == w) end += g_page;
+    mprotect((void *)pg, end - pg, prot_flags(w));
+    pg = end - g_page;
+  }
+}
+void set_prot(const void *host, Mirror &m, int prot, const std::unordered_map<const void *, Mirror> &reg) {
+  if (m.prot == prot && prot != P_NONE) return;
+  if (m.prot == P_NONE && prot == P_NONE) {
+    // the device wrote the field again while the host copy was already closed: only the pages the host had fetched in between
+    // need closing (none at all in a loop of device calls -- an mprotect over the whole 100 MB span costs milliseconds)
+    if (m.faults == 0) return;
+    const uintptr_t lo = span_lo(host);
+    for (size_t i = 0; i < m.page_ok.size(); i++)
+      if (m.page_ok[i]) { m.page_ok[i] = 0; mprotect((void *)(lo + i * g_page), g_page, prot_flags(page_need(lo + i * g_page, reg))); }
+    m.faults = 0;
+    return;
+  }
+  m.prot = prot;
+  if (prot == P_NONE) { m.page_ok.assign((span_hi(host, m.bytes) - span_lo(host)) / g_page, 0); m.faults = 0; }
+  else m.page_ok.clear();
+  apply_prot(host, m, reg);
+}
+
 int kind_of_N(int N) {
   if (N == VOLUME / 2) return TMHIP_FIELD_EO;
   if (N == VOLUME) return TMHIP_FIELD_FULL;
@@ -135,14 +223,34 @@ Parts parts_of(int kind, int N) {
 
 int nsites(int kind) { return kind == TMHIP_FIELD_FULL ? VOLUME : VOLUME / 2; }
 
+// Lazy mode never lets the runtime touch the program's own pages: a copy from / to pageable memory registers those pages with the
+// driver, and every later mprotect on them goes through its MMU notifier (measured: 28 ms per call instead of microseconds).  Data
+// moves through a page-locked bounce buffer instead; uploads and whole-field downloads are the rare events in this mode.
+void *g_bounce = nullptr;
+size_t g_bounce_bytes = 0;
+void *bounce(size_t bytes) {
+  if (g_bounce_bytes < bytes) {
+    if (g_bounce) tmhip_pinned_free(g_bounce);
+    g_bounce = nullptr; g_bounce_bytes = 0;
+    CK(tmhip_pinned_alloc(bytes, &g_bounce));
+    g_bounce_bytes = bytes;
+  }
+  return g_bounce;
+}
+
 // host <-> device for a mirror of any shape (KIND_LIN: the two halves are plain prefixes, no site permutation)
-void upload(tmhip_ctx *c, const void *host, Mirror &m) {
+void upload(tmhip_ctx *c, const void *host_user, Mirror &m) {
+  const void *host = host_user;
+  if (g_mode == TMLQCD_HIP_LAZY) { void *b = bounce(m.bytes); memcpy(b, host_user, m.bytes); host = b; }
   if (m.kind != KIND_LIN) { CK(tmhip_field_upload(c, m.f, host, nsites(m.kind))); return; }
   const Parts pt = parts_of(KIND_LIN, m.n);
   CK(tmhip_field_upload(c, tmhip_field_even(m.f), host, pt.cnt[0]));
   if (pt.n > 1) CK(tmhip_field_upload(c, tmhip_field_odd(m.f), (const spinor *)host + VOLUME / 2, pt.cnt[1]));
 }
-void download(tmhip_ctx *c, const void *host, Mirror &m) {
+void download(tmhip_ctx *c, const void *host_user, Mirror &m) {
+  if (m.prot != P_RW) mprotect((void *)span_lo(host_user), span_hi(host_user, m.bytes) - span_lo(host_user), PROT_READ | PROT_WRITE);   // lazy mode: the copy below stores to these pages
+  const bool staged = g_mode == TMLQCD_HIP_LAZY || m.prot != P_RW;
+  const void *host = staged ? bounce(m.bytes) : host_user;
   if (m.kind != KIND_LIN) {
     CK(tmhip_field_download(c, m.f, const_cast<void *>(host), nsites(m.kind)));
   } else {
@@ -150,7 +258,14 @@ void download(tmhip_ctx *c, const void *host, Mirror &m) {
     CK(tmhip_field_download(c, tmhip_field_even(m.f), const_cast<void *>(host), pt.cnt[0]));
     if (pt.n > 1) CK(tmhip_field_download(c, tmhip_field_odd(m.f), (spinor *)const_cast<void *>(host) + VOLUME / 2, pt.cnt[1]));
   }
+  if (staged) memcpy(const_cast<void *>(host_user), host, m.bytes);
   m.host_valid = true;
+  if (m.prot != P_RW) { m.prot = -1; set_prot(host_user, m, g_mode == TMLQCD_HIP_LAZY ? P_RO : P_RW, g_reg); }   // both copies current: watch for host stores
+}
+// a mirror is about to go away (or to stop being watched): bring the host up to date and give it its pages back
+void release_host(tmhip_ctx *c, const void *host, Mirror &m) {
+  if (m.f && m.dev_valid && !m.host_valid) download(c, host, m);
+  if (m.prot != P_RW) set_prot(host, m, P_RW, g_reg);
 }
 
 // drop the least recently used mirrors that hold nothing the host does not have
@@ -163,22 +278,38 @@ void evict_if_crowded(tmhip_ctx *c, const void *keep) {
     for (auto &kv : g_reg)
       if (kv.first != keep && kv.second.host_valid && kv.second.last_use < oldest) { oldest = kv.second.last_use; victim = kv.first; }
     if (!victim) return;   // everything else is device-only data (resident mode): keep it
+    release_host(c, victim, g_reg[victim]);
     if (g_reg[victim].f) tmhip_field_free(c, g_reg[victim].f);
     g_reg.erase(victim);
   }
 }
 
 Mirror &mirror(tmhip_ctx *c, const void *host, int kind, int n = 0) {
-  if (g_reg.find(host) == g_reg.end()) evict_if_crowded(c, host);
+  const size_t bytes = (size_t)(kind == KIND_LIN ? n : nsites(kind)) * sizeof(spinor);
+  if (g_reg.find(host) == g_reg.end()) {
+    evict_if_crowded(c, host);
+    if (g_mode == TMLQCD_HIP_LAZY) {
+      // one device mirror per host byte: an array the program now addresses from another base (the halves of a full field, a
+      // block inside a field) must not have a second, independently valid copy of the same bytes in HBM
+      std::vector<const void *> overlap;
+      for (auto &kv : g_reg)
+        if ((uintptr_t)kv.first < (uintptr_t)host + bytes && (uintptr_t)host < (uintptr_t)kv.first + kv.second.bytes) overlap.push_back(kv.first);
+      for (const void *o : overlap) {
+        release_host(c, o, g_reg[o]);
+        if (g_reg[o].f) tmhip_field_free(c, g_reg[o].f);
+        g_reg.erase(o);
+      }
+    }
+  }
   Mirror &m = g_reg[host];
   if (m.f && (m.kind != kind || (kind == KIND_LIN && m.n != n))) {   // same host buffer re-used with another shape (or another prefix length)
-    if (m.dev_valid && !m.host_valid) download(c, host, m);
+    release_host(c, host, m);
     tmhip_field_free(c, m.f);
     m = Mirror();
   }
   if (!m.f) {
     CK(tmhip_field_alloc(c, kind == KIND_LIN ? TMHIP_FIELD_FULL : kind, &m.f));
-    m.kind = kind; m.n = n; m.dev_valid = false; m.host_valid = true;
+    m.kind = kind; m.n = n; m.dev_valid = false; m.host_valid = true; m.bytes = bytes; m.prot = P_RW;
   }
   m.last_use = ++g_tick;   // after the reset above: a mirror in use by the current call must never be the eviction victim of its sibling
   return m;
@@ -191,6 +322,7 @@ tmhip_field *in(tmhip_ctx *c, const void *host, int kind, int n = 0) {
       upload(c, host, m);
     m.dev_valid = true;
   }
+  if (g_mode == TMLQCD_HIP_LAZY && m.host_valid && m.prot == P_RW) set_prot(host, m, P_RO, g_reg);   // the mirror stays good until the host stores to the array
   return m.f;
 }
 
@@ -202,7 +334,75 @@ void done(tmhip_ctx *c, const void *host) {
   if (g_mode == TMLQCD_HIP_COHERENT) {
     download(c, host, m);
     m.dev_valid = false;   // coherent mode: the host copy is the truth (it may be rewritten or its address recycled)
+  } else if (g_mode == TMLQCD_HIP_LAZY) {
+    set_prot(host, m, P_NONE, g_reg);   // the host's next load from the array faults and fetches what it needs
   }
+}
+
+// SIGSEGV on a protected page of a mirrored host array (lazy mode); anything else goes to the handler that was there before
+void lazy_fault(int sig, siginfo_t *si, void *uctx) {
+  const uintptr_t addr = (uintptr_t)si->si_addr, page = addr & ~(g_page - 1);
+  bool ours = false;
+  // Host threads (an OpenMP loop over a stale field) may fault at the same time: one at a time in here.  A fault of the thread that
+  // already is in here would be a bug of this handler: let it crash instead of spinning on itself.
+  static std::atomic<int> lock(0);
+  static pthread_t owner;
+  const bool nested = g_in_handler && pthread_equal(owner, pthread_self());
+  if (g_ctx && si->si_code == SEGV_ACCERR && !nested) {
+    int expected = 0;
+    while (!lock.compare_exchange_weak(expected, 1, std::memory_order_acquire)) expected = 0;
+    owner = pthread_self();
+    g_in_handler = 1;
+    const bool store = (((ucontext_t *)uctx)->uc_mcontext.gregs[REG_ERR] & 2) != 0;
+    for (auto &kv : g_reg) {
+      Mirror &m = kv.second;
+      const void *host = kv.first;
+      if (!m.bytes || page < span_lo(host) || page >= span_hi(host, m.bytes)) continue;
+      ours = true;                                   // (also when another thread has opened the page in the meantime: just run again)
+      if (m.prot == P_RW) continue;
+      if (store) {
+        g_lazy_stats[3]++;                                   // the host is about to change the array: its copy becomes the only good one
+        if (!m.host_valid) download(g_ctx, host, m);
+        m.dev_valid = false;
+        set_prot(host, m, P_RW, g_reg);
+      } else if (m.prot == P_NONE) {
+        const size_t idx = (page - span_lo(host)) / g_page;
+        if (m.page_ok[idx]) continue;                // (the page was closed by a neighbour's wish only)
+        if (m.kind != TMHIP_FIELD_EO || ++m.faults > LAZY_PAGE_FAULTS) {
+          g_lazy_stats[2]++;
+          download(g_ctx, host, m);                  // the host reads on: fetch the rest in one go (both copies stay current, P_RO)
+        } else {
+          const uintptr_t base = (uintptr_t)host, lo = page > base ? page : base, hi = page + g_page < base + m.bytes ? page + g_page : base + m.bytes;
+          const int s0 = (int)((lo - base) / sizeof(spinor)), s1 = (int)((hi - base + sizeof(spinor) - 1) / sizeof(spinor));
+          static void *tmp = nullptr;                 // page-locked: see bounce()
+          if (!tmp) CK(tmhip_pinned_alloc(64 * sizeof(spinor), &tmp));
+          if (tmhip_field_download_range(g_ctx, m.f, tmp, s0, s1 - s0)) die("lazy synchronisation of a page failed");
+          mprotect((void *)page, g_page, PROT_READ | PROT_WRITE);
+          memcpy((void *)lo, (const char *)tmp + (lo - (base + (size_t)s0 * sizeof(spinor))), hi - lo);
+          m.page_ok[idx] = 1;
+          g_lazy_stats[1]++;
+        }
+      }
+    }
+    if (ours) { g_lazy_stats[0]++; mprotect((void *)page, g_page, prot_flags(page_need(page, g_reg))); }
+    g_in_handler = 0;
+    lock.store(0, std::memory_order_release);
+  }
+  if (ours) return;                                  // the faulting instruction runs again
+  if (g_old_segv.sa_flags & SA_SIGINFO) { if (g_old_segv.sa_sigaction) { g_old_segv.sa_sigaction(sig, si, uctx); return; } }
+  else if (g_old_segv.sa_handler != SIG_DFL && g_old_segv.sa_handler != SIG_IGN) { g_old_segv.sa_handler(sig); return; }
+  signal(SIGSEGV, SIG_DFL);                          // not ours, nobody else's: die the ordinary way when the instruction faults again
+}
+void install_lazy_handler() {
+  if (g_handler_installed) return;
+  g_page = (uintptr_t)sysconf(_SC_PAGESIZE);
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_sigaction = lazy_fault;
+  sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+  sigemptyset(&sa.sa_mask);
+  if (sigaction(SIGSEGV, &sa, &g_old_segv)) die("cannot install the SIGSEGV handler of the lazy residency mode");
+  g_handler_installed = true;
 }
 
 tmhip_field *half(tmhip_field *f, int kind, int par) {
@@ -216,8 +416,13 @@ extern "C" {
 
 // ------------------------------------------------------------------ residency control
 void tmlqcd_hip_set_device(int device) { g_device = device; }
+void tmlqcd_hip_lazy_stats(unsigned long out[4]) { for (int k = 0; k < 4; k++) out[k] = g_lazy_stats[k]; }
 void tmlqcd_hip_set_residency(int mode) {
+  if (mode != TMLQCD_HIP_COHERENT && mode != TMLQCD_HIP_RESIDENT && mode != TMLQCD_HIP_LAZY) die("tmlqcd_hip_set_residency: unknown mode");
   if (mode == TMLQCD_HIP_COHERENT && g_mode == TMLQCD_HIP_RESIDENT) tmlqcd_hip_sync_all_to_host();
+  if (g_mode == TMLQCD_HIP_LAZY && mode != TMLQCD_HIP_LAZY)        // leaving lazy mode: every host array current and unwatched again
+    for (auto &kv : g_reg) release_host(ctx(), kv.first, kv.second);
+  if (mode == TMLQCD_HIP_LAZY) install_lazy_handler();
   // whenever the host copy is current it is authoritative: a mirror left over from an earlier call may belong to a
   // host array that has since been rewritten, or to a freed one whose address was recycled
   for (auto &kv : g_reg) if (kv.second.host_valid) kv.second.dev_valid = false;
@@ -234,11 +439,15 @@ void tmlqcd_hip_sync_all_to_host(void) {
 }
 void tmlqcd_hip_host_modified(spinor *field) {
   auto it = g_reg.find(field);
-  if (it != g_reg.end()) { it->second.dev_valid = false; it->second.host_valid = true; }
+  if (it != g_reg.end()) {
+    it->second.dev_valid = false; it->second.host_valid = true;
+    if (it->second.prot != P_RW) set_prot(field, it->second, P_RW, g_reg);
+  }
 }
 void tmlqcd_hip_forget(spinor *field) {
   auto it = g_reg.find(field);
   if (it == g_reg.end()) return;
+  if (it->second.prot != P_RW) { it->second.host_valid = true; set_prot(field, it->second, P_RW, g_reg); }   // (the array is being freed: nothing to fetch)
   if (it->second.f) tmhip_field_free(g_ctx, it->second.f);
   g_reg.erase(it);
 }
@@ -246,9 +455,10 @@ void tmlqcd_hip_comm_init(const char unique_id[128]) { CK(tmhip_comm_init(ctx(),
 void tmlqcd_hip_finalize(void) {
   if (!g_ctx) return;
   tmlqcd_hip_sync_all_to_host();
-  for (auto &kv : g_reg) if (kv.second.f) tmhip_field_free(g_ctx, kv.second.f);
+  for (auto &kv : g_reg) { if (kv.second.prot != P_RW) set_prot(kv.first, kv.second, P_RW, g_reg); if (kv.second.f) tmhip_field_free(g_ctx, kv.second.f); }
   g_reg.clear();
   if (g_full_tmp) { tmhip_field_free(g_ctx, g_full_tmp); g_full_tmp = nullptr; }
+  if (g_bounce) { tmhip_pinned_free(g_bounce); g_bounce = nullptr; g_bounce_bytes = 0; }
   tmhip_destroy(g_ctx);
   g_ctx = nullptr;
   g_gauge_uploaded = false;
@@ -894,7 +1104,7 @@ void deriv_Sb(const int ieo, spinor *const l, spinor *const k, hamiltonian_field
   if (!g_deriv_pending) CK(tmhip_derivative_zero(c));
   CK(tmhip_deriv_Sb(c, ieo, fl, fk, factor));
   g_deriv_pending = true;
-  if (g_mode == TMLQCD_HIP_COHERENT) tmlqcd_hip_flush_derivative(hf);
+  if (g_mode != TMLQCD_HIP_RESIDENT) tmlqcd_hip_flush_derivative(hf);   // (lazy mode watches spinor arrays only)
 }
 /* Clover part of the force under helper names (the reference keeps sw_deriv_nd / sw_spinor in the same objects, which therefore
  * stay on the link line): the statements of cloverdet_derivative, monomial/cloverdet_monomial.c:67-72,125-147 */
@@ -913,7 +1123,7 @@ void tmlqcd_hip_sw_all(hamiltonian_field_t *const hf, const double kappa, const 
   if (!g_deriv_pending) CK(tmhip_derivative_zero(c));
   CK(tmhip_sw_all(c, &hf->gaugefield[0][0], kappa, c_sw));
   g_deriv_pending = true;
-  if (g_mode == TMLQCD_HIP_COHERENT) tmlqcd_hip_flush_derivative(hf);
+  if (g_mode != TMLQCD_HIP_RESIDENT) tmlqcd_hip_flush_derivative(hf);   // (lazy mode watches spinor arrays only)
 }
 void tmlqcd_hip_flush_derivative(hamiltonian_field_t *const hf) {
   if (!g_deriv_pending) return;
@@ -933,7 +1143,7 @@ void tmlqcd_hip_update_gauge(const double step, hamiltonian_field_t *const hf) {
   if (!g_momenta_resident) CK(tmhip_momenta_upload(c, &hf->momenta[0][0]));
   CK(tmhip_update_gauge(c, step));
   g_clover_uploaded = false;
-  if (g_mode == TMLQCD_HIP_COHERENT) {
+  if (g_mode != TMLQCD_HIP_RESIDENT) {
     CK(tmhip_gauge_download(c, &hf->gaugefield[0][0]));
     hf->update_gauge_copy = 1;
     g_update_gauge_copy = 1;
@@ -1032,6 +1242,7 @@ double tmlqcd_hip_benchmark_loop(spinor *f0, spinor *f1, spinor *f2, int iters) 
   g_reg[f2].dev_valid = true; g_reg[f2].host_valid = false;
   g_mode = saved;
   if (g_mode == TMLQCD_HIP_COHERENT) { tmlqcd_hip_sync_to_host(f1); tmlqcd_hip_sync_to_host(f2); }
+  if (g_mode == TMLQCD_HIP_LAZY) { set_prot(f1, g_reg[f1], P_NONE, g_reg); set_prot(f2, g_reg[f2], P_NONE, g_reg); }
   return ms * 1e-3;
 }
 
