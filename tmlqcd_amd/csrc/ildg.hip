@@ -42,17 +42,23 @@ __device__ __forceinline__ size_t ildg_site_index(const IldgGeom &g, size_t f) {
 }
 __device__ __forceinline__ unsigned bswap32(unsigned v) { return __builtin_bswap32(v); }
 
-// CRC-32 of `words` 32-bit words of LDS (memory byte order), DML_crc32(0, buf, 4 * words)
-__device__ __forceinline__ unsigned ildg_crc(const unsigned *w, int words, const unsigned *tab) {
+// CRC-32 of `words` 32-bit words of LDS (memory byte order), DML_crc32(0, buf, 4 * words), four bytes per step ("slicing by 4"):
+// tab[0] is the byte table of DML_crc32.c, tab[k][n] = tab[0][n] advanced by k more zero bytes, so one step is four INDEPENDENT
+// look-ups instead of a chain of four -- the dependent chain of a 576-byte site is 144 LDS round trips, not 576
+__device__ __forceinline__ unsigned ildg_crc(const unsigned *w, int words, const unsigned (*tab)[256]) {
   unsigned c = 0xffffffffu;
   for (int i = 0; i < words; i++) {
-    const unsigned v = w[i];
-    c = tab[(c ^ v) & 0xff] ^ (c >> 8);
-    c = tab[(c ^ (v >> 8)) & 0xff] ^ (c >> 8);
-    c = tab[(c ^ (v >> 16)) & 0xff] ^ (c >> 8);
-    c = tab[(c ^ (v >> 24)) & 0xff] ^ (c >> 8);
+    const unsigned v = c ^ w[i];
+    c = tab[3][v & 0xff] ^ tab[2][(v >> 8) & 0xff] ^ tab[1][(v >> 16) & 0xff] ^ tab[0][v >> 24];
   }
   return c ^ 0xffffffffu;
+}
+__device__ __forceinline__ void ildg_crc_tables(unsigned (*tab)[256], int lane) {
+  for (int n = lane; n < 256; n += ILDG_SITES) {
+    unsigned c = crc_table_entry((unsigned)n);
+    tab[0][n] = c;
+    for (int k = 1; k < 4; k++) { c = crc_table_entry(c & 0xff) ^ (c >> 8); tab[k][n] = c; }
+  }
 }
 // io/dml.c:49-60 for the lane's site, then XOR over the wave and into the two global words
 __device__ __forceinline__ void ildg_checksum_accum(unsigned crc, unsigned long long rank64, bool active, unsigned *sums) {
@@ -69,10 +75,10 @@ __device__ __forceinline__ void ildg_checksum_accum(unsigned crc, unsigned long 
 // file bytes -> lexicographic links [ix][4][9] complex double.  WPS = 32-bit words per file site: 144 (64-bit data) or 72.
 template <int WPS>
 __global__ __launch_bounds__(ILDG_SITES) void ildg_unpack_kernel(const unsigned *__restrict__ file, v2d *__restrict__ raw, IldgGeom g, size_t nsites, unsigned *sums) {
-  __shared__ unsigned tab[256];
+  __shared__ unsigned tab[4][256];
   __shared__ unsigned st[ILDG_SITES * ILDG_STRIDE];
   const int lane = threadIdx.x;
-  for (int n = lane; n < 256; n += ILDG_SITES) tab[n] = crc_table_entry((unsigned)n);
+  ildg_crc_tables(tab, lane);
   const size_t s0 = (size_t)blockIdx.x * ILDG_SITES;
   const int ns = (int)(nsites - s0 < ILDG_SITES ? nsites - s0 : ILDG_SITES);
   // 1. stage: the block's ns * WPS words are contiguous in the file; 16 bytes per lane and step
@@ -112,10 +118,10 @@ __global__ __launch_bounds__(ILDG_SITES) void ildg_unpack_kernel(const unsigned 
 // lexicographic links -> file bytes (io/gauge_write_binary.c:150-175) and their checksum
 template <int WPS>
 __global__ __launch_bounds__(ILDG_SITES) void ildg_pack_kernel(unsigned *__restrict__ file, const v2d *__restrict__ raw, IldgGeom g, size_t nsites, unsigned *sums) {
-  __shared__ unsigned tab[256];
+  __shared__ unsigned tab[4][256];
   __shared__ unsigned st[ILDG_SITES * ILDG_STRIDE];
   const int lane = threadIdx.x;
-  for (int n = lane; n < 256; n += ILDG_SITES) tab[n] = crc_table_entry((unsigned)n);
+  ildg_crc_tables(tab, lane);
   const size_t s0 = (size_t)blockIdx.x * ILDG_SITES;
   const int ns = (int)(nsites - s0 < ILDG_SITES ? nsites - s0 : ILDG_SITES);
   for (int k = lane; k < ns * 36; k += ILDG_SITES) {

@@ -58,6 +58,7 @@ timed("sw_all (owner-computes)", lambda: lat.sw_all(kappa, c_sw), 5)
 lat.momenta_upload(__import__("numpy").zeros((lat.V, 4, 8)))
 timed("update_gauge (exp(step P) U, halo, re-sort)", lambda: lat.update_gauge(0.01), 5)
 timed("update_momenta", lambda: lat.update_momenta(0.01), 5)
+lat.sw_term(None, kappa, c_sw); lat.sw_invert(0, mu)     # the links moved: clover blocks of the new links for the operators below
 for name in ("Qtm_pm_psi", "Mtm_plus_psi", "Mtm_plus_sym_psi", "Qtm_plus_sym_psi", "Mtm_plus_sym_dagg_psi", "Qsw_pm_psi"):
     timed(name, lambda n=name: lat.op(n, c, a), 20)
 
