@@ -143,73 +143,6 @@ __device__ __forceinline__ int lex_index(const LexGeom &g, int t, int x, int y, 
   return t * XYZ + sp;
 }
 
-// F_kl(x) = Q_kl(x) - Q_kl(x)^dagger, Q = sum of the four plaquette leaves (clover_term.c:104-154); plane p = (k,l), k < l
-__global__ __launch_bounds__(128) void sw_leaf_kernel(const v2d *__restrict__ raw, v2d *__restrict__ F, LexGeom g) {
-  const int ix = blockIdx.x * 128 + threadIdx.x;
-  if (ix >= g.V) return;
-  const int p = blockIdx.y;
-  const int k = p < 3 ? 0 : (p < 5 ? 1 : 2), l = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
-  int c[4];
-  int r = ix;
-  c[3] = r % g.LZ; r /= g.LZ; c[2] = r % g.LY; r /= g.LY; c[1] = r % g.LX; c[0] = r / g.LX;
-  auto at = [&](int dk, int dl) {
-    int d[4] = {c[0], c[1], c[2], c[3]};
-    d[k] += dk; d[l] += dl;
-    return lex_index(g, d[0], d[1], d[2], d[3]);
-  };
-  const int xpk = at(1, 0), xpl = at(0, 1), xmk = at(-1, 0), xml = at(0, -1), xpkml = at(1, -1), xplmk = at(-1, 1), xmkml = at(-1, -1);
-  M3 q, v1, v2;
-  v1 = m3_mul<false, false>(m3_load(raw, ix, k), m3_load(raw, xpk, l));
-  v2 = m3_mul<false, false>(m3_load(raw, ix, l), m3_load(raw, xpl, k));
-  q = m3_mul<false, true>(v1, v2);
-  v1 = m3_mul<false, true>(m3_load(raw, ix, l), m3_load(raw, xplmk, k));
-  v2 = m3_mul<true, false>(m3_load(raw, xmk, l), m3_load(raw, xmk, k));
-  m3_acc(q, m3_mul<false, false>(v1, v2));
-  v1 = m3_mul<false, false>(m3_load(raw, xmkml, l), m3_load(raw, xmk, k));
-  v2 = m3_mul<false, false>(m3_load(raw, xmkml, k), m3_load(raw, xml, l));
-  m3_acc(q, m3_mul<true, false>(v1, v2));
-  v1 = m3_mul<true, false>(m3_load(raw, xml, l), m3_load(raw, xml, k));
-  v2 = m3_mul<false, true>(m3_load(raw, xpkml, l), m3_load(raw, ix, k));
-  m3_acc(q, m3_mul<false, false>(v1, v2));
-  v2d *o = F + (size_t)p * 9 * g.V + ix;
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) o[(size_t)(3 * i + j) * g.V] = q.e[3 * i + j] - m3_conj(q.e[3 * j + i]);
-}
-
-// clover_term.c:156-197: E_k = F_0k, B_1 = F_23, B_2 = -F_13, B_3 = F_12 combined into the six 3x3 blocks, written
-// straight into the device layout swd[par][2a+b][e][i].  Planes are stored as p = 0..5 <-> (01,02,03,12,13,23).
-__global__ __launch_bounds__(256) void sw_assemble_kernel(const v2d *__restrict__ F, v2d *__restrict__ d, int gs, int Vh, int V, int LX, int LY,
-                                                          int LZ, int toff, double ka_csw_8) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= Vh) return;
-  const int par = blockIdx.y;
-  const int LZh = LZ / 2;
-  int r = i / LZh;
-  const int y = r % LY;
-  r /= LY;
-  const int x = r % LX, t = r / LX;
-  const int o = (t + x + y + toff + par) & 1;
-  const size_t ix = 2 * (size_t)i + o;
-  v2d *dst = d + (size_t)par * 54 * gs + i;
-#pragma unroll
-  for (int e = 0; e < 9; e++) {
-    const v2d e1 = F[((size_t)0 * 9 + e) * V + ix], e2 = F[((size_t)1 * 9 + e) * V + ix], e3 = F[((size_t)2 * 9 + e) * V + ix];
-    const v2d m3 = F[((size_t)3 * 9 + e) * V + ix], f13 = F[((size_t)4 * 9 + e) * V + ix], m1 = F[((size_t)5 * 9 + e) * V + ix];
-    const v2d m2 = v2d{-f13.x, -f13.y};
-    const double one = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
-    auto itimes = [](v2d a) { return v2d{-a.y, a.x}; };
-    v2d a;
-    a = itimes(e3 - m3);                 dst[(size_t)(0 * 9 + e) * gs] = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y};          // sw[x][0][0]
-    a = itimes(e3 + m3);                 dst[(size_t)(1 * 9 + e) * gs] = v2d{one - ka_csw_8 * a.x, -ka_csw_8 * a.y};         // sw[x][0][1]
-    a = itimes(e1 - m1) + (e2 - m2);     dst[(size_t)(2 * 9 + e) * gs] = v2d{ka_csw_8 * a.x, ka_csw_8 * a.y};                // sw[x][1][0]
-    a = itimes(e1 + m1) + (e2 + m2);     dst[(size_t)(3 * 9 + e) * gs] = v2d{-ka_csw_8 * a.x, -ka_csw_8 * a.y};              // sw[x][1][1]
-    a = itimes(m3 - e3);                 dst[(size_t)(4 * 9 + e) * gs] = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y};          // sw[x][2][0]
-    a = itimes(m3 + e3);                 dst[(size_t)(5 * 9 + e) * gs] = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y};          // sw[x][2][1]
-  }
-}
-
 // clover_invert.c:88-160: 6x6 complex inverse by Householder triangularisation without pivoting, inversion of the
 // triangle in place, then the reflections from the right in reverse order.  Fully unrolled => `a` lives in registers.
 __device__ __forceinline__ int six_invert_dev(v2d (&a)[6][6]) {
@@ -755,6 +688,88 @@ __global__ __launch_bounds__(256) void sw_pack_slabs_kernel(v2d *__restrict__ ou
   for (int m = 0; m < 30; m++) out[((size_t)w * 30 + m) * XYZ + sp] = Wc[(size_t)m * ws + s];
 }
 
+// ------------------------------------------------------------------ sw_term in one kernel
+// (operator/clover_term.c:88-200).  Block = 64 sites of one parity x 6 waves: wave p builds F_kl = Q_kl - Q_kl^dagger of plane
+// p = (01, 02, 03, 12, 13, 23) -- Q = the four plaquette leaves around the site (:104-154), twelve forward links of eight sites,
+// loaded as coalesced SoA planes of the stencil's gauge copy (interior / unsplit) or from the raw links with their halo slabs (the
+// t-faces of a T-split rank) -- the six F meet in LDS (54 KB), and wave b writes block b of sw[x][3][2] = 1 + (kappa c_sw / 8) *
+// combinations of E_k = F_0k, B_1 = F_23, B_2 = -F_13, B_3 = F_12 (:156-197) straight into the device layout swd[par][2a+b][e][i].
+// Round 1 walked the raw AoS links with one thread per (site, plane) and went through a 906 MB F array in HBM: 2.25 + 0.5 ms at 32^4
+// (3.0 ms per call with its allocation); this kernel: 1.26 ms per call.
+#ifndef SWT_MINW
+#define SWT_MINW 2   /* 3 waves per SIMD would fit the LDS but spills (168 VGPRs, 160 B of scratch): 1.77 vs 1.26 ms at 32^4 */
+#endif
+#ifdef SWT_NOSTEP
+#define SWT_STEP()
+#else
+#define SWT_STEP() SW_STEP()
+#endif
+template <class LD>
+__global__ __launch_bounds__(384, LD::min_blocks == 1 ? 1 : SWT_MINW) void sw_term_kernel(const LD ld, v2d *__restrict__ swd, unsigned gs, int LX, int LY, int LZ,
+                                                                                   int i_begin, int i_end, int chunk, double ka_csw_8) {
+  __shared__ v2d F[6][9][64];
+  const int lane = threadIdx.x & 63;
+  const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = blockIdx.x >> 3, sb = (blockIdx.x & 7) * chunk + (q >> 1), par = q & 1, opp = 1 - par;
+  if (sb * 64 >= i_end - i_begin) return;
+  const int i = i_begin + sb * 64 + lane;
+  const bool active = i < i_end;
+  const int LZh = LZ / 2;
+  SwSite x;
+  {
+    const int ii = active ? i : i_begin;
+    int r = ii / LZh;
+    const int kz = ii - r * LZh;
+    x.y = r % LY; r /= LY;
+    x.x = r % LX; x.t = r / LX;
+    x.z = 2 * kz + ((x.t + x.x + x.y + par) & 1);
+  }
+  const int k = p < 3 ? 0 : (p < 5 ? 1 : 2), l = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
+  const SwSite xpk = sw_shift(x, k, 1), xmk = sw_shift(x, k, -1);
+  const typename LD::Loc l0 = ld.locate(x), lpk = ld.locate(xpk), lpl = ld.locate(sw_shift(x, l, 1)), lmk = ld.locate(xmk), lml = ld.locate(sw_shift(x, l, -1));
+  const typename LD::Loc lpkml = ld.locate(sw_shift(xpk, l, -1)), lplmk = ld.locate(sw_shift(xmk, l, 1)), lmkml = ld.locate(sw_shift(xmk, l, -1));
+  M3 Q, v1, v2;
+  v1 = m3_mul<false, false>(ld.link(l0, par, k), ld.link(lpk, opp, l));
+  v2 = m3_mul<false, false>(ld.link(l0, par, l), ld.link(lpl, opp, k));
+  Q = m3_mul<false, true>(v1, v2);
+  SWT_STEP();
+  v1 = m3_mul<false, true>(ld.link(l0, par, l), ld.link(lplmk, par, k));
+  v2 = m3_mul<true, false>(ld.link(lmk, opp, l), ld.link(lmk, opp, k));
+  m3_acc(Q, m3_mul<false, false>(v1, v2));
+  SWT_STEP();
+  v1 = m3_mul<false, false>(ld.link(lmkml, par, l), ld.link(lmk, opp, k));
+  v2 = m3_mul<false, false>(ld.link(lmkml, par, k), ld.link(lml, opp, l));
+  m3_acc(Q, m3_mul<true, false>(v1, v2));
+  SWT_STEP();
+  v1 = m3_mul<true, false>(ld.link(lml, opp, l), ld.link(lml, opp, k));
+  v2 = m3_mul<false, true>(ld.link(lpkml, par, l), ld.link(l0, par, k));
+  m3_acc(Q, m3_mul<false, false>(v1, v2));
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) F[p][3 * a + b][lane] = Q.e[3 * a + b] - m3_conj(Q.e[3 * b + a]);
+  __syncthreads();
+  if (!active) return;
+  v2d *dst = swd + ((size_t)par * 54 + (size_t)p * 9) * gs + i;      // wave p writes block p = 2a + b of sw[x][a][b]
+  auto itimes = [](v2d a) { return v2d{-a.y, a.x}; };
+#pragma unroll
+  for (int e = 0; e < 9; e++) {
+    const v2d e1 = F[0][e][lane], e2 = F[1][e][lane], e3 = F[2][e][lane], m3 = F[3][e][lane], f13 = F[4][e][lane], m1 = F[5][e][lane];
+    const v2d m2 = v2d{-f13.x, -f13.y};
+    const double one = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+    v2d a, r;
+    switch (p) {
+      case 0: a = itimes(e3 - m3);             r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][0][0]
+      case 1: a = itimes(e3 + m3);             r = v2d{one - ka_csw_8 * a.x, -ka_csw_8 * a.y}; break;    // sw[x][0][1]
+      case 2: a = itimes(e1 - m1) + (e2 - m2); r = v2d{ka_csw_8 * a.x, ka_csw_8 * a.y}; break;           // sw[x][1][0]
+      case 3: a = itimes(e1 + m1) + (e2 + m2); r = v2d{-ka_csw_8 * a.x, -ka_csw_8 * a.y}; break;         // sw[x][1][1]
+      case 4: a = itimes(m3 - e3);             r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][2][0]
+      default: a = itimes(m3 + e3);            r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][2][1]
+    }
+    dst[(size_t)((unsigned)e * gs)] = r;
+  }
+}
+
 static int need64(const tmhip_field *f, const char *who) {
   if (!f || f->kind != TMHIP_FIELD_EO || f->prec != 0) { fprintf(stderr, "[tmlqcd_hip] %s: needs a one-parity fp64 field\n", who); return 1; }
   return 0;
@@ -827,23 +842,35 @@ int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c
   if (!gauge_host && !(ctx->gauge_raw && ctx->gauge_raw_valid)) TMHIP_FAIL("tmhip_sw_term: null gauge field and no links resident on the device");
   TMHIP_CHECK(hipSetDevice(ctx->device));
   if (clover_alloc(ctx)) return 1;
-  const size_t gbytes = (size_t)ctx->VPR * 4 * 9 * sizeof(v2d), fbytes = (size_t)6 * 9 * ctx->V * sizeof(v2d);
-  void *F = nullptr;
-  if (!ctx->gauge_raw) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge_raw, gbytes));   // kept: the clover force (tmhip_sw_all) walks the same links
-  void *raw = ctx->gauge_raw;
-  TMHIP_CHECK(hipMalloc(&F, fbytes));
+  const size_t gbytes = (size_t)ctx->VPR * 4 * 9 * sizeof(v2d);
+  if (!ctx->gauge_raw) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge_raw, gbytes));   // kept: the clover force (tmhip_sw_all) and the t-faces of split ranks walk these links
   if (gauge_host) {   // NULL: the links tmhip_set_gauge / tmhip_update_gauge left in HBM
-    TMHIP_CHECK(hipMemcpyAsync(raw, gauge_host, gbytes, hipMemcpyHostToDevice, ctx->stream));
-    ctx->gauge_copy_current = false;   // (re-sorted when the clover force next needs the stencil's copy of these links)
+    TMHIP_CHECK(hipMemcpyAsync(ctx->gauge_raw, gauge_host, gbytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->gauge_copy_current = false;
+    ctx->gauge_raw_valid = true;
   }
-  LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, ctx->g.nproc_t > 1 ? 1 : 0};
-  hipLaunchKernelGGL(sw_leaf_kernel, dim3((ctx->V + 127) / 128, 6), dim3(128), 0, ctx->stream, (const v2d *)raw, (v2d *)F, g);
-  hipLaunchKernelGGL(sw_assemble_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (const v2d *)F, ctx->sw, ctx->gs, ctx->Vh,
-                     ctx->V, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.proc_t * ctx->g.T, kappa * c_sw / 8.);
+  const bool split = ctx->g.nproc_t > 1;
+  const int ib = split ? ctx->face : 0, ie = split ? ctx->Vh - ctx->face : ctx->Vh;      // sites whose plaquettes stay on this rank
+  const double c = kappa * c_sw / 8.;
+  if (ie > ib && (!split || ctx->g.T > 2)) {
+    if (!ctx->gauge_copy_current && tmhip_resort_gauge(ctx)) return 1;     // the SoA planes the interior reads must come from these links
+    const SwFastLd ld{ctx->gauge, (unsigned)ctx->gs, nullptr, 0u, ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->Vh};
+    const int chunk = ((ie - ib + 63) / 64 + 7) / 8;
+    hipLaunchKernelGGL((sw_term_kernel<SwFastLd>), dim3(chunk * 16), dim3(384), 0, ctx->stream, ld, ctx->sw, (unsigned)ctx->gs, ctx->g.LX, ctx->g.LY, ctx->g.LZ,
+                       ib, ie, chunk, c);
+  }
+  if (split) {
+    LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, 1};
+    const SwEdgeLd ld{(const v2d *)ctx->gauge_raw, nullptr, 0u, nullptr, g, ctx->Vh};
+    const int chunk = ((ctx->face + 63) / 64 + 7) / 8;
+    for (int w = 0; w < (ctx->g.T > 1 ? 2 : 1); w++) {
+      const int fb = w ? ctx->Vh - ctx->face : 0;
+      hipLaunchKernelGGL((sw_term_kernel<SwEdgeLd>), dim3(chunk * 16), dim3(384), 0, ctx->stream, ld, ctx->sw, (unsigned)ctx->gs, ctx->g.LX, ctx->g.LY, ctx->g.LZ,
+                         fb, fb + ctx->face, chunk, c);
+    }
+  }
   TMHIP_CHECK(hipGetLastError());
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
-  TMHIP_CHECK(hipFree(F));
-  ctx->gauge_raw_valid = true;
   ctx->sw_set = true;
   ctx->clover_set = false;     // sw_inv no longer matches
   ctx->clover32_set = false;
