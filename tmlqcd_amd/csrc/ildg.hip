@@ -5,9 +5,8 @@
 // g_gauge_field[g_ipt[t][x][y][z]][mu]) and accumulates the SciDAC checksum over the file bytes of every site (io/dml.c:49-60:
 // CRC-32 of the site's bytes, rotated by rank % 29 and rank % 31, XOR-ed over sites).  Here the record's bytes go to the device as
 // they lie in the file and ONE kernel does the rest in HBM: byte swap, precision conversion, the x <-> z transposition into the
-// lexicographic order of g_gauge_field, the link rotation, and the checksum -- byte work bound by HBM, so a wave stages 64 file
-// sites (36 KB, read as 1 KiB coalesced rows) in LDS, every lane then walks ITS site's bytes for the CRC (site stride 145 words:
-// conflict-free), and the 64 x 36 complex numbers leave LDS in flat order so that the stores are whole 576-byte link records.
+// lexicographic order of g_gauge_field, the link rotation, and the checksum -- byte work bound by HBM: whole 1 KiB rows in and out,
+// a lane owns one 144-byte link in between, the per-site CRC is assembled from the four link CRCs (see below).
 // The write path is the mirror image.  The LIME container is framed on the host by a reader / writer written from the published
 // format of c-lime 1.3.x (not part of the reference tree, not installed here): 144-byte record headers
 //   0: magic 0x456789ab (be32)  4: version 1 (be16)  6: MB 0x80 | ME 0x40  8: data length (be64)  16: type, 128 bytes, NUL-padded
@@ -26,10 +25,10 @@ __host__ __device__ inline unsigned crc_table_entry(unsigned n) {
   return c;
 }
 
-#define ILDG_SITES 64          /* file sites per block = one wave */
-#define ILDG_STRIDE 145        /* words per staged site (144 data words + 1: odd stride, lanes hit different banks) */
+#define ILDG_BS 256            /* threads per block = 4 waves x 16 file sites x 4 links */
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 struct IldgGeom { int T, LX, LY, LZ; unsigned long long rank0; };   // local extents; DML rank of this rank's first file site
 
 // lexicographic index ((t LX + x) LY + y) LZ + z of the f-th site of the file order ((t LZ + z) LY + y) LX + x
@@ -42,114 +41,184 @@ __device__ __forceinline__ size_t ildg_site_index(const IldgGeom &g, size_t f) {
 }
 __device__ __forceinline__ unsigned bswap32(unsigned v) { return __builtin_bswap32(v); }
 
-// CRC-32 of `words` 32-bit words of LDS (memory byte order), DML_crc32(0, buf, 4 * words), four bytes per step ("slicing by 4"):
-// tab[0] is the byte table of DML_crc32.c, tab[k][n] = tab[0][n] advanced by k more zero bytes, so one step is four INDEPENDENT
-// look-ups instead of a chain of four -- the dependent chain of a 576-byte site is 144 LDS round trips, not 576
-__device__ __forceinline__ unsigned ildg_crc(const unsigned *w, int words, const unsigned (*tab)[256]) {
-  unsigned c = 0xffffffffu;
-  for (int i = 0; i < words; i++) {
-    const unsigned v = c ^ w[i];
-    c = tab[3][v & 0xff] ^ tab[2][(v >> 8) & 0xff] ^ tab[1][(v >> 16) & 0xff] ^ tab[0][v >> 24];
-  }
-  return c ^ 0xffffffffu;
+// A wave owns 16 consecutive file sites = 64 links = 9216 contiguous bytes of a 64-bit record, a lane ONE link: file link j (x, y, z,
+// t) of site f is the chunk of 144 bytes (72 for 32-bit data) at (4 f + j) chunks and becomes g_gauge_field[ix][mu], mu = (j + 1) % 4
+// (gauge_read_binary.c:187-190).  Global memory is only touched in whole 1 KiB rows: the wave's part of the record goes through a
+// private 9 KB LDS region (nine 16-byte steps in, each lane then takes its own 144 bytes out of it: lane stride 36 words, conflict-
+// free for 16-byte reads), the converted numbers go back into the region in the order of the destination, and leave it in flat
+// order again, so that the stores are whole 576-byte site records (the x <-> z transposition moves whole sites).
+// Checksum: DML_crc32 over a site's bytes = its four link chunks in order.  CRC(A || B) = Z_|B|(CRC(A)) xor CRC(B), Z_n = the
+// CRC register advanced by n zero bytes (linear over GF(2): a 32 x 32 bit matrix), so lane j computes the CRC of its chunk (four
+// bytes per step, four independent table look-ups: "slicing by 4"), applies Z_chunk (3 - j) times and the four lanes of a site
+// XOR their results; the site's rank rotations and the XOR over sites follow io/dml.c:49-60.
+#define ILDG_WSITES 16                         /* file sites per wave */
+#define ILDG_SLOTS 1024                        /* checksum accumulators (pairs of words) the waves spread their atomics over */
+struct IldgLds { unsigned tab[4][256]; unsigned zop[32]; v4u region[ILDG_BS / 64][ILDG_WSITES * 36]; };
+// the tables are compile-time constants (building them per block -- above all the 144 dependent steps of the zero operator -- cost a
+// quarter of the kernel); a block copies them from constant memory into LDS, where 64 lanes can index them independently
+struct IldgConst { unsigned tab[4][256]; unsigned zop[2][32]; };     // zop[0]: 144 zero bytes (64-bit links), zop[1]: 72 (32-bit)
+constexpr unsigned crc_entry_c(unsigned n) {
+  unsigned c = n;
+  for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+  return c;
 }
-__device__ __forceinline__ void ildg_crc_tables(unsigned (*tab)[256], int lane) {
-  for (int n = lane; n < 256; n += ILDG_SITES) {
-    unsigned c = crc_table_entry((unsigned)n);
-    tab[0][n] = c;
-    for (int k = 1; k < 4; k++) { c = crc_table_entry(c & 0xff) ^ (c >> 8); tab[k][n] = c; }
+constexpr IldgConst ildg_make_const() {
+  IldgConst t{};
+  for (unsigned n = 0; n < 256; n++) {
+    unsigned c = crc_entry_c(n);
+    t.tab[0][n] = c;
+    for (int k = 1; k < 4; k++) { c = crc_entry_c(c & 0xff) ^ (c >> 8); t.tab[k][n] = c; }
   }
+  for (int w = 0; w < 2; w++)
+    for (unsigned b = 0; b < 32; b++) {
+      unsigned c = 1u << b;
+      for (int n = 0; n < (w ? 72 : 144); n++) c = t.tab[0][c & 0xff] ^ (c >> 8);
+      t.zop[w][b] = c;
+    }
+  return t;
 }
-// io/dml.c:49-60 for the lane's site, then XOR over the wave and into the two global words
-__device__ __forceinline__ void ildg_checksum_accum(unsigned crc, unsigned long long rank64, bool active, unsigned *sums) {
+__constant__ IldgConst c_ildg = ildg_make_const();
+__device__ __forceinline__ void ildg_tables(IldgLds &L, int chunk_bytes) {
+  for (int n = threadIdx.x; n < 1024; n += ILDG_BS) (&L.tab[0][0])[n] = (&c_ildg.tab[0][0])[n];
+  if (threadIdx.x < 32) L.zop[threadIdx.x] = c_ildg.zop[chunk_bytes == 144 ? 0 : 1][threadIdx.x];
+  __syncthreads();
+}
+__device__ __forceinline__ unsigned ildg_crc_step(unsigned c, unsigned w, const IldgLds &L) {
+  const unsigned v = c ^ w;
+  return L.tab[3][v & 0xff] ^ L.tab[2][(v >> 8) & 0xff] ^ L.tab[1][(v >> 16) & 0xff] ^ L.tab[0][v >> 24];
+}
+__device__ __forceinline__ unsigned ildg_zero_op(unsigned c, const IldgLds &L) {
+  unsigned r = 0;
+#pragma unroll 8
+  for (int b = 0; b < 32; b++) r ^= ((c >> b) & 1u) ? L.zop[b] : 0u;
+  return r;
+}
+// chunk CRC of lane j (already final, i.e. with DML_crc32's pre / post inversion) -> site CRC in the site's four lanes -> checksum words
+__device__ __forceinline__ void ildg_checksum_accum(unsigned crc, int j, unsigned long long rank64, bool active, const IldgLds &L, unsigned *sums) {
+  if (j < 3) crc = ildg_zero_op(crc, L);
+  if (j < 2) crc = ildg_zero_op(crc, L);
+  if (j < 1) crc = ildg_zero_op(crc, L);
+  crc ^= __shfl_xor(crc, 1, 64);
+  crc ^= __shfl_xor(crc, 2, 64);               // every lane of the site now holds DML_crc32(0, site bytes)
   const unsigned rank = (unsigned)rank64;      // DML_SiteRank is uint32_t (io/dml.h:40)
   const unsigned r29 = rank % 29, r31 = rank % 31;
-  unsigned a = active ? (crc << r29 | crc >> (32 - r29)) : 0u, b = active ? (crc << r31 | crc >> (32 - r31)) : 0u;   // (rank % 29 == 0: x >> 32 is x on this
-  if (active && r29 == 0) a = crc;                                                                                 //  target too, but do not rely on it)
-  if (active && r31 == 0) b = crc;
+  const bool lead = active && j == 0;
+  unsigned a = lead ? (r29 ? (crc << r29 | crc >> (32 - r29)) : crc) : 0u, b = lead ? (r31 ? (crc << r31 | crc >> (32 - r31)) : crc) : 0u;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { a ^= __shfl_xor(a, off, 64); b ^= __shfl_xor(b, off, 64); }
-  if ((threadIdx.x & 63) == 0) { atomicXor(sums, a); atomicXor(sums + 1, b); }
+  // XOR is associative and commutative: any order gives the same words.  One address would serialise the atomics of all waves
+  // (measured: 131 072 atomics on one word = 1.5 ms, the whole kernel): ILDG_SLOTS pairs, folded on the host.
+  if ((threadIdx.x & 63) == 0) {
+    unsigned *slot = sums + 2 * ((blockIdx.x * (ILDG_BS / 64) + (threadIdx.x >> 6)) & (ILDG_SLOTS - 1));
+    atomicXor(slot, a); atomicXor(slot + 1, b);
+  }
 }
 
 // file bytes -> lexicographic links [ix][4][9] complex double.  WPS = 32-bit words per file site: 144 (64-bit data) or 72.
 template <int WPS>
-__global__ __launch_bounds__(ILDG_SITES) void ildg_unpack_kernel(const unsigned *__restrict__ file, v2d *__restrict__ raw, IldgGeom g, size_t nsites, unsigned *sums) {
-  __shared__ unsigned tab[4][256];
-  __shared__ unsigned st[ILDG_SITES * ILDG_STRIDE];
-  const int lane = threadIdx.x;
-  ildg_crc_tables(tab, lane);
-  const size_t s0 = (size_t)blockIdx.x * ILDG_SITES;
-  const int ns = (int)(nsites - s0 < ILDG_SITES ? nsites - s0 : ILDG_SITES);
-  // 1. stage: the block's ns * WPS words are contiguous in the file; 16 bytes per lane and step
-  const v4u *src = reinterpret_cast<const v4u *>(file + s0 * WPS);
-  const int nq = ns * WPS / 4;
-  for (int q = lane; q < nq; q += ILDG_SITES) {
-    const v4u v = __builtin_nontemporal_load(src + q);
-    const int w = 4 * q, s = w / WPS, o = w - s * WPS;     // (WPS % 4 == 0: the four words stay in one site)
-    unsigned *d = st + s * ILDG_STRIDE + o;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+__global__ __launch_bounds__(ILDG_BS) void ildg_unpack_kernel(const unsigned *__restrict__ file, v2d *__restrict__ raw, IldgGeom g, size_t nsites, unsigned *sums) {
+  __shared__ IldgLds L;
+  ildg_tables(L, WPS);                         // chunk = WPS / 4 words = WPS bytes
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 3;
+  const size_t f0 = ((size_t)blockIdx.x * (ILDG_BS / 64) + wv) * ILDG_WSITES, f = f0 + (lane >> 2);
+  const int ns = f0 >= nsites ? 0 : (int)(nsites - f0 < ILDG_WSITES ? nsites - f0 : ILDG_WSITES);
+  const bool active = (lane >> 2) < ns;
+  v4u *R = L.region[wv];
+  // 1. the wave's part of the record, whole rows: ns * WPS words
+  {
+    const int nq = ns * WPS / 4;               // 16-byte pieces
+    const v4u *src = reinterpret_cast<const v4u *>(file + f0 * WPS);
+    for (int q = lane; q < nq; q += 64) R[q] = __builtin_nontemporal_load(src + q);
   }
   __syncthreads();
-  // 2. checksum: every lane its own site, over the bytes as they lie in the file
-  {
-    const bool active = lane < ns;
-    const unsigned crc = active ? ildg_crc(st + lane * ILDG_STRIDE, WPS, tab) : 0u;
-    ildg_checksum_accum(crc, g.rank0 + s0 + lane, active, sums);
-  }
-  // 3. unpack in flat order: 36 complex numbers per site; file link j (x, y, z, t) is mu = (j + 1) % 4 (gauge_read_binary.c:187-190)
-  for (int k = lane; k < ns * 36; k += ILDG_SITES) {
-    const int s = k / 36, e = k - s * 36, j = e / 9, c = e - j * 9;
-    const unsigned *w = st + s * ILDG_STRIDE;
-    v2d val;
+  // 2. every lane its link: CRC over the file bytes, conversion
+  unsigned crc = 0xffffffffu;
+  v2d u[9];
+  if (active) {
     if (WPS == 144) {
-      const unsigned *p = w + 4 * e;
-      const unsigned long long re = ((unsigned long long)bswap32(p[0]) << 32) | bswap32(p[1]), im = ((unsigned long long)bswap32(p[2]) << 32) | bswap32(p[3]);
-      val = v2d{__longlong_as_double((long long)re), __longlong_as_double((long long)im)};
+      const v4u *p = R + lane * 9;
+#pragma unroll
+      for (int e = 0; e < 9; e++) {
+        const v4u w = p[e];
+        crc = ildg_crc_step(ildg_crc_step(ildg_crc_step(ildg_crc_step(crc, w.x, L), w.y, L), w.z, L), w.w, L);
+        const unsigned long long re = ((unsigned long long)bswap32(w.x) << 32) | bswap32(w.y), im = ((unsigned long long)bswap32(w.z) << 32) | bswap32(w.w);
+        u[e] = v2d{__longlong_as_double((long long)re), __longlong_as_double((long long)im)};
+      }
     } else {
-      const unsigned *p = w + 2 * e;
-      val = v2d{(double)__uint_as_float(bswap32(p[0])), (double)__uint_as_float(bswap32(p[1]))};   // be_to_cpu_assign_single2double
+      const v2u *p = reinterpret_cast<const v2u *>(R) + lane * 9;
+#pragma unroll
+      for (int e = 0; e < 9; e++) {
+        const v2u w = p[e];
+        crc = ildg_crc_step(ildg_crc_step(crc, w.x, L), w.y, L);
+        u[e] = v2d{(double)__uint_as_float(bswap32(w.x)), (double)__uint_as_float(bswap32(w.y))};   // be_to_cpu_assign_single2double
+      }
     }
-    const size_t ix = ildg_site_index(g, s0 + s);
-    raw[(ix * 4 + ((j + 1) & 3)) * 9 + c] = val;
+  }
+  ildg_checksum_accum(crc ^ 0xffffffffu, j, g.rank0 + f, active, L, sums);
+  __syncthreads();                             // every lane has taken its bytes: the region now receives the destination order
+  if (active) {
+    v2d *o = reinterpret_cast<v2d *>(R) + ((lane >> 2) * 4 + ((j + 1) & 3)) * 9;
+#pragma unroll
+    for (int e = 0; e < 9; e++) o[e] = u[e];
+  }
+  __syncthreads();
+  // 3. whole 576-byte site records out
+  for (int k = lane; k < ns * 36; k += 64) {
+    const int s = k / 36, e = k - s * 36;
+    raw[ildg_site_index(g, f0 + s) * 36 + e] = reinterpret_cast<const v2d *>(R)[k];
   }
 }
 
 // lexicographic links -> file bytes (io/gauge_write_binary.c:150-175) and their checksum
 template <int WPS>
-__global__ __launch_bounds__(ILDG_SITES) void ildg_pack_kernel(unsigned *__restrict__ file, const v2d *__restrict__ raw, IldgGeom g, size_t nsites, unsigned *sums) {
-  __shared__ unsigned tab[4][256];
-  __shared__ unsigned st[ILDG_SITES * ILDG_STRIDE];
-  const int lane = threadIdx.x;
-  ildg_crc_tables(tab, lane);
-  const size_t s0 = (size_t)blockIdx.x * ILDG_SITES;
-  const int ns = (int)(nsites - s0 < ILDG_SITES ? nsites - s0 : ILDG_SITES);
-  for (int k = lane; k < ns * 36; k += ILDG_SITES) {
-    const int s = k / 36, e = k - s * 36, j = e / 9, c = e - j * 9;
-    const size_t ix = ildg_site_index(g, s0 + s);
-    const v2d val = raw[(ix * 4 + ((j + 1) & 3)) * 9 + c];
-    unsigned *w = st + s * ILDG_STRIDE;
-    if (WPS == 144) {
-      const unsigned long long re = (unsigned long long)__double_as_longlong(val.x), im = (unsigned long long)__double_as_longlong(val.y);
-      unsigned *p = w + 4 * e;
-      p[0] = bswap32((unsigned)(re >> 32)); p[1] = bswap32((unsigned)re); p[2] = bswap32((unsigned)(im >> 32)); p[3] = bswap32((unsigned)im);
-    } else {
-      unsigned *p = w + 2 * e;
-      p[0] = bswap32(__float_as_uint((float)val.x)); p[1] = bswap32(__float_as_uint((float)val.y));   // be_to_cpu_assign_double2single
+__global__ __launch_bounds__(ILDG_BS) void ildg_pack_kernel(unsigned *__restrict__ file, const v2d *__restrict__ raw, IldgGeom g, size_t nsites, unsigned *sums) {
+  __shared__ IldgLds L;
+  ildg_tables(L, WPS);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 3;
+  const size_t f0 = ((size_t)blockIdx.x * (ILDG_BS / 64) + wv) * ILDG_WSITES, f = f0 + (lane >> 2);
+  const int ns = f0 >= nsites ? 0 : (int)(nsites - f0 < ILDG_WSITES ? nsites - f0 : ILDG_WSITES);
+  const bool active = (lane >> 2) < ns;
+  v4u *R = L.region[wv];
+  // 1. whole site records in, into the order of the file (link mu -> file link (mu + 3) % 4)
+  for (int k = lane; k < ns * 36; k += 64) {
+    const int s = k / 36, e = k - s * 36, mu = e / 9, c = e - mu * 9;
+    reinterpret_cast<v2d *>(R)[s * 36 + ((mu + 3) & 3) * 9 + c] = raw[ildg_site_index(g, f0 + s) * 36 + e];
+  }
+  __syncthreads();
+  // 2. every lane its link: conversion, CRC over the bytes that go to the file
+  unsigned crc = 0xffffffffu;
+  v4u w4[9];
+  v2u w2[9];
+  if (active) {
+    const v2d *p = reinterpret_cast<const v2d *>(R) + lane * 9;
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+      const v2d val = p[e];
+      if (WPS == 144) {
+        const unsigned long long re = (unsigned long long)__double_as_longlong(val.x), im = (unsigned long long)__double_as_longlong(val.y);
+        w4[e] = v4u{bswap32((unsigned)(re >> 32)), bswap32((unsigned)re), bswap32((unsigned)(im >> 32)), bswap32((unsigned)im)};
+        crc = ildg_crc_step(ildg_crc_step(ildg_crc_step(ildg_crc_step(crc, w4[e].x, L), w4[e].y, L), w4[e].z, L), w4[e].w, L);
+      } else {
+        w2[e] = v2u{bswap32(__float_as_uint((float)val.x)), bswap32(__float_as_uint((float)val.y))};   // be_to_cpu_assign_double2single
+        crc = ildg_crc_step(ildg_crc_step(crc, w2[e].x, L), w2[e].y, L);
+      }
+    }
+  }
+  ildg_checksum_accum(crc ^ 0xffffffffu, j, g.rank0 + f, active, L, sums);
+  __syncthreads();                             // (32-bit data: the packed words of a lane land where another lane's input lay)
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+      if (WPS == 144) R[lane * 9 + e] = w4[e];
+      else reinterpret_cast<v2u *>(R)[lane * 9 + e] = w2[e];
     }
   }
   __syncthreads();
+  // 3. the wave's part of the record, whole rows
   {
-    const bool active = lane < ns;
-    const unsigned crc = active ? ildg_crc(st + lane * ILDG_STRIDE, WPS, tab) : 0u;
-    ildg_checksum_accum(crc, g.rank0 + s0 + lane, active, sums);
-  }
-  v4u *dst = reinterpret_cast<v4u *>(file + s0 * WPS);
-  const int nq = ns * WPS / 4;
-  for (int q = lane; q < nq; q += ILDG_SITES) {
-    const int w = 4 * q, s = w / WPS, o = w - s * WPS;
-    const unsigned *d = st + s * ILDG_STRIDE + o;
-    dst[q] = v4u{d[0], d[1], d[2], d[3]};
+    const int nq = ns * WPS / 4;
+    v4u *dst = reinterpret_cast<v4u *>(file + f0 * WPS);
+    for (int q = lane; q < nq; q += 64) dst[q] = R[q];
   }
 }
 
@@ -227,8 +296,17 @@ bool xml_value(const std::string &msg, const char *tag, std::string &val) {
 }
 
 int sums_reserve(tmhip_ctx *ctx) {
-  if (!ctx->io_sums) TMHIP_CHECK(hipMalloc((void **)&ctx->io_sums, 2 * sizeof(unsigned)));
-  TMHIP_CHECK(hipMemsetAsync(ctx->io_sums, 0, 2 * sizeof(unsigned), ctx->stream));
+  if (!ctx->io_sums) TMHIP_CHECK(hipMalloc((void **)&ctx->io_sums, 2 * ILDG_SLOTS * sizeof(unsigned)));
+  TMHIP_CHECK(hipMemsetAsync(ctx->io_sums, 0, 2 * ILDG_SLOTS * sizeof(unsigned), ctx->stream));
+  return 0;
+}
+// the checksum words of the launch that has just been enqueued (synchronises the stream)
+int sums_fetch(tmhip_ctx *ctx, unsigned out[2]) {
+  static unsigned h[2 * ILDG_SLOTS];
+  TMHIP_CHECK(hipMemcpyAsync(h, ctx->io_sums, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  out[0] = out[1] = 0;
+  for (int k = 0; k < ILDG_SLOTS; k++) { out[0] ^= h[2 * k]; out[1] ^= h[2 * k + 1]; }
   return 0;
 }
 IldgGeom io_geom(const tmhip_ctx *ctx) {
@@ -249,17 +327,16 @@ int tmhip_gauge_unpack_ildg(tmhip_ctx *ctx, const void *file_bytes, int prec, un
   if (tmhip_stage_reserve(ctx, fbytes) || sums_reserve(ctx)) return 1;
   if (!ctx->gauge_raw) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge_raw, gbytes));
   TMHIP_CHECK(hipMemcpyAsync(ctx->stage, file_bytes, fbytes, hipMemcpyHostToDevice, ctx->stream));
-  const dim3 grid((unsigned)((nsites + ILDG_SITES - 1) / ILDG_SITES));
-  if (prec == 64) hipLaunchKernelGGL(ildg_unpack_kernel<144>, grid, dim3(ILDG_SITES), 0, ctx->stream, (const unsigned *)ctx->stage, ctx->gauge_raw, io_geom(ctx), nsites, ctx->io_sums);
-  else hipLaunchKernelGGL(ildg_unpack_kernel<72>, grid, dim3(ILDG_SITES), 0, ctx->stream, (const unsigned *)ctx->stage, ctx->gauge_raw, io_geom(ctx), nsites, ctx->io_sums);
+  const dim3 grid((unsigned)((nsites + ILDG_BS / 4 - 1) / (ILDG_BS / 4)));
+  if (prec == 64) hipLaunchKernelGGL(ildg_unpack_kernel<144>, grid, dim3(ILDG_BS), 0, ctx->stream, (const unsigned *)ctx->stage, ctx->gauge_raw, io_geom(ctx), nsites, ctx->io_sums);
+  else hipLaunchKernelGGL(ildg_unpack_kernel<72>, grid, dim3(ILDG_BS), 0, ctx->stream, (const unsigned *)ctx->stage, ctx->gauge_raw, io_geom(ctx), nsites, ctx->io_sums);
   TMHIP_CHECK(hipGetLastError());
   ctx->gauge_raw_valid = true;
   if (ctx->g.nproc_t > 1 && tmhip_exchange_gauge_halo(ctx)) return 1;
   ctx->sw_set = false; ctx->clover_set = false; ctx->clover32_set = false;      // clover blocks belong to the old links
   if (tmhip_resort_gauge(ctx)) return 1;
   unsigned h[2];
-  TMHIP_CHECK(hipMemcpyAsync(h, ctx->io_sums, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (sums_fetch(ctx, h)) return 1;
   if (sums) { sums[0] = h[0]; sums[1] = h[1]; }
   if (ctx->opt_recon == 12) return tmhip_check_gauge_recon(ctx);
   return 0;
@@ -272,14 +349,13 @@ int tmhip_gauge_pack_ildg(tmhip_ctx *ctx, void *file_bytes, int prec, unsigned *
   TMHIP_CHECK(hipSetDevice(ctx->device));
   const size_t nsites = (size_t)ctx->V, fbytes = nsites * 4 * 9 * (prec == 64 ? 16 : 8);
   if (tmhip_stage_reserve(ctx, fbytes) || sums_reserve(ctx)) return 1;
-  const dim3 grid((unsigned)((nsites + ILDG_SITES - 1) / ILDG_SITES));
-  if (prec == 64) hipLaunchKernelGGL(ildg_pack_kernel<144>, grid, dim3(ILDG_SITES), 0, ctx->stream, (unsigned *)ctx->stage, (const v2d *)ctx->gauge_raw, io_geom(ctx), nsites, ctx->io_sums);
-  else hipLaunchKernelGGL(ildg_pack_kernel<72>, grid, dim3(ILDG_SITES), 0, ctx->stream, (unsigned *)ctx->stage, (const v2d *)ctx->gauge_raw, io_geom(ctx), nsites, ctx->io_sums);
+  const dim3 grid((unsigned)((nsites + ILDG_BS / 4 - 1) / (ILDG_BS / 4)));
+  if (prec == 64) hipLaunchKernelGGL(ildg_pack_kernel<144>, grid, dim3(ILDG_BS), 0, ctx->stream, (unsigned *)ctx->stage, (const v2d *)ctx->gauge_raw, io_geom(ctx), nsites, ctx->io_sums);
+  else hipLaunchKernelGGL(ildg_pack_kernel<72>, grid, dim3(ILDG_BS), 0, ctx->stream, (unsigned *)ctx->stage, (const v2d *)ctx->gauge_raw, io_geom(ctx), nsites, ctx->io_sums);
   TMHIP_CHECK(hipGetLastError());
   unsigned h[2];
   TMHIP_CHECK(hipMemcpyAsync(file_bytes, ctx->stage, fbytes, hipMemcpyDeviceToHost, ctx->stream));
-  TMHIP_CHECK(hipMemcpyAsync(h, ctx->io_sums, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (sums_fetch(ctx, h)) return 1;
   if (sums) { sums[0] = h[0]; sums[1] = h[1]; }
   return 0;
 }
