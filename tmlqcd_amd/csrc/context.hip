@@ -653,6 +653,7 @@ int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
   if (ctx->g.nproc_t > 1) TMHIP_FAIL("loopback is a single-rank self-test");
   ctx->loopback = on != 0;
   ctx->loopback_rccl = on == 2;
+  ctx->loopback_direct = on == 3;   // experiment: the pack kernel writes straight into the receive buffers (what an IPC-mapped neighbour buffer would allow)
   if (on == 2 && !ctx->comm_ready) {  // one-rank RCCL communicator: faces travel through ncclSend/ncclRecv to self
     TMHIP_CHECK(hipSetDevice(ctx->device));
     ncclUniqueId u;
@@ -670,6 +671,7 @@ int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
 //   send_dn -> rank-1 (lands in its recv_up),  send_up -> rank+1 (lands in its recv_dn).
 int tmhip_halo_exchange(tmhip_ctx *ctx) {
   const size_t n = (size_t)6 * ctx->face * 2;  // doubles per face
+  if (ctx->g.nproc_t == 1 && ctx->loopback_direct) return 0;   // (the pack kernel already wrote the receive buffers)
   if (ctx->g.nproc_t == 1 && !ctx->loopback_rccl) {  // periodic wrap onto ourselves (loopback self-test)
     TMHIP_CHECK(hipMemcpyAsync(ctx->recv_up, ctx->send_dn, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm_stream));
     TMHIP_CHECK(hipMemcpyAsync(ctx->recv_dn, ctx->send_up, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm_stream));

@@ -99,7 +99,7 @@ struct tmhip_ctx {
   // halo exchange
   // Two communicators over the same ranks: `comm` carries the half-spinor faces on comm_stream, `comm_red` (ncclCommSplit of
   // `comm`) everything issued on the main stream (scalar all-reduces, force halos) -- no communicator is driven from two streams.
-  ncclComm_t comm, comm_red; bool comm_ready; bool loopback; bool loopback_rccl;
+  ncclComm_t comm, comm_red; bool comm_ready; bool loopback; bool loopback_rccl; bool loopback_direct;
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
   unsigned int *sync_flags; unsigned int hop_seq;  // [0] in-ready, [1] boundary-done, [2] timeout error
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
