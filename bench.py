@@ -48,7 +48,8 @@ def parse(argv=None):
     ap.add_argument("--no-rank-check", action="store_true", help="N > 1: skip the multi-rank parity check and the configs[3] leg")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B runs)")
     ap.add_argument("--loopback", type=int, default=0,
-                    help="1-GPU rehearsal of the multi-GPU path: 1 = faces exchanged with self by D2D copies, 2 = through a one-rank RCCL communicator")
+                    help="1-GPU rehearsal of the multi-GPU path: 1 = faces exchanged with self by D2D copies, 2 = through a one-rank RCCL communicator, "
+                         "3 = written straight into the receive buffers by the pack kernel (diagnostic)")
     return ap.parse_args(argv)
 
 

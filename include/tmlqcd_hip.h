@@ -275,7 +275,8 @@ int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]); /* ri
 int tmhip_comm_count(tmhip_ctx *ctx, int *nranks_faces, int *nranks_reduce);
 /* Single-GPU self-test of the split-phase path: faces are packed, "exchanged"
  * with this rank itself and consumed by the boundary kernel.  on = 1: device-to-device
- * copies; on = 2: through a one-rank RCCL communicator (ncclSend/ncclRecv to self). */
+ * copies; on = 2: through a one-rank RCCL communicator (ncclSend/ncclRecv to self); on = 3 (diagnostic): the pack kernel
+ * writes the receive buffers directly, no exchange step at all. */
 int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on);
 
 /* Single-process ring of n contexts (ctxs[r] = rank r of an n-way T split; one per GPU, or several
