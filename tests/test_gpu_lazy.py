@@ -133,6 +133,36 @@ def test_host_threads_read_a_stale_field_at_the_same_time(prog):
         assert abs(got - want) < 1e-9 * max(1.0, abs(want))
 
 
+def test_full_lattice_fields_and_site_prefixes(prog):
+    """Mirrors of the other two shapes: a lexicographic full-lattice field (D_psi: fetched whole on the first fault) and the
+    first-N-sites prefix of an array (linalg with N < VOLUME/2); the same host bytes are never mirrored twice."""
+    stub, d, orc, f, (T, L, V, N), block = prog
+    d.D_psi.argtypes = [VP, VP]
+    d.assign_add_mul_r.argtypes = [VP, VP, C.c_double, C.c_int]
+    d.tmlqcd_hip_set_residency(LAZY)
+    # two full fields = f[0..1] and f[2..3] taken together (fields lie back to back in the block)
+    Pq = np.frombuffer(block, dtype=np.float64, count=V * 24, offset=f[0].ctypes.data - block.ctypes.data).reshape(V, 4, 3, 2)
+    Pp = np.frombuffer(block, dtype=np.float64, count=V * 24, offset=f[2].ctypes.data - block.ctypes.data).reshape(V, 4, 3, 2)
+    src = random_spinor(75, V)
+    Pq[:] = src
+    d.D_psi(_p(Pp), _p(Pq))
+    q = orc.new_field(orc.VPR)
+    q[:V] = src
+    want = np.zeros_like(q)
+    orc.D_psi(want, q)
+    assert rel_err(Pp, want[:V]) < TOL                       # numpy loads fault into the stale full field
+    # now address the first half of the output as a one-parity array: the full mirror gives way, the bytes stay right
+    a = f[2].copy()
+    d.Hopping_Matrix(0, _p(f[4]), _p(f[2]))
+    k = orc.new_field(); k[:N] = a
+    r = orc.new_field(); orc.Hopping_Matrix(0, r, k)
+    assert rel_err(f[4], r[:N]) < TOL and np.array_equal(f[2], a) and np.array_equal(Pp[:N], a)
+    # prefix of 1000 sites: P += c Q on the device, the rest of the array untouched and still readable
+    y0 = f[4].copy()
+    d.assign_add_mul_r(_p(f[4]), _p(f[2]), 0.5, 1000)
+    assert rel_err(f[4][:1000], y0[:1000] + 0.5 * a[:1000]) < TOL and np.array_equal(f[4][1000:], y0[1000:])
+
+
 def test_solver_and_mode_switch(prog):
     stub, d, orc, f, (T, L, V, N), _ = prog
     d.tmlqcd_hip_set_residency(LAZY)
