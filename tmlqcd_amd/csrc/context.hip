@@ -307,7 +307,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "block")) { if (value != 0 && value != 64 && value != 256) TMHIP_FAIL("block must be 0 (automatic), 64 or 256"); ctx->opt_block = value; }
   else if (!strcmp(name, "minw")) { if (value < 0 || value > 8) TMHIP_FAIL("minw must be in [0, 8] waves per SIMD"); ctx->opt_minw = value; }
   else if (!strcmp(name, "occ")) { if (value < 0 || value > 8) TMHIP_FAIL("occ must be in [0, 8] waves per SIMD (0 = no cap)"); ctx->opt_occ = value; }
-  else if (!strcmp(name, "xcd")) { if (value < 0 || value > 5) TMHIP_FAIL("xcd must be 0 (none), 1 (chunk), 2 (automatic), 3 (slab), 4 (tile) or 5 (brick)"); ctx->opt_xcd = value; }
+  else if (!strcmp(name, "xcd")) { if (value < 0 || value > 6) TMHIP_FAIL("xcd must be 0 (none), 1 (chunk), 2 (automatic), 3 (slab), 4 (tile), 5 or 6 (bricks: the time-slices in 4 / 2 blocks x the x-planes in 2 / 4)"); ctx->opt_xcd = value; }
   else if (!strcmp(name, "nt")) ctx->opt_nt = value;
   else if (!strcmp(name, "tgrp")) { if (value < 0 || value > ctx->g.T) TMHIP_FAIL("tgrp must be in [0, T]"); ctx->opt_tgrp = value; }
   else if (!strcmp(name, "flagsync")) ctx->opt_flagsync = value;
