@@ -302,6 +302,9 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "cg_fused_dot" 2 (default: alpha / residual / norm in the stencil epilogues), 1 scalar product only, 0 plain linalg kernels
  *   "cg_sync" 1: host-side scalars as in the reference loop;  "cg_batch" n: iterations enqueued between two polls of `done`
  *   "bench_graph" 1: tmhip_bench_hopping captures its loop into one hipGraph and replays it (diagnostic: launch floor on small lattices)
+ *   "gauge_cache" -1 (automatic) / 0 / 1: the 64-thread stencil launches of small unsplit lattices load the links with (0) or without (1) the
+ *                  streaming hint; automatic = without while the gauge copy is <= 200 MB (it then stays in the Infinity Cache between calls)
+ *   "swall_order" 0 / 1: block order of the owner-computes sw_all (one chunk per XCD / slab order, default)
  *   "swall_atomic" 1: tmhip_sw_all in the scatter form of the reference (fp64 atomics) instead of the owner-computes kernel (A/B only)
  *   "gaux" / "gdrop": diagnostics (gauge links through a buffer descriptor / dropped), profiles/r01_diagnostics.md
  * One option changes what is read from memory:

@@ -181,7 +181,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
   ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 2; ctx->opt_fusedface = -1; ctx->opt_gaux = -1;
-  ctx->opt_gdrop = 0; ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_facesplit = 0; ctx->opt_recon = 0; ctx->opt_swall_order = 1;
+  ctx->opt_gdrop = 0; ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_facesplit = 0; ctx->opt_recon = 0; ctx->opt_swall_order = 1; ctx->opt_gauge_cache = -1;
   ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
@@ -315,6 +315,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "fusedface")) ctx->opt_fusedface = value;
   else if (!strcmp(name, "facesplit")) ctx->opt_facesplit = value;
   else if (!strcmp(name, "bench_graph")) ctx->opt_bench_graph = value;
+  else if (!strcmp(name, "gauge_cache")) { if (value < -1 || value > 1) TMHIP_FAIL("gauge_cache must be -1 (automatic), 0 or 1"); ctx->opt_gauge_cache = value; }
   else if (!strcmp(name, "swall_atomic")) ctx->opt_swall_atomic = value != 0;
   else if (!strcmp(name, "swall_order")) { if (value < 0 || value > 1) TMHIP_FAIL("swall_order must be 0 (chunk per XCD) or 1 (slab order, default)"); ctx->opt_swall_order = value; }
   else if (!strcmp(name, "gaux")) ctx->opt_gaux = value;

@@ -96,7 +96,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipEventRecord(c->ev_comm, c->comm_stream));
     hop64::HopArgs a;
     hop64::fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr, c->opt_stg, 0};
+    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr, c->opt_stg, 0, c->opt_gauge_cache};
     hop64::launch_interior(c, a, EPI_STORE, o);
   }
   for (int r = 0; r < n; r++) {
@@ -105,7 +105,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     hop64::HopArgs a;
     hop64::fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr, c->opt_stg, 0};
+    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr, c->opt_stg, 0, c->opt_gauge_cache};
     hop64::launch_boundary(c, a, EPI_STORE, o, c->stream);
     TMHIP_CHECK(hipGetLastError());
   }

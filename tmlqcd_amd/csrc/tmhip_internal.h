@@ -115,6 +115,7 @@ struct tmhip_ctx {
   // options
   int opt_block, opt_xcd, opt_nt, opt_minw, opt_occ, opt_occ32;        // stencil launch shape (tmhip_set_option, include/tmlqcd_hip.h)
   int opt_tgrp, opt_shape, opt_gaux, opt_gdrop;
+  int opt_gauge_cache;                                                  // -1 automatic; 0 / 1: small-lattice launches load the links with / without the streaming hint
   int opt_hopsplit;                                                     // -1 automatic, 0 / 1: the eight hops of a site spread over four waves (small unsplit lattices)
   int opt_stg32;                                                        // the same for the fp32 stencil (default 0: measured slower there)
   int opt_stg;                                                          // 1 = LDS-staged stencil (own-block input spinors staged once, y/z neighbours read from LDS)
