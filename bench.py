@@ -45,6 +45,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="wall budget of the timed loops of the CPU-baseline leg (all thread counts together)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = sweep {16, 64, all physical cores}; n = that thread count only")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-rows", action="store_true", help="skip the informational next-row legs (MD step, ILDG record)")
     ap.add_argument("--no-rank-check", action="store_true", help="N > 1: skip the multi-rank parity check and the configs[3] leg")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B runs)")
     ap.add_argument("--loopback", type=int, default=0,
@@ -499,6 +500,44 @@ def rank_main(args, world, rank, local_rank):
         except Exception as e:
             cg16 = {"error": repr(e)}
 
+    # --- informational: the rows next to the path (SURVEY section 8 f) on the headline lattice, everything resident in HBM.  One
+    # molecular-dynamics step of the clover determinant without its solves (update_gauge.c, clover_term.c, clover_invert.c, deriv_Sb.c,
+    # clover_deriv.c, clover_accumulate_deriv.c, update_momenta.c) and an ILDG record into / out of the resident links.
+    rows = None
+    if world == 1 and not args.loopback and not args.no_rows:
+        try:
+            kap, csw = 0.125, 1.5
+            lat.momenta_upload(np.zeros((lat.V, 4, 8)))
+            a, b = lat.field(src), lat.field()
+            lat.Hopping_Matrix(0, b, a)
+
+            def md_step():
+                lat.update_gauge(0.0)                        # (zero momenta: the links stay SU(3) and the same)
+                lat.sw_term(None, kap, csw); lat.sw_invert(0, lat_mu)
+                lat.derivative_zero(); lat.swpm_zero()
+                lat.deriv_Sb(1, a, b, 0.5); lat.deriv_Sb(0, b, a, 0.5)
+                lat.sw_spinor_eo(0, b, b, 0.5); lat.sw_spinor_eo(1, a, a, 0.5)
+                lat.sw_deriv(0, lat_mu); lat.sw_all(kap, csw)
+                lat.update_momenta(0.0)
+            lat_mu = 0.01
+            md_step(); lat.sync()
+            t2 = time.perf_counter()
+            for _ in range(5):
+                md_step()
+            lat.sync()
+            md_ms = 1e3 * (time.perf_counter() - t2) / 5
+            rec, sums = lat.gauge_pack_ildg(64)
+            t2 = time.perf_counter(); lat.gauge_unpack_ildg(rec, 64); t_un = time.perf_counter() - t2
+            t2 = time.perf_counter(); lat.gauge_pack_ildg(64); t_pk = time.perf_counter() - t2
+            rows = {"md_step_ms": md_ms, "md_step": "update_gauge, sw_term, sw_invert, 2 x deriv_Sb, 2 x sw_spinor_eo, sw_deriv, sw_all, update_momenta "
+                                                    "on the links / momenta / derivative resident in HBM (no solves)",
+                    "ildg_unpack_ms": 1e3 * t_un, "ildg_pack_ms": 1e3 * t_pk, "ildg_record_MB": rec.size / 1e6,
+                    "ildg_note": "604 MB ildg-binary-data record <-> resident links incl. the PCIe copy of the record; checksum %08x %08x" % sums}
+            for f in (a, b):
+                f.free()
+        except Exception as e:                            # informational legs never cost the headline line
+            rows = {"error": repr(e)}
+
     if rank == 0:
         sdt = 1e6 * dt / (args.steps * V)                   # us per site-update, benchmark.c:318
         mflops = world * 1608.0 / sdt                       # benchmark.c:327 "Mflops(total)"
@@ -528,7 +567,7 @@ def rank_main(args, world, rank, local_rank):
                                         if args.loopback else "single GPU"))},
             "lattice_updates_per_s": args.steps / dt, "us_per_site": sdt,
             "cg": dict(cg, operator="Qtm_pm_psi", N="VOLUME/2"),
-            "cg_16": cg16, "gauge_recon12": recon, "nocom": nocom,
+            "cg_16": cg16, "gauge_recon12": recon, "nocom": nocom, "next_rows": rows,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "hop_kernel (Hopping_Matrix, one parity)",
                          "us_per_launch": 1e6 * t_launch, "achieved_2880B_model": achieved * 2880.0 / 1536.0},
