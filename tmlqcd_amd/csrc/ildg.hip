@@ -322,6 +322,7 @@ extern "C" {
  * io/dml.c:63-66).  On a T-split rank the halo slabs are exchanged with the ring neighbours (xchange_gauge). */
 int tmhip_gauge_unpack_ildg(tmhip_ctx *ctx, const void *file_bytes, int prec, unsigned *sums) {
   if (!file_bytes || (prec != 32 && prec != 64)) TMHIP_FAIL("tmhip_gauge_unpack_ildg: null data or precision %d (32 or 64)", prec);
+  if (ctx->g.nproc_t > 1 && !ctx->comm_ready) TMHIP_FAIL("tmhip_gauge_unpack_ildg: T-split rank without tmhip_comm_init (the halo slabs of the new links come from the ring neighbours)");
   TMHIP_CHECK(hipSetDevice(ctx->device));
   const size_t nsites = (size_t)ctx->V, fbytes = nsites * 4 * 9 * (prec == 64 ? 16 : 8), gbytes = (size_t)ctx->VPR * 36 * sizeof(v2d);
   if (tmhip_stage_reserve(ctx, fbytes) || sums_reserve(ctx)) return 1;
