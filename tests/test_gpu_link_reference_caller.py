@@ -89,13 +89,11 @@ def test_c_main_linked_at_link_time_runs_the_benchmark_loop(c_host_program):
     assert d["max_rel_err_vs_oracle"] < 1e-13 and d["mflops_resident"] > d["mflops_coherent"] > 0
 
 
-def test_unmodified_c_main_runs_resident_under_the_lazy_mode():
+def test_unmodified_c_main_runs_resident_under_the_lazy_mode(c_host_program):
     """The same binary, not a byte changed, with TMLQCD_HIP_RESIDENCY=lazy in its environment: its plain loop over the reference's
     symbols (host calloc'ed arrays, no residency call) keeps the fields in HBM -- the program's own loads decide when a page comes
     back -- and still passes its built-in comparison with the oracle (it reads the complete output on the host afterwards)."""
-    exe = os.path.join(ROOT, "tests", "c_host", "mini_benchmark")
-    if not os.path.exists(exe):
-        pytest.skip("tests/c_host/mini_benchmark not built")
+    exe = c_host_program
     out = {}
     for mode in ("coherent", "lazy"):
         env = dict(os.environ, TMLQCD_HIP_RESIDENCY=mode)
