@@ -107,3 +107,62 @@ def test_geometry_tables_self_consistent():
         hi = o.hi()
         # odd entries address the OTHER parity's sub-index space and stay inside field + halo
         assert hi[:V // 2, 1::2].max() < VR // 2 and hi[:V // 2, 1::2].min() >= 0
+
+
+def _ildg_worker(rank, world, port, T, L, prec, path, out_dir):
+    """One rank of a T-split read of an ILDG file: seeks to ITS part of the ildg-binary-data record (the offset the reference computes
+    in gauge_read_binary.c:158-163 for g_nproc_x = g_nproc_y = g_nproc_z = 1), unpacks it, and the ranks combine their checksum words
+    with a bit-wise XOR (DML_checksum_combine, io/dml.c:63-66: MPI_Allreduce with MPI_BXOR)."""
+    sys.path.insert(0, ROOT)
+    import struct
+    import torch
+    import torch.distributed as dist
+    from oracle import ildgbind as ib
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    raw = open(path, "rb").read()
+    pos = 0
+    while True:                                                        # walk the LIME records to the binary one
+        n = struct.unpack(">Q", raw[pos + 8:pos + 16])[0]
+        if raw[pos + 16:pos + 144].split(b"\0")[0] == b"ildg-binary-data":
+            break
+        pos += 144 + (n + 7) // 8 * 8
+    sb = 576 if prec == 64 else 288
+    Vloc = T * L ** 3
+    assert n == world * Vloc * sb
+    mine = np.frombuffer(raw, dtype=np.uint8, count=Vloc * sb, offset=pos + 144 + rank * Vloc * sb)
+    gf, sums = ib.unpack(mine, prec, T, L, L, L, rank0=rank * Vloc)
+    words = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(words, torch.tensor(sums, dtype=torch.int64))
+    a = b = 0
+    for w in words:
+        a ^= int(w[0]); b ^= int(w[1])
+    np.savez(os.path.join(out_dir, "ildg_rank%d.npz" % rank), gf=gf, sums=np.array([a, b], dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_t_split_ranks_read_their_part_of_an_ildg_record(tmp_path, prec):
+    import multiprocessing as mp
+    from oracle import ildgbind as ib
+    from tmlqcd_amd import synthetic as syn
+    world, T, L = 2, 2, 4
+    Tg = T * world
+    g = syn.gauge_field(31, Tg, L, L, L)
+    path = str(tmp_path / "conf.lime")
+    rc, sums = ib.write_gauge_field(path, g, prec, Tg, L, L, L)
+    assert rc == 0
+    port = 29850 + (os.getpid() % 100) + prec
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_ildg_worker, args=(r, world, port, T, L, prec, path, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, "rank exited with %r" % p.exitcode
+    want = g if prec == 64 else g.astype(np.float32).astype(np.float64)
+    V = T * L ** 3
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "ildg_rank%d.npz" % r))
+        assert np.array_equal(d["gf"], want[r * V:(r + 1) * V])
+        assert (int(d["sums"][0]), int(d["sums"][1])) == sums          # every rank ends up with the file's checksum
