@@ -126,6 +126,20 @@ def test_t_split_ranks_pack_their_part_of_the_record():
     assert np.array_equal(np.concatenate(parts), rec) and (xa, xb) == sums
 
 
+def test_reader_combines_checksums_through_the_reduction_communicator():
+    """The multi-rank leg of the reader (own part of the record at its offset, ncclAllGather of the checksum words, XOR) with a
+    one-rank RCCL communicator: the same calls a T-split rank makes."""
+    from tmlqcd_amd import Lattice
+    name = "ildg_%dx%dx%dx%d_prec64.lime" % (T, LX, LY, LZ)
+    lat = Lattice(T, LX, LY, LZ, kappa=0.125, mu=0.01)
+    lat.set_loopback(2)
+    assert lat.comm_count() == (1, 1)
+    rc, gf, info = lat.read_gauge_field(os.path.join(GOLD, name))
+    assert rc == 0 and "%08x" % info.suma == META["files"][name]["suma"] and "%08x" % info.sumb == META["files"][name]["sumb"]
+    assert np.array_equal(gf[:lat.V], syn.gauge_field(META["gauge_seed"], T, LX, LY, LZ))
+    lat.close()
+
+
 def test_drop_in_read_and_write_gauge_field(host_stub, tmp_path):
     """The reference's symbols on the host's g_gauge_field: read_gauge_field fills it, sets GaugeInfo and g_update_gauge_copy, and the
     next Hopping_Matrix runs on the links the reader left in HBM; write_gauge_field writes the fixture back byte for byte."""

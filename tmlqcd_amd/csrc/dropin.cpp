@@ -1184,8 +1184,7 @@ paramsGaugeInfo GaugeInfo = {0., 0, {0, 0}, NULL, NULL};
  * reference's messages.  The device keeps the links it has just unpacked, so the refresh that g_update_gauge_copy triggers at the
  * next operator call does not upload them again (gf == g_gauge_field only). */
 int read_gauge_field(char *filename, su3 **const gf) {
-  tmhip_ctx *c = ctx();
-  if (c == nullptr || (g_nproc_t > 1)) die("read_gauge_field: single-rank reader (T-split ranks: tmhip_gauge_unpack_ildg on their part of the record)");
+  tmhip_ctx *c = ctx();      // (T-split ranks: every rank reads its part of the record, tmlqcd_hip_comm_init must have been called)
   g_calls++;
   static tmhip_gauge_info info;
   const int prec = &gauge_precision_read_flag && gauge_precision_read_flag == 32 ? 32 : 64;

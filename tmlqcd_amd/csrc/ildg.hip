@@ -309,6 +309,20 @@ int sums_fetch(tmhip_ctx *ctx, unsigned out[2]) {
   for (int k = 0; k < ILDG_SLOTS; k++) { out[0] ^= h[2 * k]; out[1] ^= h[2 * k + 1]; }
   return 0;
 }
+// XOR of the checksum words over the ranks (io/dml.c:63-66): RCCL has no bit-wise XOR reduction, so the words are gathered
+int sums_combine(tmhip_ctx *ctx, unsigned sums[2]) {
+  int n = 0;
+  TMHIP_NCCL_CHECK(ncclCommCount(ctx->comm_red, &n));
+  if (n < 1 || n > ILDG_SLOTS) TMHIP_FAIL("sums_combine: %d ranks", n);
+  TMHIP_CHECK(hipMemcpyAsync(ctx->io_sums, sums, 2 * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+  TMHIP_NCCL_CHECK(ncclAllGather(ctx->io_sums, ctx->io_sums + 2, 2, ncclUint32, ctx->comm_red, ctx->stream));   // (io_sums holds 2 * ILDG_SLOTS words)
+  std::vector<unsigned> h(2 * (size_t)n);
+  TMHIP_CHECK(hipMemcpyAsync(h.data(), ctx->io_sums + 2, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  sums[0] = sums[1] = 0;
+  for (int k = 0; k < n; k++) { sums[0] ^= h[2 * k]; sums[1] ^= h[2 * k + 1]; }
+  return 0;
+}
 IldgGeom io_geom(const tmhip_ctx *ctx) {
   return IldgGeom{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, (unsigned long long)ctx->g.proc_t * ctx->g.T * ctx->g.LX * ctx->g.LY * ctx->g.LZ};
 }
@@ -367,12 +381,14 @@ int tmhip_gauge_pack_ildg(tmhip_ctx *ctx, void *file_bytes, int prec, unsigned *
  * g_gauge_field layout ([VOLUMEPLUSRAND][4] su3).  prec_expected = gauge_precision_read_flag (64 / 32).  Returns 0, or -1 like the
  * reference (messages on stderr); info (may be NULL) receives what GaugeInfo would hold. */
 int tmhip_read_gauge_field(tmhip_ctx *ctx, const char *filename, int prec_expected, int io_checks, void *host_gf, tmhip_gauge_info *info) {
-  if (ctx->g.nproc_t != 1) TMHIP_FAIL("tmhip_read_gauge_field: single rank only (T-split ranks hand their part of the record to tmhip_gauge_unpack_ildg)");
+  // T-split ranks: every rank walks the records itself and reads ITS contiguous part of the binary record (the offset of
+  // gauge_read_binary.c:158-163 for a decomposition in T only); the checksum words are combined over the ranks (DML_checksum_combine)
+  if (ctx->g.nproc_t > 1 && !ctx->comm_ready) TMHIP_FAIL("tmhip_read_gauge_field: T-split rank without tmhip_comm_init");
   FILE *fp = fopen(filename, "rb");
   if (!fp) { fprintf(stderr, "[tmlqcd_hip] read_gauge_field: cannot open %s\n", filename); return -1; }
   std::vector<LimeRecord> recs;
   if (lime_scan(fp, recs)) { fprintf(stderr, "[tmlqcd_hip] read_gauge_field: %s is not a LIME file (bad record header)\n", filename); fclose(fp); return -1; }
-  const int L[4] = {ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.T};
+  const int L[4] = {ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.T * ctx->g.nproc_t};
   int n_bin = 0, n_sum = 0, n_fmt = 0, fmt_ok = 0, sum_ok = 0;
   int fprec = 0, fl[4] = {0, 0, 0, 0};
   unsigned calc[2] = {0, 0}, stored[2] = {0, 0};
@@ -383,7 +399,7 @@ int tmhip_read_gauge_field(tmhip_ctx *ctx, const char *filename, int prec_expect
         fprintf(stderr, "In gauge file %s, multiple LIME records with name: \"ildg-binary-data\" found.\nUnable to verify integrity of the gauge field data.\n", filename);
         fclose(fp); return -1;
       }
-      const unsigned long long want = (unsigned long long)ctx->V * 4 * 144 / (prec_expected == 64 ? 1 : 2);
+      const unsigned long long mine = (unsigned long long)ctx->V * 4 * 144 / (prec_expected == 64 ? 1 : 2), want = mine * ctx->g.nproc_t;
       if (r.bytes != want) {     // gauge_read_binary.c:148-155
         fprintf(stderr, "Lattice size and precision found in data file do not match those requested at input.\nExpected LX = %d, LY = %d, LZ = %d, LT = %d, and %s precision.\n"
                         "Expected %llu bytes, found %llu bytes.\nGauge file reading failed at binary part, unable to proceed.\n",
@@ -391,10 +407,11 @@ int tmhip_read_gauge_field(tmhip_ctx *ctx, const char *filename, int prec_expect
         fclose(fp); return -1;
       }
       void *buf = nullptr;
-      if (hipHostMalloc(&buf, r.bytes, hipHostMallocDefault) != hipSuccess) { fprintf(stderr, "[tmlqcd_hip] read_gauge_field: no pinned buffer of %llu bytes\n", r.bytes); fclose(fp); return -1; }
-      const bool ok = !fseek(fp, r.data_pos, SEEK_SET) && fread(buf, 1, r.bytes, fp) == r.bytes;
-      const int rc = ok ? tmhip_gauge_unpack_ildg(ctx, buf, prec_expected, calc) : 1;
+      if (hipHostMalloc(&buf, mine, hipHostMallocDefault) != hipSuccess) { fprintf(stderr, "[tmlqcd_hip] read_gauge_field: no pinned buffer of %llu bytes\n", mine); fclose(fp); return -1; }
+      const bool ok = !fseek(fp, r.data_pos + (long)(mine * ctx->g.proc_t), SEEK_SET) && fread(buf, 1, mine, fp) == mine;
+      int rc = ok ? tmhip_gauge_unpack_ildg(ctx, buf, prec_expected, calc) : 1;
       (void)hipHostFree(buf);
+      if (!rc && tmhip_reduce_over_ranks(ctx)) rc = sums_combine(ctx, calc);
       if (rc) { fprintf(stderr, "Gauge file reading failed at binary part, unable to proceed.\n"); fclose(fp); return -1; }
     } else if (r.type == "scidac-checksum") {
       if (n_sum++) {
