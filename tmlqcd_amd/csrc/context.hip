@@ -250,7 +250,7 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->io_sums) (void)hipFree(ctx->io_sums);
   if (ctx->swpm_halo_send) (void)hipFree(ctx->swpm_halo_send);
   if (ctx->swpm_halo_recv) (void)hipFree(ctx->swpm_halo_recv);
-  if (ctx->comm_ready) { ncclCommDestroy(ctx->comm_red); ncclCommDestroy(ctx->comm); }
+  if (ctx->comm_ready) { if (ctx->comm_red != ctx->comm) ncclCommDestroy(ctx->comm_red); ncclCommDestroy(ctx->comm); }
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
   (void)hipFree(ctx->sync_flags);
@@ -638,7 +638,13 @@ int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]) {
   memcpy(&u, id, sizeof(u));
   TMHIP_NCCL_CHECK(ncclCommInitRank(&ctx->comm, ctx->g.nproc_t, u, ctx->g.proc_t));
   // second communicator over the same ranks for everything issued on the main stream (collective: every rank calls it here)
-  TMHIP_NCCL_CHECK(ncclCommSplit(ctx->comm, 0, ctx->g.proc_t, &ctx->comm_red, nullptr));
+  const ncclResult_t rs = ncclCommSplit(ctx->comm, 0, ctx->g.proc_t, &ctx->comm_red, nullptr);
+  if (rs != ncclSuccess) {
+    // (an RCCL without ncclCommSplit: every rank fails here alike.)  One communicator for both streams is what round 1 ran with: on a
+    // rank, a reduction is never in flight together with a face exchange, so this is a fallback, not an error.
+    fprintf(stderr, "[tmlqcd_hip] ncclCommSplit failed (%s): reductions share the face communicator\n", ncclGetErrorString(rs));
+    ctx->comm_red = ctx->comm;
+  }
   ctx->comm_ready = true;
   return 0;
 }
