@@ -241,6 +241,7 @@ int tmhip_momenta_upload(tmhip_ctx *ctx, const void *host_momenta);
 int tmhip_momenta_download(tmhip_ctx *ctx, void *host_momenta);
 int tmhip_update_momenta(tmhip_ctx *ctx, double step);   /* update_momenta.c:67-72 from the device-resident derivative field */
 int tmhip_update_gauge(tmhip_ctx *ctx, double step);     /* update_gauge.c:51-110 */
+int tmhip_multi_update_gauge(int n, tmhip_ctx **ctxs, double step);   /* the same for n contexts of one process holding a T-split lattice (peer copies) */
 int tmhip_gauge_download(tmhip_ctx *ctx, void *host_gauge);   /* [VOLUMEPLUSRAND][4] su3, e.g. at the end of a trajectory */
 
 /* ---- ILDG gauge configurations (io/gauge_read.c:28-198, io/gauge_read_binary.c:140-200, io/gauge_write.c:22-59,

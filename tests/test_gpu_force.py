@@ -374,6 +374,47 @@ def test_update_gauge_at_scale_keeps_the_links_unitary_and_the_clover_term_follo
     lat.close()
 
 
+@pytest.mark.parametrize("T,L,world", [(2, 4, 2), (4, 4, 3)])
+def test_update_gauge_on_t_slabs_refreshes_the_halo_links(T, L, world):
+    """update_gauge on T-split ranks (contexts of one process, peer copies): the updated t = 0 / T-1 slices reach the neighbours' halo
+    slabs and the re-sorted stencil copies use them -- links and a stencil application afterwards == the unsplit oracle, slab by slab."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    from tmlqcd_amd.hip import multi_Hopping_Matrix, multi_update_gauge
+    Tg = T * world
+    kappa, mu, theta = 0.13, 0.02, (1.0, 0.25, 0.0, 0.5)
+    orc = Oracle(Tg, L, L, L, kappa=kappa, mu=mu, theta=theta, threads=4)
+    g = syn.gauge_field(16, Tg, L, L, L)
+    rng = np.random.default_rng(77)
+    mom = rng.standard_normal((Tg * L ** 3, 4, 8))
+    V = T * L ** 3
+    lats = [Lattice(T, L, L, L, kappa=kappa, mu=mu, theta=theta, nproc_t=world, proc_t=r) for r in range(world)]
+    for r, lat in enumerate(lats):
+        lat.set_gauge(syn.gauge_field(16, T, L, L, L, world, r))
+        lat.momenta_upload(np.ascontiguousarray(mom[r * V:(r + 1) * V]))
+    for step in (0.05, -0.02):
+        multi_update_gauge(lats, step)
+        orc.update_gauge(g, mom, step)
+    orc.set_gauge(g)
+    XYZ = L ** 3
+    for r, lat in enumerate(lats):
+        got = lat.gauge_download()
+        assert rel_err(got[:V], g[r * V:(r + 1) * V]) < TOL
+        up, dn = (r + 1) % world, (r - 1) % world
+        assert np.array_equal(got[V:V + XYZ], lats[up].gauge_download()[:XYZ])                     # t = T slab = the up neighbour's t = 0
+        assert np.array_equal(got[V + XYZ:V + 2 * XYZ], lats[dn].gauge_download()[V - XYZ:V])      # t = -1 slab = the down neighbour's t = T-1
+    k = orc.new_field(); k[:orc.Vh] = syn.spinor_field_eo(21, 1, Tg, L, L, L)
+    ref = orc.new_field(); orc.Hopping_Matrix(0, ref, k)
+    ks = [lat.field(syn.spinor_field_eo(21, 1, T, L, L, L, world, r)) for r, lat in enumerate(lats)]
+    ls = [lat.field() for lat in lats]
+    multi_Hopping_Matrix(lats, 0, ls, ks)
+    Vh = V // 2
+    for r, lat in enumerate(lats):
+        assert rel_err(ls[r].download(), ref[r * Vh:(r + 1) * Vh]) < TOL, r
+        lat.close()
+
+
 def test_update_gauge_drop_in_keeps_the_links_in_hbm(host_stub):
     """tmlqcd_hip_update_gauge(step, hf): coherent mode = the reference's update_gauge as the host sees it (links updated in
     hf->gaugefield, flags raised) with no second upload; resident mode = the host links stay behind until

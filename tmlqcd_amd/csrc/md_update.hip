@@ -166,6 +166,34 @@ int tmhip_update_gauge(tmhip_ctx *ctx, double step) {
   return tmhip_resort_gauge(ctx);
 }
 
+/* The same on a T-split lattice held by n contexts of one process (peer copies instead of RCCL, as tmhip_multi_sw_all): every
+ * rank updates its links, the t = 0 / t = T-1 slices travel to the ring neighbours' halo slabs, the stencil copies are re-sorted. */
+int tmhip_multi_update_gauge(int n, tmhip_ctx **ctxs, double step) {
+  if (n < 2) TMHIP_FAIL("tmhip_multi_update_gauge needs >= 2 contexts");
+  for (int r = 0; r < n; r++) {
+    tmhip_ctx *c = ctxs[r];
+    if (c->g.nproc_t != n || c->g.proc_t != r) TMHIP_FAIL("context %d is not rank %d of a %d-way T split", r, r, n);
+    if (!c->gauge_raw || !c->gauge_raw_valid || !c->momenta) TMHIP_FAIL("tmhip_multi_update_gauge: rank %d has no resident links / momenta", r);
+    TMHIP_CHECK(hipSetDevice(c->device));
+    const size_t nlinks = (size_t)c->V * 4;
+    hipLaunchKernelGGL(update_gauge_kernel, dim3((unsigned)((nlinks + 255) / 256)), dim3(256), 0, c->stream, c->gauge_raw, (const double *)c->momenta, nlinks, step);
+    TMHIP_CHECK(hipGetLastError());
+  }
+  for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
+  const size_t XYZ = (size_t)ctxs[0]->g.LX * ctxs[0]->g.LY * ctxs[0]->g.LZ, sb = XYZ * 36 * sizeof(v2d);
+  for (int r = 0; r < n; r++) {
+    tmhip_ctx *c = ctxs[r], *up = ctxs[(r + 1) % n], *dn = ctxs[(r + n - 1) % n];
+    TMHIP_CHECK(hipSetDevice(c->device));
+    v2d *slab_up = c->gauge_raw + (size_t)c->V * 36, *slab_dn = slab_up + XYZ * 36;                                    // t = T, t = -1
+    TMHIP_CHECK(hipMemcpyPeerAsync(slab_up, c->device, up->gauge_raw, up->device, sb, c->stream));                                            // the up neighbour's t = 0
+    TMHIP_CHECK(hipMemcpyPeerAsync(slab_dn, c->device, dn->gauge_raw + (size_t)(dn->g.T - 1) * XYZ * 36, dn->device, sb, c->stream));         // the down neighbour's t = T-1
+    c->sw_set = false; c->clover_set = false; c->clover32_set = false;
+    if (tmhip_resort_gauge(c)) return 1;
+  }
+  for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
+  return 0;
+}
+
 /* the device-resident links in the host layout of g_gauge_field ([VOLUMEPLUSRAND][4] su3) */
 int tmhip_gauge_download(tmhip_ctx *ctx, void *host) {
   if (!host) TMHIP_FAIL("tmhip_gauge_download: null argument");

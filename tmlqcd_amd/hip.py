@@ -105,6 +105,7 @@ def load_library():
         "tmhip_derivative_download": [vp, vp, i],
         "tmhip_multi_deriv_Sb": [i, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), d],
         "tmhip_multi_sw_all": [i, C.POINTER(vp), d, d],
+        "tmhip_multi_update_gauge": [i, C.POINTER(vp), d],
         "tmhip_sw_invert": [vp, i, d],
         "tmhip_get_clover": [vp, vp, vp],
         "tmhip_clover_inv": [vp, vp, i, d],
@@ -646,3 +647,10 @@ def multi_sw_all(lats, kappa, c_sw):
     n = len(lats)
     arr = C.c_void_p * n
     _ck(lats[0].lib.tmhip_multi_sw_all(n, arr(*[l.h for l in lats]), kappa, c_sw), "tmhip_multi_sw_all")
+
+
+def multi_update_gauge(lats, step):
+    """update_gauge on a T-split lattice held by several contexts of THIS process: links updated, halo slabs by peer copies, stencil copies re-sorted."""
+    n = len(lats)
+    arr = C.c_void_p * n
+    _ck(lats[0].lib.tmhip_multi_update_gauge(n, arr(*[l.h for l in lats]), step), "tmhip_multi_update_gauge")
