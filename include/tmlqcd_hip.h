@@ -275,15 +275,21 @@ int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]); /* ri
  * (ncclCommSplit of the first) for the scalar all-reduces of the linalg (MPI_Allreduce in linalg/square_norm.c:314) and the
  * force halos on the main stream.  Ranks in each as RCCL reports them (ncclCommCount); 0, 0 before tmhip_comm_init. */
 int tmhip_comm_count(tmhip_ctx *ctx, int *nranks_faces, int *nranks_reduce);
+/* 1: the reductions have their own communicator; 0: ncclCommSplit was unavailable (or switched off with the "comm_split" option) and
+ * they share the face communicator -- still correct, a face exchange is never in flight together with a reduction; -1: no communicator */
+int tmhip_comm_is_split(tmhip_ctx *ctx);
 /* Single-GPU self-test of the split-phase path: faces are packed, "exchanged"
- * with this rank itself and consumed by the boundary kernel.  on = 1: device-to-device
- * copies; on = 2: through a one-rank RCCL communicator (ncclSend/ncclRecv to self); on = 3 (diagnostic): the pack kernel
- * writes the receive buffers directly, no exchange step at all. */
+ * with this rank itself and consumed by the exterior kernel.  on = 1: device-to-device
+ * copies; on = 2: through a one-rank RCCL communicator (ncclSend/ncclRecv to self). */
 int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on);
+/* Test hook: holds the comm stream back for `ms` milliseconds (<= 20000) in front of the next thing enqueued on it, i.e. the next halo
+ * exchange -- what a late neighbour looks like from this rank (xchange_field's MPI_Waitall simply waits, xchange/xchange_field.c:98-250;
+ * so does the split path here, up to "flag_timeout_ms").  Changes no result. */
+int tmhip_comm_stream_delay_ms(tmhip_ctx *ctx, int ms);
 
 /* Single-process ring of n contexts (ctxs[r] = rank r of an n-way T split; one per GPU, or several
  * on one GPU as a self-test): Hopping_Matrix on every slab with the faces moved by peer copies
- * (hipMemcpyPeerAsync) instead of RCCL.  Same pack / interior / boundary kernels as the RCCL path. */
+ * (hipMemcpyPeerAsync) instead of RCCL.  Same pack / stencil / exterior kernels as the RCCL path. */
 int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhip_field **l, tmhip_field **k);
 
 /* ---- measurement ---------------------------------------------------------- */
@@ -298,17 +304,19 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "xcd"   block order: 2 automatic (default; tile order up to L = 32, slab order above), 0 none, 1 one chunk per XCD,
  *           3 slab, 4 tile;  "tgrp" time-slices per tile group (0 = automatic)
  *   "occ" / "occ32"  waves per SIMD allowed by a dynamic-LDS cap for the fp64 / fp32 stencil (3 / 0 = no cap)
- *   "minw" 4: __launch_bounds__(BS, 4);  "shape" n: compact n-x-plane block shape
- *   "flagsync" 1|0 flag kernels vs HIP events on the split path;  "fusedface" -1 (default: on from T_local = 16 up) | 1 | 0: faces in the same launch as the interior;
- *   "facesplit" 0|1 two-kernel split path: one thread per face site (default) vs the face kernel with the eight hops of a site spread over the four waves of a block
+ *   "minw" 4: __launch_bounds__(BS, 4)
+ *   "split_sync" 0 (default) | 1: T-split ranks -- 0: the exterior kernel (main stream) and the pack kernel (comm stream) wait on the device for a
+ *                flag of the other stream; 1: the two streams are ordered by HIP events, no wait on the device at all (slower: two events on the
+ *                main stream per stencil)
+ *   "flag_timeout_ms" bound of those device-side waits (default 120 s, or TMLQCD_HIP_FLAG_TIMEOUT_S in the environment; 0 = none): a late
+ *                neighbour is waited for, a dead one becomes an error of the next synchronising call (reported once, then cleared)
+ *   "comm_split" 1|0 (before tmhip_comm_init / tmhip_comm_set_loopback(2)): 0 keeps the reductions on the face communicator (the fallback of an RCCL without ncclCommSplit)
  *   "cg_fused_dot" 2 (default: alpha / residual / norm in the stencil epilogues), 1 scalar product only, 0 plain linalg kernels
  *   "cg_sync" 1: host-side scalars as in the reference loop;  "cg_batch" n: iterations enqueued between two polls of `done`
- *   "bench_graph" 1: tmhip_bench_hopping captures its loop into one hipGraph and replays it (diagnostic: launch floor on small lattices)
  *   "gauge_cache" -1 (automatic) / 0 / 1: the 64-thread stencil launches of small unsplit lattices load the links with (0) or without (1) the
  *                  streaming hint; automatic = without while the gauge copy is <= 200 MB (it then stays in the Infinity Cache between calls)
  *   "swall_order" 0 / 1: block order of the owner-computes sw_all (one chunk per XCD / slab order, default)
  *   "swall_atomic" 1: tmhip_sw_all in the scatter form of the reference (fp64 atomics) instead of the owner-computes kernel (A/B only)
- *   "gaux" / "gdrop": diagnostics (gauge links through a buffer descriptor / dropped), profiles/r01_diagnostics.md
  * One option changes what is read from memory:
  * "gauge_recon" = 12 makes the twisted-mass stencil launches (fp64 and fp32) fetch only the first two rows of every link and
  * rebuild the third as conj(row0 x row1) in registers (the 12-real compression the reference exposes for its external

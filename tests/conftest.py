@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Device-side waits of the split path are bounded (tmlqcd_hip.h "flag_timeout_ms", default 120 s).  In the test suite a wait that
+# long can only be a bug (a deadlock between the stencil kernel and the exchange it waits for): let it surface as an error within
+# 20 s instead of two minutes per call.  The late-neighbour tests delay by 6 s, well inside.
+os.environ.setdefault("TMLQCD_HIP_FLAG_TIMEOUT_S", "20")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -74,19 +74,17 @@ def test_fused_epilogues(setup16, ieo):
         f.free()
 
 
-@pytest.mark.parametrize("mode,flagsync,fusedface,facesplit", [(1, 1, 0, 1), (2, 1, 0, 1), (1, 0, 0, 1), (1, 1, 1, 1), (2, 1, 1, 1),
-                                                               (1, 1, 0, 0), (1, 0, 0, 0)])
-def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface, facesplit):
-    """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self,
-    consumed by the boundary kernels -- must equal the plain periodic stencil."""
+@pytest.mark.parametrize("mode,split_sync", [(1, 0), (2, 0), (1, 1), (2, 1)])
+def test_loopback_split_path_matches(setup16, mode, split_sync):
+    """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self, the stencil over all sites with the hop
+    across the cut taken from the received faces -- inside the stencil kernel behind a flag (split_sync 0, default) or by the
+    exterior kernel behind a HIP event (1) -- must equal the plain periodic stencil."""
     orc, lat = setup16
     N = orc.Vh
     k = random_spinor(31, N)
     ref = orc.new_field()
     dk, dl = lat.field(k), lat.field()
-    lat.set_option("fusedface", fusedface)  # 1: one kernel, face blocks wait in-kernel for the exchanged faces
-    lat.set_option("flagsync", flagsync)  # cross-stream ordering by device flags (default) or HIP events
-    lat.set_option("facesplit", facesplit)  # 1: face kernel with the hops of a site over four waves, 0: one thread per face site
+    lat.set_option("split_sync", split_sync)
     lat.set_loopback(mode)  # 1: D2D copies, 2: one-rank RCCL communicator (ncclSend/Recv to self)
     try:
         for rep in range(3):       # repeated calls re-use the face buffers: a stale-cache bug would show here
@@ -96,6 +94,19 @@ def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface, facespl
                 orc.Hopping_Matrix(ieo, ref, kk)
                 lat.Hopping_Matrix(ieo, dl, dk)
                 assert rel_err(dl.download(), ref[:N]) < TOL
+        # every fused epilogue pushes the exterior kernel's one term through its own factors
+        p = random_spinor(32, N)
+        dp = lat.field(p)
+        c = 0.83 - 0.41j
+        for ieo in (0, 1):
+            orc.tm_times_Hopping_Matrix(ieo, ref, k, c)
+            dk.upload(k)
+            lat.tm_times_Hopping_Matrix(ieo, dl, dk, c)
+            assert rel_err(dl.download(), ref[:N]) < TOL
+            orc.tm_sub_Hopping_Matrix(ieo, ref, p, k, c)
+            lat.tm_sub_Hopping_Matrix(ieo, dl, dp, dk, c)
+            assert rel_err(dl.download(), ref[:N]) < TOL
+        dp.free()
         # a dependent chain without host round trips in between (what Qtm_pm_psi does)
         dk.upload(k)
         q = lat.field()
@@ -103,12 +114,84 @@ def test_loopback_split_path_matches(setup16, mode, flagsync, fusedface, facespl
         qref = orc.new_field(); orc.op("Qtm_pm_psi", qref, k.copy())
         assert rel_err(q.download(), qref[:N]) < TOL
         q.free()
-        lat.sync()  # also checks the bounded-spin error word
+        lat.sync()
     finally:
         lat.set_loopback(0)
-        lat.set_option("flagsync", 1)
-        lat.set_option("fusedface", -1)
-        lat.set_option("facesplit", 0)
+        lat.set_option("split_sync", 0)
+    dk.free(); dl.free()
+
+
+@pytest.mark.parametrize("mode,split_sync", [(1, 0), (2, 0), (2, 1)])
+def test_split_path_waits_for_a_late_neighbour(setup16, mode, split_sync):
+    """xchange_field's MPI_Waitall waits as long as the neighbour needs (xchange/xchange_field.c:98-250).  So does the split path:
+    the comm stream is held back 6 s in front of the exchange (what a neighbour arriving late looks like from this rank) and the
+    result is still the oracle's, with default settings; nothing is left behind for the next call."""
+    import time
+    orc, lat = setup16
+    N = orc.Vh
+    k = random_spinor(33, N)
+    ref = orc.new_field()
+    dk, dl = lat.field(k), lat.field()
+    lat.set_option("split_sync", split_sync)
+    lat.set_loopback(mode)
+    try:
+        lat.Hopping_Matrix(0, dl, dk)          # warm: buffers, (mode 2) the communicator
+        lat.sync()
+        t0 = time.time()
+        lat.comm_stream_delay_ms(6000)
+        lat.Hopping_Matrix(0, dl, dk)
+        out = dl.download()
+        dt = time.time() - t0
+        orc.Hopping_Matrix(0, ref, k)
+        assert dt > 5.5, dt                    # the call really sat behind the delay
+        assert rel_err(out, ref[:N]) < TOL
+        lat.sync()                             # no error is reported ...
+        lat.Hopping_Matrix(1, dl, dk)          # ... and the next call is an ordinary one
+        orc.Hopping_Matrix(1, ref, k)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+        # the same inside a solver: the delay lands in front of one of the exchanges of cg_her
+        q = random_spinor(34, N)
+        P = orc.new_field()
+        it_ref, _ = orc.cg_her(P, q.copy(), 500, 1e-18, 1, N)
+        dq, dp = lat.field(q), lat.field()
+        lat.comm_stream_delay_ms(5000)
+        it, _ = lat.cg_her(dp, dq, 500, 1e-18, 1, N)
+        assert abs(it - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9
+        dq.free(); dp.free()
+    finally:
+        lat.set_loopback(0)
+        lat.set_option("split_sync", 0)
+    dk.free(); dl.free()
+
+
+def test_split_path_deadline_is_reported_once_and_cleared(setup16):
+    """A neighbour that never answers must not hang the GPU: with a 50 ms bound on the device-side wait and the comm stream held
+    back 2 s, the call that synchronises reports the error -- and the NEXT call on the same context is an ordinary, correct one
+    (round 2's error word was sticky: one late neighbour poisoned the context)."""
+    import tmlqcd_amd
+    orc, lat = setup16
+    N = orc.Vh
+    k = random_spinor(35, N)
+    ref = orc.new_field()
+    dk, dl = lat.field(k), lat.field()
+    lat.set_loopback(1)
+    try:
+        lat.Hopping_Matrix(0, dl, dk)
+        lat.sync()
+        lat.set_option("flag_timeout_ms", 50)
+        lat.comm_stream_delay_ms(2000)
+        lat.Hopping_Matrix(0, dl, dk)
+        with pytest.raises(tmlqcd_amd.hip.TmHipError):
+            lat.sync()
+        lat.set_option("flag_timeout_ms", 20000)
+        for ieo in (0, 1):
+            lat.Hopping_Matrix(ieo, dl, dk)
+            orc.Hopping_Matrix(ieo, ref, k)
+            assert rel_err(dl.download(), ref[:N]) < TOL
+        lat.sync()
+    finally:
+        lat.set_option("flag_timeout_ms", 20000)
+        lat.set_loopback(0)
     dk.free(); dl.free()
 
 

@@ -255,21 +255,21 @@ def test_cg_fused_scalar_product_path(fused):
     assert it3 == -1 and it_c == -1 and len(hist3) == 7
     assert rel_err(dp.download(), Pc[:N]) < 1e-9          # P after exactly 7 updates, no extra / missing alpha p
     # the same solve on the split-phase path (T-split rank rehearsed on one GPU): with cg_fused_dot = 2 the reductions are
-    # spread over the boundary kernel (comm stream) and the interior kernel (main stream)
-    for mode, ff in ((1, 0), (2, 0), (1, 1), (2, 1)):      # ff = 1: interior and faces in ONE launch, face blocks wait in-kernel
-        lat.set_loopback(mode); lat.set_option("fusedface", ff)
+    # spread over the stencil kernel (all sites but the two boundary slices) and the exterior kernel (those two)
+    for mode, ss in ((1, 0), (2, 0), (1, 1), (2, 1)):      # ss = 1: HIP events + exterior kernel instead of the in-kernel flag wait
+        lat.set_loopback(mode); lat.set_option("split_sync", ss)
         dp.zero()
         it4, hist4 = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
-        lat.set_loopback(0); lat.set_option("fusedface", -1)
-        assert abs(it4 - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9, (mode, ff)
+        lat.set_loopback(0); lat.set_option("split_sync", 0)
+        assert abs(it4 - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9, (mode, ss)
         m4 = min(len(hist4), len(hist_ref)) - 1
         assert np.allclose(hist4[:m4], hist_ref[:m4], rtol=1e-6)
     lat.close()
 
 
 def test_cg_fused_split_path_wide_short_local_lattice():
-    """A T-split rank whose faces are a large part of its volume (4 x 16^3: half the sites are face sites): the face kernel
-    writes more reduction partials than the interior kernel.  Every face-kernel variant must reproduce the unsplit solve."""
+    """A T-split rank whose faces are a large part of its volume (4 x 16^3: half the sites are face sites): the exterior kernel
+    owns half of the reduction.  Must reproduce the unsplit solve."""
     from oracle.oraclebind import Oracle
     from tmlqcd_amd import Lattice
     from tmlqcd_amd import synthetic as syn
@@ -283,14 +283,14 @@ def test_cg_fused_split_path_wide_short_local_lattice():
     P = orc.new_field()
     it_ref, hist_ref = orc.cg_her(P, q.copy(), 500, 1e-20, 1, N)
     dq, dp = lat.field(q), lat.field()
-    for loop, fs, ff in ((0, 1, 0), (1, 1, 0), (1, 0, 0), (1, 1, 1), (2, 1, 0)):
-        lat.set_loopback(loop); lat.set_option("facesplit", fs); lat.set_option("fusedface", ff)
+    for loop, ss in ((0, 0), (1, 0), (2, 0), (1, 1)):
+        lat.set_loopback(loop); lat.set_option("split_sync", ss)
         dp.zero()
         it, hist = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
-        assert abs(it - it_ref) <= 1, (loop, fs, ff, it, it_ref)
+        assert abs(it - it_ref) <= 1, (loop, ss, it, it_ref)
         m = min(len(hist), len(hist_ref)) - 1
-        assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6), (loop, fs, ff)
-        assert rel_err(dp.download(), P[:N]) < 1e-9, (loop, fs, ff)
+        assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6), (loop, ss)
+        assert rel_err(dp.download(), P[:N]) < 1e-9, (loop, ss)
     lat.close()
 
 

@@ -96,11 +96,25 @@ __global__ __launch_bounds__(256) void gauge_recon_dev_kernel(const v2d *__restr
 
 // ------------------------------------------------------------------ helpers
 int tmhip_check_async_error(tmhip_ctx *ctx) {
-  if (!ctx->hop_seq) return 0;  // no split-phase stencil has run: nothing can have timed out
-  unsigned int err = 0;        // set by a bounded cross-stream spin that gave up (flag_wait_kernel, block_wait_flag, fused face blocks)
-  TMHIP_CHECK(hipMemcpyAsync(&err, ctx->sync_flags + 2, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
-  TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
-  if (err) TMHIP_FAIL("cross-stream flag wait timed out: the halo exchange did not complete, results since the last check are invalid");
+  if (ctx->hop_seq) {   // a split-phase stencil has run: did a bounded wait for the faces give up (wave_wait_flag, hopping_impl.inc)?
+    unsigned int err = 0;
+    TMHIP_CHECK(hipMemcpyAsync(&err, ctx->sync_flags + 2, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
+    TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (err) {
+      // reported once: the word is cleared (behind everything enqueued so far on both streams), so a neighbour that was late once
+      // does not poison the context
+      TMHIP_CHECK(hipStreamSynchronize(ctx->comm_stream));
+      TMHIP_CHECK(hipMemsetAsync(ctx->sync_flags + 2, 0, sizeof(err), ctx->stream));
+      TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+      TMHIP_FAIL("the wait for the neighbours' faces gave up after %.3f s (option flag_timeout_ms): results since the last check are invalid",
+                 (double)ctx->flag_timeout_ticks * 1.0e-8);
+    }
+  }
+  if (!ctx->comm_ready) return 0;
+  ncclResult_t st = ncclSuccess;
+  TMHIP_NCCL_CHECK(ncclCommGetAsyncError(ctx->comm, &st));
+  if (st == ncclSuccess && ctx->comm_red != ctx->comm) TMHIP_NCCL_CHECK(ncclCommGetAsyncError(ctx->comm_red, &st));
+  if (st != ncclSuccess && st != ncclInProgress) TMHIP_FAIL("the halo communicator reports an asynchronous error (%s): results since the last check are invalid", ncclGetErrorString(st));
   return 0;
 }
 
@@ -180,8 +194,15 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
-  ctx->opt_cg_batch = 4; ctx->opt_flagsync = 1; ctx->opt_cg_fused_dot = 2; ctx->opt_fusedface = -1; ctx->opt_gaux = -1;
-  ctx->opt_gdrop = 0; ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_facesplit = 0; ctx->opt_recon = 0; ctx->opt_swall_order = 1; ctx->opt_gauge_cache = -1;
+  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0;
+  {
+    // bound of the device-side waits for the neighbours' faces: TMLQCD_HIP_FLAG_TIMEOUT_S in the environment (0 = none), default 120 s
+    double sec = 120.0;
+    const char *e = getenv("TMLQCD_HIP_FLAG_TIMEOUT_S");
+    if (e && *e) { char *end = nullptr; const double v = strtod(e, &end); if (end != e && v >= 0.0) sec = v; }
+    ctx->flag_timeout_ticks = (unsigned long long)(sec * 1.0e8);
+  }
+  ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_recon = 0; ctx->opt_swall_order = 1; ctx->opt_gauge_cache = -1;
   ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
@@ -195,8 +216,8 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   TMHIP_CHECK(hipMalloc((void **)&ctx->gauge, (size_t)2 * 72 * ctx->gs * sizeof(v2d)));
   ctx->max_partials = 12 * ((ctx->ns + 1023) / 1024 + 1);
   {
-    // fused stencil+reduction: one per wave of the (padded) grid, plus -- on the split path -- four per 64 face sites of the face kernel
-    int need = 4 * ((ctx->ns + 255) / 256 + 8 + 7 * ctx->g.T) + 8 * ((ctx->face + 63) / 64 + 1);
+    // fused stencil+reduction: one per wave of the (padded) grid, plus -- on the split path -- one per wave of the exterior kernel
+    int need = 4 * ((ctx->ns + 255) / 256 + 8 + 7 * ctx->g.T) + 4 * 128;
     if (ctx->ns <= 262144 && need < ctx->ns / 16 + 64) need = ctx->ns / 16 + 64;   // hop-split kernel on small lattices: four partials per 64 sites
     if (ctx->max_partials < need) ctx->max_partials = need;
   }
@@ -204,14 +225,15 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   TMHIP_CHECK(hipMalloc((void **)&ctx->result_dev, 4 * sizeof(double)));
   TMHIP_CHECK(hipHostMalloc((void **)&ctx->result_host, 4 * sizeof(double)));
   const size_t fb = (size_t)6 * ctx->face * sizeof(v2d);
-  TMHIP_CHECK(hipMalloc((void **)&ctx->send_up, fb));
-  TMHIP_CHECK(hipMalloc((void **)&ctx->send_dn, fb));
-  TMHIP_CHECK(hipMalloc((void **)&ctx->recv_up, fb));
-  TMHIP_CHECK(hipMalloc((void **)&ctx->recv_dn, fb));
+  // [send_dn | send_up] and [recv_up | recv_dn]: what goes down arrives at the lower neighbour as its "up" face and vice versa, so
+  // the periodic wrap onto ourselves (loopback) is ONE copy of both faces
+  TMHIP_CHECK(hipMalloc((void **)&ctx->send_dn, 2 * fb));
+  TMHIP_CHECK(hipMalloc((void **)&ctx->recv_up, 2 * fb));
+  ctx->send_up = ctx->send_dn + (size_t)6 * ctx->face;
+  ctx->recv_dn = ctx->recv_up + (size_t)6 * ctx->face;
   TMHIP_CHECK(hipMalloc((void **)&ctx->sync_flags, 64));
   TMHIP_CHECK(hipMemsetAsync(ctx->sync_flags, 0, 64, ctx->stream));
-  TMHIP_CHECK(hipMemsetAsync(ctx->recv_up, 0, fb, ctx->stream));
-  TMHIP_CHECK(hipMemsetAsync(ctx->recv_dn, 0, fb, ctx->stream));
+  TMHIP_CHECK(hipMemsetAsync(ctx->recv_up, 0, 2 * fb, ctx->stream));
   for (int i = 0; i < 3; i++) {
     if (field_alloc_impl(ctx, TMHIP_FIELD_EO, &ctx->scratch[i])) return 1;
     if (field_alloc_impl(ctx, TMHIP_FIELD_EO, &ctx->sf[i])) return 1;
@@ -254,7 +276,7 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
   (void)hipFree(ctx->sync_flags);
-  (void)hipFree(ctx->send_up); (void)hipFree(ctx->send_dn); (void)hipFree(ctx->recv_up); (void)hipFree(ctx->recv_dn);
+  (void)hipFree(ctx->send_dn); (void)hipFree(ctx->recv_up);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->cg_state) (void)hipFree(ctx->cg_state);
   if (ctx->cg_hist) (void)hipFree(ctx->cg_hist);
@@ -307,40 +329,25 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "block")) { if (value != 0 && value != 64 && value != 256) TMHIP_FAIL("block must be 0 (automatic), 64 or 256"); ctx->opt_block = value; }
   else if (!strcmp(name, "minw")) { if (value < 0 || value > 8) TMHIP_FAIL("minw must be in [0, 8] waves per SIMD"); ctx->opt_minw = value; }
   else if (!strcmp(name, "occ")) { if (value < 0 || value > 8) TMHIP_FAIL("occ must be in [0, 8] waves per SIMD (0 = no cap)"); ctx->opt_occ = value; }
-  else if (!strcmp(name, "xcd")) { if (value < 0 || value > 6) TMHIP_FAIL("xcd must be 0 (none), 1 (chunk), 2 (automatic), 3 (slab), 4 (tile), 5 or 6 (bricks: the time-slices in 4 / 2 blocks x the x-planes in 2 / 4)"); ctx->opt_xcd = value; }
+  else if (!strcmp(name, "xcd")) { if (value < 0 || value > 4) TMHIP_FAIL("xcd must be 0 (none), 1 (chunk), 2 (automatic), 3 (slab) or 4 (tile)"); ctx->opt_xcd = value; }
   else if (!strcmp(name, "nt")) ctx->opt_nt = value;
   else if (!strcmp(name, "tgrp")) { if (value < 0 || value > ctx->g.T) TMHIP_FAIL("tgrp must be in [0, T]"); ctx->opt_tgrp = value; }
-  else if (!strcmp(name, "flagsync")) ctx->opt_flagsync = value;
+  else if (!strcmp(name, "split_sync")) { if (value < 0 || value > 1) TMHIP_FAIL("split_sync must be 0 (boundary hop in the stencil kernel, behind a flag) or 1 (HIP events + exterior kernel)"); ctx->opt_split_sync = value; }
+  else if (!strcmp(name, "flag_timeout_ms")) { if (value < 0) TMHIP_FAIL("flag_timeout_ms must be >= 0 (0 = wait without bound)"); ctx->flag_timeout_ticks = (unsigned long long)value * 100000ull; }
+  else if (!strcmp(name, "comm_split")) { if (ctx->comm_ready) TMHIP_FAIL("comm_split must be set before the communicator is created"); ctx->opt_comm_split = value != 0; }
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
-  else if (!strcmp(name, "fusedface")) ctx->opt_fusedface = value;
-  else if (!strcmp(name, "facesplit")) ctx->opt_facesplit = value;
-  else if (!strcmp(name, "bench_graph")) ctx->opt_bench_graph = value;
   else if (!strcmp(name, "gauge_cache")) { if (value < -1 || value > 1) TMHIP_FAIL("gauge_cache must be -1 (automatic), 0 or 1"); ctx->opt_gauge_cache = value; }
   else if (!strcmp(name, "swall_atomic")) ctx->opt_swall_atomic = value != 0;
   else if (!strcmp(name, "swall_order")) { if (value < 0 || value > 1) TMHIP_FAIL("swall_order must be 0 (chunk per XCD) or 1 (slab order, default)"); ctx->opt_swall_order = value; }
-  else if (!strcmp(name, "gaux")) ctx->opt_gaux = value;
-  else if (!strcmp(name, "gdrop")) ctx->opt_gdrop = value;
   else if (!strcmp(name, "occ32")) { if (value < 0 || value > 8) TMHIP_FAIL("occ32 must be in [0, 8]"); ctx->opt_occ32 = value; }
   else if (!strcmp(name, "gauge_recon")) {
     if (value != 12 && value != 18 && value != 0) TMHIP_FAIL("gauge_recon must be 12 or 18");
     ctx->opt_recon = value == 12 ? 12 : 0;
     if (ctx->opt_recon == 12) return tmhip_check_gauge_recon(ctx);
   }
-  else if (!strcmp(name, "gauge_mem")) {
-    // experiment: where the once-per-call link stream lives -- 0 hipMalloc (default), 1 hipDeviceMallocUncached (not cached in L2),
-    // 2 fine-grained, 3 physically contiguous.  Re-allocates the gauge copy: tmhip_set_gauge has to follow.
-    if (value < 0 || value > 3) TMHIP_FAIL("gauge_mem must be 0 (default), 1 (uncached), 2 (fine-grained) or 3 (contiguous)");
-    TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
-    TMHIP_CHECK(hipFree(ctx->gauge));
-    ctx->gauge = nullptr; ctx->gauge_set = false;
-    const size_t bytes = (size_t)2 * 72 * ctx->gs * sizeof(v2d);
-    if (value == 0) TMHIP_CHECK(hipMalloc((void **)&ctx->gauge, bytes));
-    else TMHIP_CHECK(hipExtMallocWithFlags((void **)&ctx->gauge, bytes, value == 1 ? hipDeviceMallocUncached : (value == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocContiguous)));
-  }
   else if (!strcmp(name, "hopsplit")) { if (value < -1 || value > 1) TMHIP_FAIL("hopsplit must be -1 (automatic), 0 or 1"); ctx->opt_hopsplit = value; }
   else if (!strcmp(name, "lds32")) { if (value < 0 || value > 1) TMHIP_FAIL("lds32 must be 0 or 1"); ctx->opt_stg32 = value; }
   else if (!strcmp(name, "lds")) { if (value < 0 || value > 1) TMHIP_FAIL("lds must be 0 (gather kernel) or 1 (per-wave LDS staging of the own-site spinors)"); ctx->opt_stg = value; }
-  else if (!strcmp(name, "shape")) { if (value < 0 || value > 16) TMHIP_FAIL("shape must be in [0, 16] x-planes per block"); ctx->opt_shape = value; }
   else if (!strcmp(name, "cg_sync")) ctx->opt_cg_sync = value;
   else if (!strcmp(name, "cg_batch")) ctx->opt_cg_batch = value > 0 ? value : 1;
   else TMHIP_FAIL("unknown option %s", name);
@@ -524,7 +531,7 @@ int tmhip_H_eo_tm_inv_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k, int ie
   const double nrm = 1. / (1. + ctx->mu * ctx->mu), sign = _sign < 0. ? 1. : -1.;
   return tmhip_tm_times_hopping_matrix(ctx, ieo, l, k, nrm, sign * nrm * ctx->mu);
 }
-// raw-pointer forms with the chaining hint: inside a composition every stencil after the first gathers the previous one's output
+// raw-pointer forms
 static int hop_tm_inv(tmhip_ctx *ctx, v2d *l, const v2d *k, int ieo, double _sign, int flags) {   /* tm_operators.c:508-526 */
   const double nrm = 1. / (1. + ctx->mu * ctx->mu), sign = _sign < 0. ? 1. : -1.;
   return tmhip_launch_hopping(ctx, ieo, l, k, nullptr, EPI_TM_TIMES, nrm, sign * nrm * ctx->mu, flags);
@@ -533,7 +540,7 @@ static int hop_tm_sub_g5(tmhip_ctx *ctx, v2d *l, const v2d *p, const v2d *k, int
   return tmhip_launch_hopping(ctx, ieo, l, k, p, EPI_TM_SUB_G5, 1., (_sign < 0. ? -1. : 1.) * ctx->mu, flags);
 }
 #define HOP_FIRST HOP_COMM
-#define HOP_NEXT (HOP_COMM | HOP_CHAINED)
+#define HOP_NEXT HOP_COMM
 /* l may alias k for these (invert_eo.c:270 calls Qtm_minus_psi in place): the last stencil reads
  * k only through the element-wise epilogue `p`, never as a gathered neighbour field. */
 /* tm_operators.c:172-177 */
@@ -631,20 +638,35 @@ int tmhip_comm_get_unique_id(char id[TMHIP_UNIQUE_ID_BYTES]) {
   return 0;
 }
 
+// second communicator over the same ranks for everything issued on the main stream (collective: every rank calls it at the same point)
+static int comm_make_red(tmhip_ctx *ctx, int rank) {
+  ctx->comm_red = ctx->comm; ctx->comm_split = false;
+  if (!ctx->opt_comm_split) return 0;
+  const ncclResult_t rs = ncclCommSplit(ctx->comm, 0, rank, &ctx->comm_red, nullptr);
+  if (rs != ncclSuccess) {
+    // (an RCCL without ncclCommSplit: every rank fails here alike.)  One communicator is enough for correctness: a reduction is never
+    // in flight together with a face exchange (hopping_impl.inc launch_split), so this is a fallback, not an error.
+    fprintf(stderr, "[tmlqcd_hip] ncclCommSplit failed (%s): reductions share the face communicator\n", ncclGetErrorString(rs));
+    ctx->comm_red = ctx->comm;
+    return 0;
+  }
+  ctx->comm_split = true;
+  return 0;
+}
+
+// one thread that sleeps until the 100 MHz clock has advanced by `ticks` (bounded: at most 20 s, tmhip_comm_stream_delay_ms)
+__global__ void delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]) {
   if (ctx->g.nproc_t < 2) return 0;
   TMHIP_CHECK(hipSetDevice(ctx->device));
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   TMHIP_NCCL_CHECK(ncclCommInitRank(&ctx->comm, ctx->g.nproc_t, u, ctx->g.proc_t));
-  // second communicator over the same ranks for everything issued on the main stream (collective: every rank calls it here)
-  const ncclResult_t rs = ncclCommSplit(ctx->comm, 0, ctx->g.proc_t, &ctx->comm_red, nullptr);
-  if (rs != ncclSuccess) {
-    // (an RCCL without ncclCommSplit: every rank fails here alike.)  One communicator for both streams is what round 1 ran with: on a
-    // rank, a reduction is never in flight together with a face exchange, so this is a fallback, not an error.
-    fprintf(stderr, "[tmlqcd_hip] ncclCommSplit failed (%s): reductions share the face communicator\n", ncclGetErrorString(rs));
-    ctx->comm_red = ctx->comm;
-  }
+  if (comm_make_red(ctx, ctx->g.proc_t)) return 1;
   ctx->comm_ready = true;
   return 0;
 }
@@ -656,17 +678,30 @@ int tmhip_comm_count(tmhip_ctx *ctx, int *nranks_faces, int *nranks_reduce) {
   return 0;
 }
 
+/* 1: reductions run on their own communicator (ncclCommSplit), 0: they share the face communicator, -1: no communicator */
+int tmhip_comm_is_split(tmhip_ctx *ctx) { return ctx->comm_ready ? (ctx->comm_split ? 1 : 0) : -1; }
+
+/* Test hook: hold the comm stream back for `ms` milliseconds in front of whatever is enqueued on it next (the next halo exchange) --
+ * a neighbour that arrives late, as seen from this rank.  Results do not change; only their time of arrival does. */
+int tmhip_comm_stream_delay_ms(tmhip_ctx *ctx, int ms) {
+  if (ms < 0 || ms > 20000) TMHIP_FAIL("tmhip_comm_stream_delay_ms: 0 .. 20000 ms");
+  TMHIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, ctx->comm_stream, (unsigned long long)ms * 100000ull);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
   if (ctx->g.nproc_t > 1) TMHIP_FAIL("loopback is a single-rank self-test");
   ctx->loopback = on != 0;
   ctx->loopback_rccl = on == 2;
-  ctx->loopback_direct = on == 3;   // experiment: the pack kernel writes straight into the receive buffers (what an IPC-mapped neighbour buffer would allow)
+  if (on < 0 || on > 2) TMHIP_FAIL("loopback: 0 off, 1 device-to-device copies, 2 one-rank RCCL communicator");
   if (on == 2 && !ctx->comm_ready) {  // one-rank RCCL communicator: faces travel through ncclSend/ncclRecv to self
     TMHIP_CHECK(hipSetDevice(ctx->device));
     ncclUniqueId u;
     TMHIP_NCCL_CHECK(ncclGetUniqueId(&u));
     TMHIP_NCCL_CHECK(ncclCommInitRank(&ctx->comm, 1, u, 0));
-    TMHIP_NCCL_CHECK(ncclCommSplit(ctx->comm, 0, 0, &ctx->comm_red, nullptr));
+    if (comm_make_red(ctx, 0)) return 1;
     ctx->comm_ready = true;
   }
   return 0;
@@ -678,10 +713,8 @@ int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
 //   send_dn -> rank-1 (lands in its recv_up),  send_up -> rank+1 (lands in its recv_dn).
 int tmhip_halo_exchange(tmhip_ctx *ctx) {
   const size_t n = (size_t)6 * ctx->face * 2;  // doubles per face
-  if (ctx->g.nproc_t == 1 && ctx->loopback_direct) return 0;   // (the pack kernel already wrote the receive buffers)
   if (ctx->g.nproc_t == 1 && !ctx->loopback_rccl) {  // periodic wrap onto ourselves (loopback self-test)
-    TMHIP_CHECK(hipMemcpyAsync(ctx->recv_up, ctx->send_dn, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm_stream));
-    TMHIP_CHECK(hipMemcpyAsync(ctx->recv_dn, ctx->send_up, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm_stream));
+    TMHIP_CHECK(hipMemcpyAsync(ctx->recv_up, ctx->send_dn, 2 * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->comm_stream));   // (both faces: buffers are contiguous)
     return 0;
   }
   if (!ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
@@ -715,32 +748,10 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int a, int b, double *ms) {
 /* benchmark.c:291-300 */
 int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_field *f2, int iters, double *ms_total) {
   if (need_eo(f0, "bench") || need_eo(f1, "bench") || need_eo(f2, "bench")) return 1;
-  if (ctx->opt_bench_graph && ctx->g.nproc_t == 1 && !ctx->loopback) {
-    // diagnostic ("bench_graph" 1): the same loop captured into ONE hipGraph and replayed -- separates host enqueue cost from
-    // the GPU-side cost of a kernel boundary on small lattices (profiles/r01_diagnostics.md)
-    hipGraph_t graph; hipGraphExec_t exec;
-    TMHIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    for (int j = 0; j < iters; j++) {
-      if (tmhip_launch_hopping(ctx, 0, f1->d, f0->d, nullptr, EPI_STORE, 0, 0, HOP_COMM)) return 1;
-      if (tmhip_launch_hopping(ctx, 1, f2->d, f1->d, nullptr, EPI_STORE, 0, 0, HOP_COMM)) return 1;
-    }
-    TMHIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
-    TMHIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    TMHIP_CHECK(hipGraphLaunch(exec, ctx->stream));          // first replay untimed (upload of the executable graph)
-    if (tmhip_event_record(ctx, 14)) return 1;
-    TMHIP_CHECK(hipGraphLaunch(exec, ctx->stream));
-    if (tmhip_event_record(ctx, 15)) return 1;
-    const int rc = tmhip_event_elapsed_ms(ctx, 14, 15, ms_total);
-    TMHIP_CHECK(hipGraphExecDestroy(exec));
-    TMHIP_CHECK(hipGraphDestroy(graph));
-    return rc;
-  }
   if (tmhip_event_record(ctx, 14)) return 1;
   for (int j = 0; j < iters; j++) {
-    // back-to-back stencils (benchmark.c:295-296): f1 is the previous stencil's output and f0 has not been written since the loop
-    // began, so on a split lattice their faces may be packed early (HOP_CHAINED); the very first call makes no such promise
-    if (tmhip_launch_hopping(ctx, 0, f1->d, f0->d, nullptr, EPI_STORE, 0, 0, j ? (HOP_COMM | HOP_CHAINED) : HOP_COMM)) return 1;
-    if (tmhip_launch_hopping(ctx, 1, f2->d, f1->d, nullptr, EPI_STORE, 0, 0, HOP_COMM | HOP_CHAINED)) return 1;
+    if (tmhip_launch_hopping(ctx, 0, f1->d, f0->d, nullptr, EPI_STORE, 0, 0, HOP_COMM)) return 1;   // benchmark.c:295-296
+    if (tmhip_launch_hopping(ctx, 1, f2->d, f1->d, nullptr, EPI_STORE, 0, 0, HOP_COMM)) return 1;
   }
   if (tmhip_event_record(ctx, 15)) return 1;
   return tmhip_event_elapsed_ms(ctx, 14, 15, ms_total);

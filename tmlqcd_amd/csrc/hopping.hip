@@ -42,30 +42,31 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
   return hop64::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
 }
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
-                             double cre, double cim, int *npartials, int mode, v2d *resid, const double *scal, const v2d *cw, int chained) {
-  return hop64::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
+                             double cre, double cim, int *npartials, int mode, v2d *resid, const double *scal, const v2d *cw) {
+  return hop64::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw);
 }
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
                            double cre, double cim, int comm, const v2f *cw) {
   return hop32::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
 }
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
-                               double cre, double cim, int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw, int chained) {
-  return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
+                               double cre, double cim, int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw) {
+  return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw);
 }
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx) {
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
   const int sites = 1;
   const int spb = (split ? 256 : tmhip_hop_block(ctx)) * sites;
-  return ctx->Vh % spb == 0 && (!split || (ctx->face % (256 * sites) == 0 && ctx->g.T >= 3));
+  return ctx->Vh % spb == 0;
 }
 
 // Single-process ring: n contexts (one per GPU, or several on one GPU for the self-test) that
 // together hold a T-split lattice; faces move by peer copies instead of RCCL.  Collective over
 // all contexts because the host enqueues for every rank:
 //   1. every rank packs its two faces            (after its neighbours finished reading the previous ones)
-//   2. every rank pulls the neighbours' faces on its comm stream || runs its interior kernel
-//   3. every rank runs its boundary kernels once its pulls have landed
+//   2. every rank pulls the neighbours' faces on its comm stream
+//   3. every rank runs the stencil over all its sites but for the hops across the cuts, then -- once its pulls have landed -- the
+//      exterior kernel that adds those
 extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhip_field **l, tmhip_field **k) {
   if (n < 2) TMHIP_FAIL("tmhip_multi_hopping_matrix needs >= 2 contexts");
   for (int r = 0; r < n; r++) {
@@ -80,7 +81,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipSetDevice(c->device));
     TMHIP_CHECK(hipStreamWaitEvent(c->stream, up->ev_comm, 0));  // neighbours still pulling the previous faces
     TMHIP_CHECK(hipStreamWaitEvent(c->stream, dn->ev_comm, 0));
-    hop64::launch_pack(c, k[r]->d);
+    hop64::launch_pack(c, k[r]->d, c->stream);
     TMHIP_CHECK(hipEventRecord(c->ev_pack, c->stream));
   }
   for (int r = 0; r < n; r++) {
@@ -88,25 +89,21 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipSetDevice(c->device));
     TMHIP_CHECK(hipStreamWaitEvent(c->comm_stream, up->ev_pack, 0));
     TMHIP_CHECK(hipStreamWaitEvent(c->comm_stream, dn->ev_pack, 0));
-    // ... and after this rank's own pack: it sits behind the previous call's boundary kernel in c->stream order, and that
+    // ... and after this rank's own pack: it sits behind the previous call's exterior kernel in c->stream order, and that
     // kernel still reads recv_up / recv_dn -- the new faces must not land under it (back-to-back calls, slow ranks)
     TMHIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
     TMHIP_CHECK(hipMemcpyPeerAsync(c->recv_up, c->device, up->send_dn, up->device, fb, c->comm_stream));
     TMHIP_CHECK(hipMemcpyPeerAsync(c->recv_dn, c->device, dn->send_up, dn->device, fb, c->comm_stream));
     TMHIP_CHECK(hipEventRecord(c->ev_comm, c->comm_stream));
-    hop64::HopArgs a;
-    hop64::fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr, c->opt_stg, 0, c->opt_gauge_cache};
-    hop64::launch_interior(c, a, EPI_STORE, o);
   }
   for (int r = 0; r < n; r++) {
     tmhip_ctx *c = ctxs[r];
     TMHIP_CHECK(hipSetDevice(c->device));
-    TMHIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     hop64::HopArgs a;
     hop64::fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    const hop64::HopLaunch o = {tmhip_hop_block(c), c->opt_nt != 0, c->opt_minw, c->opt_xcd, c->opt_occ, c->opt_tgrp, c->opt_shape, c->opt_gaux, c->opt_gdrop, c->opt_recon, nullptr, c->opt_stg, 0, c->opt_gauge_cache};
-    hop64::launch_boundary(c, a, EPI_STORE, o, c->stream);
+    hop64::launch_epi<true>(a, EPI_STORE, c->stream, hop64::launch_opts(c, tmhip_hop_block(c)));
+    TMHIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    hop64::launch_exterior(c, a, EPI_STORE, c->stream);
     TMHIP_CHECK(hipGetLastError());
   }
   return 0;

@@ -99,9 +99,12 @@ struct tmhip_ctx {
   // halo exchange
   // Two communicators over the same ranks: `comm` carries the half-spinor faces on comm_stream, `comm_red` (ncclCommSplit of
   // `comm`) everything issued on the main stream (scalar all-reduces, force halos) -- no communicator is driven from two streams.
-  ncclComm_t comm, comm_red; bool comm_ready; bool loopback; bool loopback_rccl; bool loopback_direct;
+  // comm_split false: ncclCommSplit is unavailable (or switched off, "comm_split" 0) and comm_red == comm; still correct, because
+  // a face exchange is never in flight together with a main-stream collective (launch_split, hopping_impl.inc).
+  ncclComm_t comm, comm_red; bool comm_ready; bool comm_split; bool loopback; bool loopback_rccl;
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
-  unsigned int *sync_flags; unsigned int hop_seq;  // [0] in-ready, [1] boundary-done, [2] timeout error
+  unsigned int *sync_flags; unsigned int hop_seq;  // [0] main stream reached stencil n, [1] faces of stencil n received, [2] a bounded wait gave up
+  unsigned long long flag_timeout_ticks;           // bound of the device-side flag waits in ticks of the 100 MHz clock (0 = none)
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
   double *deriv;
   double *momenta;     // hamiltonian_field_t::momenta, su3adj [V][4] = double [V][4][8], resident for tmhip_update_gauge (md_update.hip)
@@ -114,15 +117,15 @@ struct tmhip_ctx {
   int mixed_trace[256]; int mixed_trace_n;   // inner iteration count of every outer iteration of the last tmhip_mixed_cg_her
   // options
   int opt_block, opt_xcd, opt_nt, opt_minw, opt_occ, opt_occ32;        // stencil launch shape (tmhip_set_option, include/tmlqcd_hip.h)
-  int opt_tgrp, opt_shape, opt_gaux, opt_gdrop;
+  int opt_tgrp;
   int opt_gauge_cache;                                                  // -1 automatic; 0 / 1: small-lattice launches load the links with / without the streaming hint
   int opt_hopsplit;                                                     // -1 automatic, 0 / 1: the eight hops of a site spread over four waves (small unsplit lattices)
   int opt_stg32;                                                        // the same for the fp32 stencil (default 0: measured slower there)
   int opt_stg;                                                          // 1 = LDS-staged stencil (own-block input spinors staged once, y/z neighbours read from LDS)
   int opt_recon;                                                        // 12 = rebuild the third row of every link in registers (opt-in)
-  int opt_flagsync, opt_fusedface, opt_facesplit;                       // split path
+  int opt_split_sync;                                                   // 0: the exterior kernel / the pack kernel wait for a flag of the other stream (default); 1: HIP events, no device-side wait
+  int opt_comm_split;                                                   // 0: do not split off a second communicator (exercises the one-communicator fallback)
   int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot;                      // cg_her
-  int opt_bench_graph;
   int opt_swall_order;                                                  // block order of the owner-computes sw_all: 0 one contiguous chunk per XCD, 1 slab order
   int opt_swall_atomic;                                                 // 1 = sw_all in the reference's scatter form (fp64 atomics), A/B only
   double gauge_recon_dev;   // max |U_row2 - conj(row0 x row1)| over all links of the resident gauge field (-1: not measured)
@@ -149,25 +152,24 @@ static inline bool tmhip_reduce_over_ranks(const tmhip_ctx *ctx) { return ctx->c
 enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4, EPI_CLOVER_INV = 5, EPI_CLOVER_G5 = 6, EPI_CLOVER = 7,
        EPI_TM_SUB_G5_NRM = 8 /* + partials of |out|^2 */, EPI_TM_SUB_G5_RES = 9 /* resid -= alpha out, partials of |resid|^2; out not stored */,
        EPI_CLOVER_G5_NRM = 10, EPI_CLOVER_G5_RES = 11 /* the same two on top of the clover_gamma5 epilogue */ };
-// `comm`: 0 no halo exchange (Hopping_Matrix_nocom), HOP_COMM exchange first, HOP_COMM | HOP_CHAINED additionally promises that the
-// face slices of `in` were final before the previous split-phase stencil of this context finished on the comm stream (its own
-// output, or a field not written since), so the faces of `in` may be packed and exchanged while the main stream is still busy
-enum { HOP_COMM = 1, HOP_CHAINED = 2 };
+// `comm`: 0 no halo exchange (Hopping_Matrix_nocom), HOP_COMM exchange the faces of `in` first
+enum { HOP_COMM = 1 };
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
                          double cre, double cim, int comm, const v2d *cw = nullptr);
 // mode 0: partials of <dotv, out>; 1: of |out|^2; 2: resid -= (*scal) * out without storing out, partials of |resid|^2
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
                              double cre, double cim, int *npartials, int mode = 0, v2d *resid = nullptr, const double *scal = nullptr,
-                             const v2d *cw = nullptr, int chained = 0);   // cw: clover blocks => clover_gamma5 epilogue (modes 1, 2 only)
+                             const v2d *cw = nullptr);   // cw: clover blocks => clover_gamma5 epilogue (modes 1, 2 only)
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
                            double cre, double cim, int comm, const v2f *cw = nullptr);
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
                                double cre, double cim, int *npartials, int mode = 0, v2f *resid = nullptr, const double *scal = nullptr,
-                               const v2f *cw = nullptr, int chained = 0);
+                               const v2f *cw = nullptr);
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx);
 int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out);
-// After a host-visible synchronisation of a T-split rank: non-zero (with a message) when a bounded cross-stream flag wait gave up,
-// i.e. the result just synchronised may have been computed from stale faces.  Free when no split-phase stencil has run.
+// After a host-visible synchronisation of a T-split rank: non-zero (with a message) when a bounded device-side wait for the
+// neighbours' faces gave up ("flag_timeout_ms") or the communicator reports an asynchronous error, i.e. the result just
+// synchronised cannot be trusted.  Reported once per occurrence -- the error word is cleared, the next call starts clean.
 int tmhip_check_async_error(tmhip_ctx *ctx);
 extern "C" int tmhip_check_gauge_recon(tmhip_ctx *ctx);   // context.hip: unitarity guard of the gauge_recon=12 option
 int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes);

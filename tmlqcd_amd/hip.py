@@ -138,6 +138,8 @@ def load_library():
         "tmhip_comm_init": [vp, C.c_char_p],
         "tmhip_comm_set_loopback": [vp, i],
         "tmhip_comm_count": [vp, C.POINTER(i), C.POINTER(i)],
+        "tmhip_comm_is_split": [vp],
+        "tmhip_comm_stream_delay_ms": [vp, i],
         "tmhip_bench_hopping": [vp, vp, vp, vp, i, pd],
         "tmhip_multi_hopping_matrix": [i, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp)],
         "tmhip_event_record": [vp, i],
@@ -608,8 +610,17 @@ class Lattice:
         _ck(self.lib.tmhip_comm_count(self.h, C.byref(a), C.byref(b)), "tmhip_comm_count")
         return a.value, b.value
 
+    def comm_is_split(self):
+        """True: reductions on their own communicator; False: they share the face communicator; None: no communicator."""
+        v = self.lib.tmhip_comm_is_split(self.h)
+        return None if v < 0 else bool(v)
+
     def set_loopback(self, on):
         _ck(self.lib.tmhip_comm_set_loopback(self.h, int(on)), "tmhip_comm_set_loopback")
+
+    def comm_stream_delay_ms(self, ms):
+        """Test hook: hold the comm stream back for `ms` milliseconds in front of the next halo exchange (a late neighbour)."""
+        _ck(self.lib.tmhip_comm_stream_delay_ms(self.h, int(ms)), "tmhip_comm_stream_delay_ms")
 
     # --- measurement ------------------------------------------------------
     def bench_hopping(self, f0, f1, f2, iters):

@@ -15,7 +15,7 @@ lat = Lattice(T, L, L, L, kappa=0.125, mu=0.01)
 lat.set_gauge(syn.gauge_field(1, T, L, L, L))
 f0 = lat.field(syn.spinor_field_eo(2, 0, T, L, L, L))
 f1, f2 = lat.field(), lat.field()
-keys = ("shape", "tgrp", "occ", "block")
+keys = ("tgrp", "occ", "block")
 grid = list(itertools.product((1, 2, 4), (2, 4, 8), (2, 3), (256,))) + [(1, 4, 3, 64), (1, 2, 3, 64), (1, 8, 3, 64)]
 res = {v: ([], []) for v in grid}
 iters = 10
