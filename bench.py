@@ -6,9 +6,13 @@ A "step" is one iteration of the reference's timed loop (benchmark.c:291-300):
 on fields resident in HBM.  `value` follows benchmark.c:318,327: Mflop/s = nranks * 1608 / (us per
 site-update).  N=1 workload: 32^4 fp64 (BASELINE.json configs[2]); N>1: weak scaling, every rank
 holds a 32^4 slab of a 32^3 x (32 N) lattice split in T, half-spinor faces exchanged over RCCL
-and overlapped with the interior stencil; the same run also measures BASELINE configs[3]
-(32^3 x 64 split N ways, the `strong` object) after checking it slab by slab against the unsplit
-lattice computed on rank 0 (`rank_check`).
+and overlapped with the stencil; the same run also measures BASELINE configs[3] (32^3 x 64 split
+N ways, the `strong` object) and north_star's literal "32^4 at 1/2/4/8 GPUs" (32^4 split N ways,
+`strong_32`), each after checking it slab by slab against the unsplit lattice computed on rank 0
+BEFORE the split operations start (`rank_check`).  Every leg is a sequence of steps the ranks
+agree on (class Phase): if any rank fails a step, all ranks leave that leg at that step -- nobody
+goes on into a halo exchange or a collective the others will not reach -- and the line is still
+printed.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -47,10 +51,12 @@ def parse(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-rows", action="store_true", help="skip the informational next-row legs (MD step, ILDG record)")
     ap.add_argument("--no-rank-check", action="store_true", help="N > 1: skip the multi-rank parity check and the configs[3] leg")
+    ap.add_argument("--rehearse-split", action="store_true",
+                    help="one GPU, with --loopback: run the multi-rank legs (rank check against the unsplit lattice, configs[3], 32^4 / N) as a world of one rank "
+                         "exchanging with itself -- the code path the N > 1 run takes, minus the rendezvous")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (A/B runs)")
     ap.add_argument("--loopback", type=int, default=0,
-                    help="1-GPU rehearsal of the multi-GPU path: 1 = faces exchanged with self by D2D copies, 2 = through a one-rank RCCL communicator, "
-                         "3 = written straight into the receive buffers by the pack kernel (diagnostic)")
+                    help="1-GPU rehearsal of the multi-GPU path: 1 = faces exchanged with self by a D2D copy, 2 = through a one-rank RCCL communicator")
     return ap.parse_args(argv)
 
 
@@ -74,7 +80,7 @@ def parent_launch(n):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
     for ln in r.stdout.splitlines():
-        if ln.startswith("{") and ("\"metric\"" in ln or "\"rendezvous\"" in ln):
+        if ln.startswith("{") and ("\"metric\"" in ln or "\"rendezvous\"" in ln or "\"selftest\"" in ln):
             line = ln
         else:
             sys.stderr.write(ln + "\n")
@@ -100,6 +106,36 @@ def rendezvous_only(world, rank):
     if rank == 0:
         print(json.dumps({"rendezvous": "ok", "n_gpus": world, "pids": t.tolist(), "backend": "gloo"}), flush=True)
     dist.destroy_process_group()
+    return 0
+
+
+def agree_selftest(world, rank):
+    """TMLQCD_BENCH_AGREE_SELFTEST=1 (CPU test, gloo): the phase / step / agree machinery of the multi-rank run without a GPU.
+    The "rank check" phase has the real one's shape (local set-up, the reference on rank 0, the split operations, a gather, the
+    comparison); TMLQCD_BENCH_INJECT_FAIL makes one rank fail in one step.  Whatever happens there, every rank leaves the phase
+    at the same step, all of them run the headline phase, and rank 0 prints ONE well-formed line."""
+    import numpy as np
+    R = Ranks(world, rank, rank, True, backend="gloo")
+    extra, trace = {}, []
+    ph = Phase(R, "rank_check")
+    try:
+        ph.step("setup", lambda: trace.append("setup"))
+        ph.step("reference", lambda: trace.append("reference") if rank == 0 else None)
+        ph.step("split_ops", lambda: trace.append("split_ops"))
+        got = ph.collective(lambda: R.gather0(np.full(4, float(rank))))
+        ph.step("compare", lambda: trace.append("compare:%s" % (None if got is None else [float(g[0]) for g in got])))
+        ph.step("timing", lambda: trace.append("timing"))
+        extra["rank_check"] = {"ok": True}
+    except PhaseAbort:
+        extra["rank_check"] = dict(ph.error, ok=False)
+    hl = Phase(R, "headline")
+    hl.step("timing", lambda: trace.append("headline"))
+    mx = R.allmax(float(len(trace)))
+    traces = R.gather0(np.frombuffer(("|".join(trace)).ljust(256).encode(), dtype=np.uint8).copy())
+    if rank == 0:
+        print(json.dumps(dict(extra, selftest="agree", n_gpus=world, max_steps_run=mx,
+                              traces=[bytes(t.tolist()).decode().strip() for t in traces])), flush=True)
+    R.close()
     return 0
 
 
@@ -184,12 +220,14 @@ def cpu_baseline(args, T, L, gpu_out):
 
 # ----------------------------------------------------------------------------------------------- one rank
 class Ranks:
-    """torch.distributed plumbing of one rank (rendezvous, barrier, max over ranks, gather to rank 0)."""
+    """torch.distributed plumbing of one rank (rendezvous, barrier, max over ranks, gather to rank 0).  backend "nccl" (= RCCL,
+    tensors on the rank's GPU) for the real run, "gloo" (CPU tensors) for the CPU tests of the launcher and of `agree`."""
 
-    def __init__(self, world, rank, local_rank, force):
+    def __init__(self, world, rank, local_rank, force, backend="nccl"):
         self.world, self.rank, self.local_rank = world, rank, local_rank
         self.on = world > 1 or force
         self.torch = self.dist = None
+        self.dev = "cpu"
         if self.on:
             # torch first: its bundled HIP/RCCL runtime must be the one every later library binds to
             import torch
@@ -197,31 +235,48 @@ class Ranks:
             self.torch, self.dist = torch, dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            ndev = torch.cuda.device_count()
-            if local_rank >= ndev:
-                raise SystemExit("[bench] rank %d wants GPU %d but this node shows %d device(s)" % (rank, local_rank, ndev))
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if backend == "nccl":
+                ndev = torch.cuda.device_count()
+                if local_rank >= ndev:
+                    raise SystemExit("[bench] rank %d wants GPU %d but this node shows %d device(s)" % (rank, local_rank, ndev))
+                torch.cuda.set_device(local_rank)
+                self.dev = "cuda"
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier(self, lat=None):
         if lat is not None:
             lat.sync()
         if self.on:
-            self.torch.cuda.synchronize()
+            if self.dev == "cuda":
+                self.torch.cuda.synchronize()
             self.dist.barrier()
 
     def allmax(self, *vals):
         if not self.on:
             return vals if len(vals) > 1 else vals[0]
-        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         out = [float(x) for x in t]
         return out if len(out) > 1 else out[0]
 
+    def agree(self, ok):
+        """Every rank calls this at the same point with its own verdict; every rank gets the same answer: the list of ranks that
+        reported a failure (empty = go on).  One all-reduce of a status word per rank -- the ranks of a multi-rank run must take
+        the same branch, or they meet in mismatched collectives (benchmark.c has the same shape: every rank runs every phase)."""
+        if not self.on:
+            return [] if ok else [0]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.dev)
+        if not ok:
+            t[self.rank] = 1.0
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [i for i, v in enumerate(t.tolist()) if v > 0.5]
+
     def bcast_uid(self, uid_bytes):
         if not self.on:
             return uid_bytes
-        u = self.torch.zeros(128, dtype=self.torch.uint8, device="cuda")
+        u = self.torch.zeros(128, dtype=self.torch.uint8, device=self.dev)
         if self.rank == 0:
             u.copy_(self.torch.tensor(list(uid_bytes), dtype=self.torch.uint8))
         self.dist.broadcast(u, 0)
@@ -232,7 +287,7 @@ class Ranks:
         import numpy as np
         if not self.on:
             return [arr]
-        t = self.torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+        t = self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.dev)
         bufs = [self.torch.empty_like(t) for _ in range(self.world)] if self.rank == 0 else None
         self.dist.gather(t, bufs, dst=0)
         return [b.cpu().numpy() for b in bufs] if self.rank == 0 else None
@@ -242,58 +297,117 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def make_lattice(R, T, L, args, nproc_t):
+class PhaseAbort(Exception):
+    """Raised on EVERY rank at the same step when any rank reported a failure there."""
+
+
+class Phase:
+    """A leg of the run as a sequence of steps.  step(name, fn) runs fn on this rank (exceptions are caught), then all ranks
+    agree on the outcome; if any rank failed, every rank leaves the phase at this very step (PhaseAbort) -- nobody goes on into
+    a collective the others will not reach.  fn may call the library (whose halo exchanges are collective over the ranks: every
+    rank runs the same fn) but no torch.distributed collective: those are steps of their own (`collective`).
+    TMLQCD_BENCH_INJECT_FAIL="<rank>:<step name>" makes that rank raise in that step (the CPU test of this machinery)."""
+
+    def __init__(self, R, name):
+        self.R, self.name = R, name
+        self.error = None          # (step, failed ranks, this rank's message) once aborted
+        inj = os.environ.get("TMLQCD_BENCH_INJECT_FAIL", "")
+        self.inject = inj.split(":", 1) if ":" in inj else None
+
+    def step(self, name, fn):
+        val, msg = None, None
+        try:
+            if self.inject and int(self.inject[0]) == self.R.rank and self.inject[1] == name:
+                raise RuntimeError("injected failure in step %r on rank %d" % (name, self.R.rank))
+            val = fn()
+        except Exception as e:    # noqa: BLE001 -- every failure of a rank has to reach the agreement below
+            msg = repr(e)
+        failed = self.R.agree(msg is None)
+        if failed:
+            self.error = {"phase": self.name, "step": name, "failed_ranks": failed, "error": msg}
+            sys.stderr.write("[bench] rank %d: phase %r stops at step %r (failed ranks %s)%s\n"
+                             % (self.R.rank, self.name, name, failed, ": " + msg if msg else ""))
+            raise PhaseAbort(name)
+        return val
+
+    def collective(self, fn):
+        """A torch.distributed collective: reached by all ranks (the step before it was agreed on), not wrapped."""
+        return fn()
+
+
+def make_lattice(ph, R, T, L, args, nproc_t):
+    """Lattice of this rank; on a T-split lattice the RCCL ring along T for the half-spinor faces (+ its split for the reductions):
+    unique id from rank 0, broadcast by the host program (tmLQCD: MPI_Bcast).  Every rank runs every step."""
     from tmlqcd_amd import Lattice
-    lat = Lattice(T, L, L, L, kappa=0.125, mu=0.01, nproc_t=nproc_t, proc_t=R.rank if nproc_t > 1 else 0, device=R.local_rank)
+    box = {}
+
+    def create():
+        lat = Lattice(T, L, L, L, kappa=0.125, mu=0.01, nproc_t=nproc_t, proc_t=R.rank if nproc_t > 1 else 0, device=R.local_rank)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            lat.set_option(k, int(v))
+        box["lat"] = lat
+        box["uid"] = lat.comm_unique_id() if (R.on and nproc_t > 1 and R.rank == 0) else b"\0" * 128
+    ph.step("create lattice", create)
+    lat = box["lat"]
     if R.on and nproc_t > 1:
-        # RCCL ring along T for the half-spinor faces (+ its split for the reductions): unique id from rank 0, broadcast by the host program
-        lat.comm_init(R.bcast_uid(lat.comm_unique_id() if R.rank == 0 else b"\0" * 128))
+        uid = ph.collective(lambda: R.bcast_uid(box["uid"]))
+        ph.step("comm_init", lambda: lat.comm_init(uid))
     if args.loopback and R.world == 1:
         lat.set_loopback(args.loopback)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        lat.set_option(k, int(v))
     return lat
 
 
-def time_hopping(R, lat, f0, f1, f2, steps, warmup):
-    """warmup untimed steps, then exactly `steps` steps between two barriers; max over ranks of (wall seconds, HIP-event ms)."""
-    lat.bench_hopping(f0, f1, f2, max(warmup, 1))
-    R.barrier(lat)
-    t0 = time.perf_counter()
-    ev_ms = lat.bench_hopping(f0, f1, f2, steps)     # HIP events on the stream the kernels run on
-    R.barrier(lat)
-    dt = time.perf_counter() - t0
-    return R.allmax(dt, ev_ms)
+def time_hopping(ph, R, lat, f0, f1, f2, steps, warmup, what="hopping"):
+    """warmup untimed steps, then exactly `steps` steps bracketed by a barrier + synchronisation on both sides (the closing one is
+    the step's own agreement all-reduce); max over ranks of (wall seconds, HIP-event ms)."""
+    ph.step(what + " warm-up", lambda: (lat.bench_hopping(f0, f1, f2, max(warmup, 1)), lat.sync()))
+    ph.collective(lambda: R.barrier(lat))
+
+    def timed():
+        t0 = time.perf_counter()
+        ev_ms = lat.bench_hopping(f0, f1, f2, steps)     # HIP events on the stream the kernels run on
+        lat.sync()
+        return time.perf_counter() - t0, ev_ms
+    dt, ev = ph.step(what + " timed loop", timed)
+    return ph.collective(lambda: R.allmax(dt, ev))
 
 
-def time_nocom(R, lat, f0, f1, f2, steps):
+def time_nocom(ph, R, lat, f0, f1, f2, steps):
     """benchmark.c:336-374: the same loop with communication switched off (Hopping_Matrix_nocom: stale faces)."""
-    for _ in range(2):
-        lat.Hopping_Matrix_nocom(0, f1, f0)
-        lat.Hopping_Matrix_nocom(1, f2, f1)
-    R.barrier(lat)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        lat.Hopping_Matrix_nocom(0, f1, f0)
-        lat.Hopping_Matrix_nocom(1, f2, f1)
-    R.barrier(lat)
-    return R.allmax(time.perf_counter() - t0)
+    def loop(n):
+        for _ in range(n):
+            lat.Hopping_Matrix_nocom(0, f1, f0)
+            lat.Hopping_Matrix_nocom(1, f2, f1)
+        lat.sync()
+    ph.step("nocom warm-up", lambda: loop(2))
+    ph.collective(lambda: R.barrier(lat))
+
+    def timed():
+        t0 = time.perf_counter()
+        loop(steps)
+        return time.perf_counter() - t0
+    dt = ph.step("nocom timed loop", timed)
+    return ph.collective(lambda: R.allmax(dt))
 
 
-def time_cg(R, lat, P, Q, total_iters, n_short=5, n_long=25):
+def time_cg(ph, R, lat, P, Q, total_iters, n_short=5, n_long=25):
     """cg_her iterations/s on a LIVE residual: every solve starts from P = 0 and stops after a fixed count, long before the
     residual of this well-conditioned system reaches the rounding floor (it needs ~24 iterations per 10 orders); the per-iteration time is
     (t(n_long) - t(n_short)) / (n_long - n_short), so the once-per-solve set-up (cg_her.c:82-88) is not counted as iterations."""
     reps = max(1, total_iters // (n_long - n_short))
 
     def solve(n):
-        P.zero()
-        R.barrier(lat)
-        t0 = time.perf_counter()
-        lat.cg_her(P, Q, n, 0.0, 1, lat.Vh)
-        R.barrier(lat)
-        return R.allmax(time.perf_counter() - t0)
+        ph.step("cg zero", lambda: (P.zero(), lat.sync()))
+        ph.collective(lambda: R.barrier(lat))
+
+        def timed():
+            t0 = time.perf_counter()
+            lat.cg_her(P, Q, n, 0.0, 1, lat.Vh)
+            lat.sync()
+            return time.perf_counter() - t0
+        dt = ph.step("cg_her %d iterations" % n, timed)
+        return ph.collective(lambda: R.allmax(dt))
     solve(n_short)
     solve(n_long)
     ts = tl = 0.0
@@ -306,49 +420,108 @@ def time_cg(R, lat, P, Q, total_iters, n_short=5, n_long=25):
             "ms_per_solve_setup": 1e3 * (ts / reps - n_short * (tl - ts) / iters)}
 
 
-def rank_check(R, S, T_loc, L, args):
-    """The multi-rank path against the unsplit lattice, inside the run that is about to be timed (body of tools/multi_rank_check.py):
-    Hopping_Matrix, Hopping_Matrix_nocom (shape only), Qtm_pm_psi, a global norm (ncclAllReduce) and a cg_her solve on the T-split
-    lattice held by lattice S of every rank, gathered to rank 0 and compared slab by slab with the same operations on the
-    unsplit (T_loc * world) x L^3 lattice computed on rank 0's GPU."""
+def split_leg(R, args, L, Tg, what, steps):
+    """One global Tg x L^3 lattice split in T over the ranks, inside the run that is about to be timed:
+      1. every rank builds its slab; rank 0 ALSO computes the unsplit lattice (Hopping_Matrix, Qtm_pm_psi, a global norm, a
+         cg_her solve) on its GPU -- BEFORE any split operation, while the other ranks wait in the step's agreement: nobody starts
+         a halo exchange its neighbour is not ready for (tmLQCD's ranks arrive together the same way: MPI_Barrier, benchmark.c:263);
+      2. the same operations on the split lattice, gathered to rank 0 and compared slab by slab (`rank_check`);
+      3. the benchmark.c loop, its communication-free twin (benchmark.c:336-374) and cg_her on the split lattice.
+    Returns (check, timing); either is a dict with ok = False and the step that failed when a rank reported a failure --
+    every rank leaves the leg at that same step."""
     import numpy as np
     from tmlqcd_amd import Lattice
     from tmlqcd_amd import synthetic as syn
     w, r = R.world, R.rank
-    k = S.field(syn.spinor_field_eo(8, 0, T_loc, L, L, L, w, r))
-    l, q, P = S.field(), S.field(), S.field()
-    S.Hopping_Matrix(0, l, k)
-    S.Qtm_pm_psi(q, k)
-    nrm = S.square_norm(q, S.Vh, 1)
-    it, hist = S.cg_her(P, k, 2000, 1e-20, 1, S.Vh)
-    got = [R.gather0(f.download()) for f in (l, q, P)]
-    for f in (k, l, q, P):
-        f.free()
-    out = None
-    if r == 0:
-        Tg = T_loc * w
-        G = Lattice(Tg, L, L, L, kappa=0.125, mu=0.01, device=R.local_rank)
-        G.set_gauge(syn.gauge_field(7, Tg, L, L, L))
-        gk = G.field(syn.spinor_field_eo(8, 0, Tg, L, L, L))
-        gl, gq, gP = G.field(), G.field(), G.field()
-        G.Hopping_Matrix(0, gl, gk)
-        G.Qtm_pm_psi(gq, gk)
-        gn = G.square_norm(gq, G.Vh, 1)
-        git, _ = G.cg_her(gP, gk, 2000, 1e-20, 1, G.Vh)
-        ref = [gl.download(), gq.download(), gP.download()]
-        G.close()
-        Vh = T_loc * L ** 3 // 2
-        dev = []
-        for slabs, b in zip(got, ref):
-            sc = np.abs(b).max()
-            dev.append(max(float(np.abs(slabs[j] - b[j * Vh:(j + 1) * Vh]).max() / sc) for j in range(w)))
-        out = {"lattice": "%dx%d^3 split in T over %d ranks (T_local %d) vs the unsplit lattice on rank 0" % (Tg, L, w, T_loc),
-               "hopping_matrix_max_rel_dev": dev[0], "qtm_pm_psi_max_rel_dev": dev[1], "cg_solution_max_rel_dev": dev[2],
-               "global_norm_rel_dev": abs(nrm - gn) / gn, "cg_iters_split": it, "cg_iters_unsplit": git,
-               "worst_operator_dev": max(dev[0], dev[1], abs(nrm - gn) / gn)}
-        out["ok"] = bool(dev[0] <= 1e-13 and dev[1] <= 1e-13 and out["global_norm_rel_dev"] <= 1e-13 and abs(it - git) <= 1 and dev[2] <= 1e-8)
-        sys.stderr.write("[bench] rank check: %s\n" % json.dumps(out))
-    return out
+    Ts = Tg // w
+    ph = Phase(R, what)
+    chk = tim = None
+    box = {}
+    try:
+        S = make_lattice(ph, R, Ts, L, args, w)
+        box["S"] = S
+
+        def upload():
+            S.set_gauge(syn.gauge_field(7, Ts, L, L, L, w, r))
+            box["k"] = S.field(syn.spinor_field_eo(8, 0, Ts, L, L, L, w, r))
+            box["q9"] = S.field(syn.spinor_field_eo(9, 1, Ts, L, L, L, w, r))
+            box["comm"] = {"rccl_nranks": list(S.comm_count()), "comm_split": S.comm_is_split()}
+            S.sync()
+        ph.step("upload", upload)
+
+        def reference():
+            if r != 0:
+                return
+            G = Lattice(Tg, L, L, L, kappa=0.125, mu=0.01, device=R.local_rank)
+            G.set_gauge(syn.gauge_field(7, Tg, L, L, L))
+            gk = G.field(syn.spinor_field_eo(8, 0, Tg, L, L, L))
+            gl, gq, gP = G.field(), G.field(), G.field()
+            G.Hopping_Matrix(0, gl, gk)
+            G.Qtm_pm_psi(gq, gk)
+            gn = G.square_norm(gq, G.Vh, 1)
+            git, _ = G.cg_her(gP, gk, 2000, 1e-20, 1, G.Vh)
+            box["ref"] = ([gl.download(), gq.download(), gP.download()], gn, git)
+            G.close()
+        ph.step("unsplit reference on rank 0", reference)      # the other ranks wait here, in the agreement
+
+        def split_ops():
+            k = box["k"]
+            l, q, P = S.field(), S.field(), S.field()
+            S.Hopping_Matrix(0, l, k)
+            S.Qtm_pm_psi(q, k)
+            nrm = S.square_norm(q, S.Vh, 1)
+            it, _ = S.cg_her(P, k, 2000, 1e-20, 1, S.Vh)
+            box["mine"] = ([f.download() for f in (l, q, P)], nrm, it)
+            for f in (l, q, P):
+                f.free()
+        ph.step("split operators", split_ops)
+        got = [ph.collective(lambda j=j: R.gather0(box["mine"][0][j])) for j in range(3)]
+
+        def compare():
+            if r != 0:
+                return None
+            ref, gn, git = box["ref"]
+            _, nrm, it = box["mine"]
+            Vh = Ts * L ** 3 // 2
+            dev = []
+            for slabs, b in zip(got, ref):
+                sc = np.abs(b).max()
+                dev.append(max(float(np.abs(slabs[j] - b[j * Vh:(j + 1) * Vh]).max() / sc) for j in range(w)))
+            out = {"lattice": "%dx%d^3 split in T over %d ranks (T_local %d) vs the unsplit lattice on rank 0" % (Tg, L, w, Ts),
+                   "hopping_matrix_max_rel_dev": dev[0], "qtm_pm_psi_max_rel_dev": dev[1], "cg_solution_max_rel_dev": dev[2],
+                   "global_norm_rel_dev": abs(nrm - gn) / gn, "cg_iters_split": it, "cg_iters_unsplit": git,
+                   "worst_operator_dev": max(dev[0], dev[1], abs(nrm - gn) / gn)}
+            out["ok"] = bool(dev[0] <= 1e-13 and dev[1] <= 1e-13 and out["global_norm_rel_dev"] <= 1e-13 and abs(it - git) <= 1 and dev[2] <= 1e-8)
+            out.update(box["comm"])
+            sys.stderr.write("[bench] %s rank check: %s\n" % (what, json.dumps(out)))
+            return out
+        chk = ph.step("compare with the unsplit lattice", compare)
+
+        f0, f1, f2 = box["k"], S.field(), S.field()
+        dts, evs = time_hopping(ph, R, S, f0, f1, f2, steps, args.warmup, what="split hopping")
+        dtn = time_nocom(ph, R, S, f0, f1, f2, steps)
+        cgs = time_cg(ph, R, S, S.field(), box["q9"], min(args.cg_iters, 100))
+        Vs = Ts * L ** 3
+        tim = {"config": "global %dx%d^3 split in T over %d GPUs (T_local %d), half-spinor faces over RCCL" % (Tg, L, w, Ts),
+               "value": w * 1608.0 / (1e6 * dts / (steps * Vs)), "unit": "Mflop/s", "ms_per_step": 1e3 * dts / steps,
+               "us_per_launch": 1e3 * evs / (2 * steps), "steps": steps, "cg_iters_per_s": cgs["iters_per_s"],
+               "nocom": {"value": w * 1608.0 / (1e6 * dtn / (steps * Vs)), "ms_per_step": 1e3 * dtn / steps,
+                         "exposed_comm_ms_per_step": 1e3 * (dts - dtn) / steps,
+                         "note": "communication switched off (Hopping_Matrix_nocom), benchmark.c:336-374"}}
+        tim.update(box["comm"])
+    except PhaseAbort:
+        err = dict(ph.error, ok=False)
+        if chk is None:
+            chk = err
+        else:
+            tim = err
+    finally:
+        if "S" in box:
+            try:
+                box["S"].close()
+            except Exception:   # noqa: BLE001
+                pass
+    return chk, tim
 
 
 def rank_main(args, world, rank, local_rank):
@@ -358,41 +531,33 @@ def rank_main(args, world, rank, local_rank):
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     R = Ranks(world, rank, local_rank, os.environ.get("TMLQCD_BENCH_FORCE_TORCH") == "1")
-    import numpy as np
+    import numpy as np   # noqa: F401 (the next-row legs)
     from tmlqcd_amd import Lattice
     from tmlqcd_amd import synthetic as syn
 
     L = args.L
     extra = {}
     # ---------------------------------------------------------------- N > 1: multi-rank parity check + BASELINE configs[3] (strong scaling)
-    if world > 1 and not args.no_rank_check:
-        try:
-            Tg = 64
-            if Tg % world or (Tg // world) % 2 or Tg // world < 2:
-                Tg = 8 * world                                      # odd rank counts: any even split serves the check
-            Ts = Tg // world
-            S = make_lattice(R, Ts, L, args, world)
-            S.set_gauge(syn.gauge_field(7, Ts, L, L, L, world, rank))
-            extra["rccl_nranks"] = list(S.comm_count())
-            chk = rank_check(R, S, Ts, L, args)
-            f0 = S.field(syn.spinor_field_eo(8, 0, Ts, L, L, L, world, rank))
-            f1, f2 = S.field(), S.field()
-            steps = max(args.steps, 20)
-            dts, evs = time_hopping(R, S, f0, f1, f2, steps, args.warmup)
-            dtn = time_nocom(R, S, f0, f1, f2, steps)
-            P, Q = S.field(), S.field(syn.spinor_field_eo(9, 1, Ts, L, L, L, world, rank))
-            cgs = time_cg(R, S, P, Q, min(args.cg_iters, 100))
-            Vs = Ts * L ** 3
-            extra["strong"] = {"config": "BASELINE configs[3]: global %dx%d^3 split in T over %d GPUs (T_local %d), half-spinor faces over RCCL" % (Tg, L, world, Ts),
-                               "value": world * 1608.0 / (1e6 * dts / (steps * Vs)), "unit": "Mflop/s", "ms_per_step": 1e3 * dts / steps,
-                               "us_per_launch": 1e3 * evs / (2 * steps), "steps": steps, "cg_iters_per_s": cgs["iters_per_s"],
-                               "nocom": {"value": world * 1608.0 / (1e6 * dtn / (steps * Vs)), "ms_per_step": 1e3 * dtn / steps,
-                                         "exposed_comm_ms_per_step": 1e3 * (dts - dtn) / steps,
-                                         "note": "communication switched off (Hopping_Matrix_nocom), benchmark.c:336-374"}}
-            extra["rank_check"] = chk
-            S.close()
-        except Exception as e:   # the check must never cost the headline line; its absence is visible in the line
-            extra["rank_check"] = {"ok": False, "error": repr(e)}
+    if (world > 1 or (args.rehearse_split and args.loopback)) and not args.no_rank_check:
+        Tg = 64
+        if Tg % world or (Tg // world) % 2 or Tg // world < 2:
+            Tg = 8 * world                                      # odd rank counts: any even split serves the check
+        steps_s = max(args.steps, 20)
+        chk, tim = split_leg(R, args, L, Tg, "configs[3]", steps_s)
+        extra["rank_check"] = chk
+        if tim is not None:
+            if tim.get("ok", True):
+                tim["config"] = "BASELINE configs[3]: " + tim["config"]
+            extra["strong"] = tim
+        for key in ("rccl_nranks", "comm_split"):
+            if isinstance(chk, dict) and key in chk:
+                extra[key] = chk[key]
+        # north_star's literal "32^4 at 1 / 2 / 4 / 8 GPUs": the headline lattice of ONE GPU cut N ways (T_local = 32 / N)
+        if L % world == 0 and (L // world) % 2 == 0:
+            chk32, tim32 = split_leg(R, args, L, L, "strong_32", steps_s)
+            if tim32 is not None and tim32.get("ok", True):
+                tim32["config"] = "north_star: 32^4 cut in T over N GPUs -- " + tim32["config"]
+            extra["strong_32"] = dict(tim32 or {}, rank_check=chk32)
 
     # ---------------------------------------------------------------- headline: weak scaling, L^4 per GPU (N = 1: BASELINE configs[2])
     T = args.T or L
@@ -401,104 +566,134 @@ def rank_main(args, world, rank, local_rank):
             raise SystemExit("--strong %d cannot be split evenly (even local T) over %d ranks" % (args.strong, world))
         T = args.strong // world
     V = T * L ** 3
-    lat = make_lattice(R, T, L, args, world)
-    if world > 1:
-        extra.setdefault("rccl_nranks", list(lat.comm_count()))
-    gauge = syn.gauge_field(7, T, L, L, L, world, rank)
-    lat.set_gauge(gauge)
-    del gauge
-    src = syn.spinor_field_eo(8, 0, T, L, L, L, world, rank)
-    f0, f1, f2 = lat.field(src), lat.field(), lat.field()
-    dt, ev_ms = time_hopping(R, lat, f0, f1, f2, args.steps, args.warmup)
-    gpu_out = f2.download() if (rank == 0 and world == 1 and not args.no_cpu) else None
+    hl = Phase(R, "headline")
+    box = {}
+    try:
+        lat = make_lattice(hl, R, T, L, args, world)
 
-    # --- CG part of the metric: cg_her on Qtm_pm_psi (solver/cg_her.c:91-126)
-    P, Q = lat.field(), lat.field(syn.spinor_field_eo(9, 1, T, L, L, L, world, rank))
-    cg = time_cg(R, lat, P, Q, args.cg_iters)
+        def upload():
+            lat.set_gauge(syn.gauge_field(7, T, L, L, L, world, rank))
+            box["src"] = syn.spinor_field_eo(8, 0, T, L, L, L, world, rank)
+            box["f"] = (lat.field(box["src"]), lat.field(), lat.field())
+            box["PQ"] = (lat.field(), lat.field(syn.spinor_field_eo(9, 1, T, L, L, L, world, rank)))
+            lat.sync()
+        hl.step("upload", upload)          # its agreement is the barrier in front of the first split stencil: every rank has its links and fields
+        if world > 1:
+            extra.setdefault("rccl_nranks", list(lat.comm_count()))
+            extra.setdefault("comm_split", lat.comm_is_split())
+        src = box["src"]
+        f0, f1, f2 = box["f"]
+        dt, ev_ms = time_hopping(hl, R, lat, f0, f1, f2, args.steps, args.warmup)
+        gpu_out = f2.download() if (rank == 0 and world == 1 and not args.no_cpu) else None
+        # --- CG part of the metric: cg_her on Qtm_pm_psi (solver/cg_her.c:91-126)
+        P, Q = box["PQ"]
+        cg = time_cg(hl, R, lat, P, Q, args.cg_iters)
+    except PhaseAbort:
+        # the headline itself failed on some rank: still ONE well-formed line (value null, the step and the ranks), non-zero exit
+        if rank == 0:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            print(json.dumps(dict({"metric": METRIC, "value": None, "unit": "Mflop/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                   "higher_is_better": True, "error": hl.error}, **extra)), flush=True)
+            os.dup2(2, 1)
+        R.close()
+        return 1
+
+    def leg(name, body):
+        """An informational leg as a phase of its own: a failure (on any rank) costs this leg, never the headline line, and every
+        rank leaves it at the same step."""
+        ph = Phase(R, name)
+        try:
+            return body(ph)
+        except PhaseAbort:
+            return {"error": ph.error}
 
     # --- full-size property of the (multi-rank) operator: Q_+ = Q_-^dagger, i.e. Re<y, Q_+ x> = Re<Q_- y, x> with global sums
-    try:
-        y, a, b = lat.field(src), lat.field(), lat.field()
-        lat.op("Qtm_plus_psi", a, Q)
-        lat.op("Qtm_minus_psi", b, y)
-        s1, s2 = lat.scalar_prod_r(y, a, lat.Vh, 1), lat.scalar_prod_r(b, Q, lat.Vh, 1)
-        extra["hermiticity_rel_dev"] = abs(s1 - s2) / max(abs(s1), 1e-300)
-        for f in (y, a, b):
-            f.free()
-    except Exception as e:
-        extra["hermiticity_rel_dev"] = repr(e)
+    def herm(ph):
+        def fn():
+            y, a, b = lat.field(src), lat.field(), lat.field()
+            lat.op("Qtm_plus_psi", a, Q)
+            lat.op("Qtm_minus_psi", b, y)
+            s1, s2 = lat.scalar_prod_r(y, a, lat.Vh, 1), lat.scalar_prod_r(b, Q, lat.Vh, 1)
+            for f in (y, a, b):
+                f.free()
+            return abs(s1 - s2) / max(abs(s1), 1e-300)
+        return ph.step("Q_plus = Q_minus^dagger", fn)
+    extra["hermiticity_rel_dev"] = leg("hermiticity", herm)
 
     # --- time to solution: cg_her vs mixed_cg_her (fp32 inner / fp64 restart) to |r|/|b| = 1e-10 (BASELINE configs[1])
-    solve = {}
-    try:                                              # extra legs never cost the headline line
-        lat.mixed_cg_her(P, Q, 2, 1e-20, 1, lat.Vh)     # untimed: builds the fp32 gauge copy and work fields once per configuration
+    def solves(ph):
+        out = {}
+        ph.step("fp32 set-up", lambda: lat.mixed_cg_her(P, Q, 2, 1e-20, 1, lat.Vh))     # untimed: builds the fp32 gauge copy and work fields once per configuration
         for name in ("cg_her", "mixed_cg_her"):
-            P.zero()
-            R.barrier(lat)
-            t2 = time.perf_counter()
-            if name == "cg_her":
-                its, _ = lat.cg_her(P, Q, 5000, 1e-20, 1, lat.Vh)
-                outer = None
-            else:
-                its, outer = lat.mixed_cg_her(P, Q, 5000, 1e-20, 1, lat.Vh)
-            R.barrier(lat)
-            dts = time.perf_counter() - t2
-            Rf = lat.field()                             # true residual on the device in fp64
-            lat.Qtm_pm_psi(Rf, P)
-            lat.diff(Rf, Q, Rf, lat.Vh)
-            res = lat.square_norm(Rf, lat.Vh, 1) / lat.square_norm(Q, lat.Vh, 1)
-            Rf.free()
-            solve[name] = {"iters": its, "seconds": dts, "true_rel_res_sq": res}
+            ph.step("zero", lambda: (P.zero(), lat.sync()))
+            ph.collective(lambda: R.barrier(lat))
+
+            def timed(name=name):
+                t2 = time.perf_counter()
+                if name == "cg_her":
+                    its, outer = lat.cg_her(P, Q, 5000, 1e-20, 1, lat.Vh)[0], None
+                else:
+                    its, outer = lat.mixed_cg_her(P, Q, 5000, 1e-20, 1, lat.Vh)
+                lat.sync()
+                return its, outer, time.perf_counter() - t2
+            its, outer, dts = ph.step("solve " + name, timed)
+            dts = ph.collective(lambda: R.allmax(dts))
+
+            def residual():
+                Rf = lat.field()                             # true residual on the device in fp64
+                lat.Qtm_pm_psi(Rf, P)
+                lat.diff(Rf, Q, Rf, lat.Vh)
+                res = lat.square_norm(Rf, lat.Vh, 1) / lat.square_norm(Q, lat.Vh, 1)
+                Rf.free()
+                return res
+            out[name] = {"iters": its, "seconds": dts, "true_rel_res_sq": ph.step("true residual " + name, residual)}
             if outer is not None:
-                solve[name]["outer_iters"] = outer
-    except Exception as e:
-        solve["error"] = repr(e)
-    cg["solve_to_1e-10"] = solve
+                out[name]["outer_iters"] = outer
+        return out
+    cg["solve_to_1e-10"] = leg("solve to 1e-10", solves)
 
     # --- benchmark.c:336-374: on a split lattice the reference also times the loop with communication switched off
     nocom = None
-    try:
-        if world > 1 or args.loopback:
-            dtn = time_nocom(R, lat, f0, f1, f2, args.steps)
-            nocom = {"value": world * 1608.0 / (1e6 * dtn / (args.steps * V)), "unit": "Mflop/s", "ms_per_step": 1e3 * dtn / args.steps,
-                     "exposed_comm_ms_per_step": 1e3 * (dt - dtn) / args.steps,
-                     "note": "communication switched off (Hopping_Matrix_nocom), benchmark.c:336-374"}
-    except Exception as e:
-        nocom = {"value": None, "note": repr(e)}
+    if world > 1 or args.loopback:
+        def nocom_leg(ph):
+            dtn = time_nocom(ph, R, lat, f0, f1, f2, args.steps)
+            return {"value": world * 1608.0 / (1e6 * dtn / (args.steps * V)), "unit": "Mflop/s", "ms_per_step": 1e3 * dtn / args.steps,
+                    "exposed_comm_ms_per_step": 1e3 * (dt - dtn) / args.steps,
+                    "note": "communication switched off (Hopping_Matrix_nocom), benchmark.c:336-374"}
+        nocom = leg("nocom", nocom_leg)
 
     # --- informational: the same loop with the opt-in 12-real gauge read (third row of each link rebuilt in registers;
     # exact for SU(3) links, guarded on the device).  Never part of `value`: the headline is the plain 18-real path.
     recon = None
-    try:
-        if world > 1:
-            raise RuntimeError("single-GPU leg")      # keep the multi-rank run to the headline measurement
-        lat.set_option("gauge_recon", 12)
-        dt12, ev12 = time_hopping(R, lat, f0, f1, f2, args.steps, 2)
-        cg12 = time_cg(R, lat, P, Q, min(args.cg_iters, 100))
-        recon = {"value": world * 1608.0 / (1e6 * dt12 / (args.steps * V)), "unit": "Mflop/s", "cg_iters_per_s": cg12["iters_per_s"],
-                 "us_per_launch": 1e3 * ev12 / (2 * args.steps), "alg_bytes_per_site": 1152,
-                 "achieved_GBps": 1152.0 * (V // 2) / (ev12 * 1e-3 / (2 * args.steps)) / 1e9,
-                 "note": "opt-in tmhip_set_option(gauge_recon, 12); COMPRESSION_12 of misc_types.h:29-33"}
-    except Exception as e:                            # informational leg: never a reason to lose the headline line
-        recon = {"value": None, "note": repr(e)}
-    finally:
-        lat.set_option("gauge_recon", 18)
+    if world == 1:                                      # keep the multi-rank run to the headline measurement
+        def recon_leg(ph):
+            lat.set_option("gauge_recon", 12)
+            try:
+                dt12, ev12 = time_hopping(ph, R, lat, f0, f1, f2, args.steps, 2, what="recon12 hopping")
+                cg12 = time_cg(ph, R, lat, P, Q, min(args.cg_iters, 100))
+            finally:
+                lat.set_option("gauge_recon", 18)
+            return {"value": world * 1608.0 / (1e6 * dt12 / (args.steps * V)), "unit": "Mflop/s", "cg_iters_per_s": cg12["iters_per_s"],
+                    "us_per_launch": 1e3 * ev12 / (2 * args.steps), "alg_bytes_per_site": 1152,
+                    "achieved_GBps": 1152.0 * (V // 2) / (ev12 * 1e-3 / (2 * args.steps)) / 1e9,
+                    "note": "opt-in tmhip_set_option(gauge_recon, 12); COMPRESSION_12 of misc_types.h:29-33"}
+        recon = leg("gauge_recon 12", recon_leg)
 
     # --- BASELINE configs[1] (16^4, one GPU): the launch-bound end of the path
     cg16 = None
     if world == 1 and not args.loopback and (T, L) == (32, 32):
-        try:
+        def cg16_leg(ph):
             l16 = Lattice(16, 16, 16, 16, kappa=0.125, mu=0.01, device=local_rank)
             l16.set_gauge(syn.gauge_field(7, 16, 16, 16, 16))
             P16, Q16 = l16.field(), l16.field(syn.spinor_field_eo(9, 1, 16, 16, 16, 16))
-            c = time_cg(R, l16, P16, Q16, 200)
+            c = time_cg(ph, R, l16, P16, Q16, 200)
             g0, g1, g2 = l16.field(syn.spinor_field_eo(8, 0, 16, 16, 16, 16)), l16.field(), l16.field()
-            d16, e16 = time_hopping(R, l16, g0, g1, g2, 500, 50)
-            cg16 = {"lattice": "16^4", "iters_per_s": c["iters_per_s"], "ms_per_iter": c["ms_per_iter"],
-                    "hopping_us_per_launch": 1e3 * e16 / 1000, "hopping_Mflop/s": 1608.0 / (1e6 * d16 / (500 * 16 ** 4))}
+            d16, e16 = time_hopping(ph, R, l16, g0, g1, g2, 500, 50, what="16^4 hopping")
             l16.close()
-        except Exception as e:
-            cg16 = {"error": repr(e)}
+            return {"lattice": "16^4", "iters_per_s": c["iters_per_s"], "ms_per_iter": c["ms_per_iter"],
+                    "hopping_us_per_launch": 1e3 * e16 / 1000, "hopping_Mflop/s": 1608.0 / (1e6 * d16 / (500 * 16 ** 4))}
+        cg16 = leg("16^4", cg16_leg)
 
     # --- informational: the rows next to the path (SURVEY section 8 f) on the headline lattice, everything resident in HBM.  One
     # molecular-dynamics step of the clover determinant without its solves (update_gauge.c, clover_term.c, clover_invert.c, deriv_Sb.c,
@@ -609,6 +804,8 @@ def main():
             return 2
     if os.environ.get("TMLQCD_BENCH_RENDEZVOUS_ONLY") == "1":
         return rendezvous_only(world, rank)
+    if os.environ.get("TMLQCD_BENCH_AGREE_SELFTEST") == "1":
+        return agree_selftest(world, rank)
     return rank_main(args, world, rank, local_rank)
 
 

@@ -42,3 +42,39 @@ def test_under_torchrun_gpus_defaults_to_world_size():
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 2
+
+
+def _selftest(inject=None):
+    env = _env(TMLQCD_BENCH_AGREE_SELFTEST="1")
+    if inject:
+        env["TMLQCD_BENCH_INJECT_FAIL"] = inject
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                      # ONE well-formed line, whatever happened in the rank check
+    return json.loads(lines[0]), r.stderr
+
+
+def test_ranks_agree_all_steps_pass():
+    rec, _ = _selftest()
+    assert rec["rank_check"] == {"ok": True}
+    assert rec["traces"][0] == "setup|reference|split_ops|compare:[0.0, 1.0]|timing|headline"
+    assert rec["traces"][1] == "setup|split_ops|compare:None|timing|headline"      # (the reference is rank 0's job)
+
+
+def test_rank_1_check_raises_and_both_ranks_take_the_same_branch():
+    """rank 1's check raises -> BOTH ranks leave the rank-check leg at that step (no rank goes on into the
+    timing collectives alone), both run the headline, rank 0 relays one line naming the step and the rank."""
+    rec, err = _selftest("1:compare")
+    rc = rec["rank_check"]
+    assert rc["ok"] is False and rc["step"] == "compare" and rc["failed_ranks"] == [1] and rc["phase"] == "rank_check"
+    for tr in rec["traces"]:
+        assert tr.endswith("|headline") and "timing" not in tr      # neither rank ran the step behind the failed one
+    assert "injected failure" in err
+
+
+def test_rank_0_reference_raises_before_any_split_operation():
+    rec, _ = _selftest("0:reference")
+    rc = rec["rank_check"]
+    assert rc["ok"] is False and rc["step"] == "reference" and rc["failed_ranks"] == [0]
+    assert rec["traces"][0] == "setup|headline" and rec["traces"][1] == "setup|headline"     # no rank started the split operators

@@ -294,6 +294,40 @@ def test_cg_fused_split_path_wide_short_local_lattice():
     lat.close()
 
 
+def test_cg_fused_with_one_communicator_for_faces_and_reductions():
+    """The fallback of an RCCL without ncclCommSplit, forced ("comm_split" 0): the scalar all-reduces of the fused CG iteration run
+    on the SAME communicator as the face exchange, from the other stream.  Correct because the exchange of a stencil has completed
+    before anything enqueued behind that stencil on the main stream starts (launch_split, hopping_impl.inc).  One-rank RCCL
+    loopback on 8 x 16^3 == the unsplit solve; the library says which form it runs."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T, L = 8, 16
+    orc = Oracle(T, L, L, L, kappa=0.13, mu=0.015, threads=8)
+    g = syn.gauge_field(41, T, L, L, L)
+    orc.set_gauge(g)
+    q = syn.spinor_field_eo(42, 1, T, L, L, L)
+    N = orc.Vh
+    P = orc.new_field()
+    it_ref, hist_ref = orc.cg_her(P, q.copy(), 500, 1e-20, 1, N)
+    for split in (0, 1):
+        lat = Lattice(T, L, L, L, kappa=0.13, mu=0.015)
+        lat.set_gauge(g)
+        assert lat.comm_is_split() is None
+        lat.set_option("comm_split", split)
+        lat.set_loopback(2)
+        assert lat.comm_is_split() is bool(split) and lat.comm_count() == (1, 1)
+        dq, dp = lat.field(q), lat.field()
+        it, hist = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
+        assert abs(it - it_ref) <= 1, (split, it, it_ref)
+        m = min(len(hist), len(hist_ref)) - 1
+        assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6), split
+        assert rel_err(dp.download(), P[:N]) < 1e-9, split
+        nrm = lat.square_norm(dp, N, 1)                       # a plain global reduction on that communicator as well
+        assert abs(nrm - orc.square_norm(P, N)) <= 1e-12 * nrm
+        lat.close()
+
+
 @pytest.mark.parametrize("dims", [(6, 4, 4, 4), (4, 4, 4, 8), (12, 4, 4, 4), (2, 4, 6, 2)])
 def test_cg_fused_iteration_on_small_block_counts(dims):
     """V/2 = 192, 256, 384: whole 64-thread blocks but not (always) whole 256-thread blocks -- the fused iteration runs with the

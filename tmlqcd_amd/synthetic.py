@@ -6,7 +6,20 @@ its own slab -- including the two halo slices the reference obtains through xcha
 lattice sees identical links.  Link construction follows random_su3 (start.c:387-425):
 two random vectors, Gram-Schmidt, third row = conj(cross product).
 """
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
+
+
+def _threads():
+    """Worker threads for the per-time-slice generators (numpy releases the GIL inside its kernels): the CPUs this process may use,
+    at most 16 -- a 64 x 32^3 gauge field took 47 s on one thread, most of a multi-rank bench run."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
 
 
 def _su3(rng, n):
@@ -34,7 +47,13 @@ def gauge_field(seed, T, LX, LY, LZ, nproc_t=1, proc_t=0):
     ts = [proc_t * T + t for t in range(T)]
     if nproc_t > 1:
         ts += [(proc_t * T + T) % Tg, (proc_t * T - 1) % Tg]
-    return np.concatenate([gauge_slice(seed, t, LX, LY, LZ) for t in ts], axis=0)
+    out = np.empty((len(ts) * XYZ, 4, 3, 3, 2), dtype=np.float64)
+
+    def fill(j):
+        out[j * XYZ:(j + 1) * XYZ] = gauge_slice(seed, ts[j], LX, LY, LZ)
+    with ThreadPoolExecutor(_threads()) as ex:      # every slice has its own seeded stream: the field does not depend on the thread count
+        list(ex.map(fill, range(len(ts))))
+    return out
 
 
 def spinor_slice(seed, t_global, LX, LY, LZ):
