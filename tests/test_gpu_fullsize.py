@@ -1,8 +1,8 @@
 """GPU: the BASELINE.json lattice sizes themselves.
 
 configs[1] 32^4 and the unsplit configs[3] volume 32^3 x 64: the oracle is fast enough on the GPU box's host cores for a
-full site-by-site comparison of the stencil and the fused operator; configs[4] 48^3 x 96 clover is checked through
-size-independent properties (exact inverse of the clover block, hermiticity, Q_+ = Q_-^dagger, positivity, CG true residual,
+full site-by-site comparison of the stencil and the fused operator; configs[4] 48^3 x 96 clover is checked site by site
+too (device sw_term / sw_invert, Qsw_pm_psi and its fp32 twin against the oracle) and through size-independent properties (exact inverse of the clover block, hermiticity, Q_+ = Q_-^dagger, positivity, CG true residual,
 fp32 vs fp64, 12-real gauge read vs full read)."""
 import numpy as np
 import pytest
@@ -106,6 +106,51 @@ def test_clover_48x96_properties():
         assert run() > 0, name
         lat.op("Qsw_pm_psi", b, y); lat.diff(b, x, b, N)
         assert lat.square_norm(b, N) <= 1e-20 * lat.square_norm(x, N), name
+    lat.close()
+
+
+def test_clover_48x96_site_by_site_against_oracle():
+    """BASELINE configs[4] at its full size against the oracle, site by site: sw_term and sw_invert computed on the device vs the
+    OpenMP restatement of operator/clover_term.c:88 / clover_invert.c:170 (itself bit-exact against the reference objects on the
+    fixtures), then one Qsw_pm_psi (operator/clovertm_operators.c:233-245) and one Qsw_pm_psi_32 application.  The arrays are
+    compared one at a time (sw 9.2 GB, sw_inv 12.2 GB each side) to keep the host footprint near 50 GB."""
+    import gc
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    if _mem_gb() < 72:
+        pytest.skip("needs ~55 GB of host memory: links, the oracle's gauge copy, sw and sw_inv of both sides")
+    T, L = 96, 48
+    kappa, mu, c_sw = 0.1394265, 0.0002, 1.69
+    orc = Oracle(T, L, L, L, kappa=kappa, mu=mu, threads=16)
+    lat = Lattice(T, L, L, L, kappa=kappa, mu=mu)
+    g = syn.gauge_field(41, T, L, L, L)
+    orc.set_gauge(g); lat.set_gauge(g)
+    lat.sw_term(None, kappa, c_sw)               # from the links resident on the device
+    lat.sw_invert(0, mu)
+    del g
+    sw_ref = orc.sw_term(kappa, c_sw)
+    sw, _ = lat.get_clover(want_sw=True, want_sw_inv=False)
+    assert rel_err(sw, sw_ref) < TOL
+    del sw
+    gc.collect()
+    swi_ref, fails = orc.sw_invert(sw_ref, 0, mu)
+    assert fails == 0
+    _, swi = lat.get_clover(want_sw=False, want_sw_inv=True)
+    assert rel_err(swi, swi_ref) < TOL           # both sets: mu != 0
+    del swi
+    gc.collect()
+    orc.set_clover(sw_ref, swi_ref)
+    N = orc.Vh
+    k = syn.spinor_field_eo(42, 1, T, L, L, L)
+    ref = orc.new_field()
+    orc.op("Qsw_pm_psi", ref, k.copy())
+    dk, dl = lat.field(k), lat.field()
+    lat.op("Qsw_pm_psi", dl, dk)
+    assert rel_err(dl.download(), ref[:N]) < TOL
+    k32, l32 = lat.field32(k.astype(np.float32)), lat.field32()
+    lat.Qsw_pm_psi_32(l32, k32)
+    assert rel_err(l32.download().astype(np.float64), ref[:N]) < 2e-5
     lat.close()
 
 

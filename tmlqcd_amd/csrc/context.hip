@@ -37,42 +37,7 @@ __global__ __launch_bounds__(256) void lexic_eo_kernel(v2d *aos, v2d *soa, int n
   else aos[tid] = *dst;
 }
 
-// raw g_gauge_field (su3[VPR][4] = v2d[VPR][4][9]) -> device gauge copy g[par][dir][e][i]
-//   dir 2mu   : U_mu(x)        = raw[ix][mu]
-//   dir 2mu+1 : U_mu(x - mu)   = raw[idn(ix,mu)][mu]     (update_backward_gauge.c:185-242)
-__global__ __launch_bounds__(256) void gauge_sort_kernel(const v2d *__restrict__ raw, v2d *__restrict__ g, int gs, int Vh, int T,
-                                                         int LX, int LY, int LZ, int toff, int split) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= Vh) return;
-  const int par = blockIdx.y;
-  const int LZh = LZ / 2;
-  const int k = i % LZh;
-  int r = i / LZh;
-  const int y = r % LY;
-  r /= LY;
-  const int x = r % LX, t = r / LX;
-  const int o = (t + x + y + toff + par) & 1;
-  const int z = 2 * k + o;
-  const int XYZ = LX * LY * LZ, V = T * XYZ;
-  const int ix = 2 * i + o;
-  int dn[4];
-  if (t > 0) dn[0] = ix - XYZ;
-  else dn[0] = split ? V + XYZ + (ix % XYZ) : ix + (T - 1) * XYZ;  // t = -1 halo slab: geometry_eo.c:296-298
-  dn[1] = (x > 0) ? ix - LY * LZ : ix + (LX - 1) * LY * LZ;
-  dn[2] = (y > 0) ? ix - LZ : ix + (LY - 1) * LZ;
-  dn[3] = (z > 0) ? ix - 1 : ix + (LZ - 1);
-  v2d *gp = g + (size_t)par * 72 * gs + i;
-#pragma unroll
-  for (int mu = 0; mu < 4; mu++) {
-    const v2d *uf = raw + ((size_t)ix * 4 + mu) * 9;
-    const v2d *ub = raw + ((size_t)dn[mu] * 4 + mu) * 9;
-#pragma unroll
-    for (int e = 0; e < 9; e++) {
-      gp[(size_t)((2 * mu) * 9 + e) * gs] = uf[e];
-      gp[(size_t)((2 * mu + 1) * 9 + e) * gs] = ub[e];
-    }
-  }
-}
+// (raw g_gauge_field -> the stencil's gauge copy g[par][dir][e][i]: links_kernel, md_update.hip)
 
 // max over all links of |row2 - conj(row0 x row1)|: how far the resident links are from exact SU(3).  Non-negative
 // doubles order like their bit patterns, so the maximum is an integer atomicMax.
@@ -123,20 +88,6 @@ int tmhip_stage_reserve(tmhip_ctx *ctx, size_t bytes) {
   if (ctx->stage) { TMHIP_CHECK(hipFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
   TMHIP_CHECK(hipMalloc(&ctx->stage, bytes));
   ctx->stage_bytes = bytes;
-  return 0;
-}
-
-// the stencil's gauge copy (and everything derived from the links) from the device-resident lexicographic field
-int tmhip_resort_gauge(tmhip_ctx *ctx) {
-  if (!ctx->gauge_raw || !ctx->gauge_raw_valid) TMHIP_FAIL("no lexicographic gauge field on the device");
-  const int toff = ctx->g.proc_t * ctx->g.T;
-  hipLaunchKernelGGL(gauge_sort_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, (const v2d *)ctx->gauge_raw, ctx->gauge,
-                     ctx->gs, ctx->Vh, ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, toff, ctx->g.nproc_t > 1 ? 1 : 0);
-  TMHIP_CHECK(hipGetLastError());
-  ctx->gauge_set = true;
-  ctx->gauge_copy_current = true;
-  ctx->gauge32_set = false;       // the fp32 twin is rebuilt lazily from the new links
-  ctx->gauge_recon_dev = -1.0;
   return 0;
 }
 

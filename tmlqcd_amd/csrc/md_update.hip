@@ -66,38 +66,139 @@ __device__ __forceinline__ void restoresu3(cd (&vr)[9], const cd (&u)[9]) {
   vr[8] = cconj(cmul(vr[0], vr[4]) - cmul(vr[1], vr[3]));
 }
 
-// one thread per link l = 4 ix + mu of the local volume
-__global__ __launch_bounds__(256) void update_gauge_kernel(v2d *__restrict__ raw, const double *__restrict__ mom, size_t nlinks, double step) {
-  const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (l >= nlinks) return;
-  double d[8];
+// One kernel for "links -> stencil copy" with or without the molecular-dynamics update in front:
+//   UPDATE   U_mu(x) <- restoresu3(exposu3(step P_mu(x))) U_mu(x)  (update_gauge.c:51-110), written back to the lexicographic field
+//   always   the link goes straight to its TWO slots of the stencil's gauge copy g[par][dir][e][site]: dir 2 mu of its own site and
+//            dir 2 mu + 1 of the site at x + mu (update_backward_gauge.c:185-242 turned from a gather into a scatter)
+// so an MD step reads every link once and never re-reads the updated field for a separate re-sort (832 + 1152 -> 640 B per link
+// site-direction).  A block owns 64 consecutive lexicographic sites = 256 links: the host-layout arrays (144-byte links, 64-byte
+// momenta) are moved between HBM and LDS as whole contiguous rows, 16 bytes per lane (a lane-per-link access has a 144-byte lane
+// stride: 363 us for 1.48 GB at 32^4, 0.51 of the peak); each thread then takes ONE link out of LDS (lane stride 36 words:
+// conflict-free 16-byte reads; the momenta rows are padded to 80 bytes for the same reason).
+// T-split ranks: the link U_t at t = T-1 is the backward link of a site of the up neighbour (not stored here), and the backward
+// t-links of the t = 0 sites come from the t = -1 halo slab once the neighbours' slices have arrived (halo_backward_kernel).
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void links_kernel(v2d *__restrict__ raw, const double *__restrict__ mom, v2d *__restrict__ g, int gs, int V, int Vh,
+                                                    int T, int LX, int LY, int LZ, int toff, int split, double step) {
+  __shared__ v2d sl[256 * 9];
+  __shared__ v2d sm[UPDATE ? 256 * 5 : 1];
+  const int tid = threadIdx.x;
+  const size_t l0 = (size_t)blockIdx.x * 256;            // first link of the block
+  const int nl = (int)(((size_t)V * 4 - l0) < 256 ? ((size_t)V * 4 - l0) : 256);
 #pragma unroll
-  for (int k = 0; k < 8; k++) d[k] = step * mom[l * 8 + k];     // _su3adj_assign_const_times_su3adj, update_gauge.c:85
-  cd w[9], v[9], z[9], out[9];
-  exposu3(w, d);
-  restoresu3(v, w);
+  for (int j = 0; j < 9; j++) {
+    const int idx = j * 256 + tid;
+    if (idx < nl * 9) sl[idx] = raw[l0 * 9 + idx];
+  }
+  if (UPDATE) {
+    const v2d *m2 = reinterpret_cast<const v2d *>(mom) + l0 * 4;
 #pragma unroll
-  for (int e = 0; e < 9; e++) z[e] = raw[l * 9 + e];
-  m3mul(out, v, z);
+    for (int j = 0; j < 4; j++) {
+      const int idx = j * 256 + tid;
+      if (idx < nl * 4) sm[(idx >> 2) * 5 + (idx & 3)] = m2[idx];
+    }
+  }
+  __syncthreads();
+  if (UPDATE) {
+    if (tid < nl) {
+      cd z[9], out[9];
 #pragma unroll
-  for (int e = 0; e < 9; e++) raw[l * 9 + e] = out[e];
-}
-
-// momenta[ix][mu][8] -= step * deriv[par][mu][8][Vh]   (update_momenta.c:67-72); one thread per site of one parity
-__global__ __launch_bounds__(256) void update_momenta_kernel(double *__restrict__ mom, const double *__restrict__ d, int Vh, int LX, int LY, int LZ, int toff, double step) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= Vh) return;
-  const int par = blockIdx.y;
-  const int LZh = LZ / 2;
-  int r = i / LZh;
+      for (int e = 0; e < 9; e++) z[e] = sl[tid * 9 + e];
+      double d[8];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const v2d m = sm[tid * 5 + k]; d[2 * k] = step * m.x; d[2 * k + 1] = step * m.y; }   // _su3adj_assign_const_times_su3adj, update_gauge.c:85
+      cd w[9], v[9];
+      exposu3(w, d);
+      restoresu3(v, w);
+      m3mul(out, v, z);
+#pragma unroll
+      for (int e = 0; e < 9; e++) sl[tid * 9 + e] = out[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      const int idx = j * 256 + tid;
+      if (idx < nl * 9) raw[l0 * 9 + idx] = sl[idx];
+    }
+  }
+  // scatter into the stencil copy, re-mapped: thread = (parity p, direction mu, pair s) so that the 32 lanes of one (p, mu) write 32
+  // consecutive sites of ONE plane -- 512 contiguous bytes per plane and store instruction instead of 128
+  const int p = tid >> 7, mu = (tid >> 5) & 3, sp = tid & 31;
+  const int ix0 = (int)(l0 >> 2);
+  const int ie = ix0 + 2 * sp;                              // even member of the pair (z even)
+  if (ie >= V) return;
+  const int z0 = ie % LZ;
+  int r = ie / LZ;
   const int y = r % LY;
   r /= LY;
   const int x = r % LX, t = r / LX;
-  const int o = (t + x + y + par + toff) & 1;
-  double *dst = mom + (2 * (size_t)i + o) * 32;
-  const double *src = d + (size_t)par * 32 * Vh + i;
-#pragma unroll 8
-  for (int e = 0; e < 32; e++) dst[e] -= step * src[(size_t)e * Vh];
+  const int rp = (t + x + y + z0 + toff) & 1;               // parity of the even member
+  const int ix = ie + (p ^ rp), z = z0 + (p ^ rp);          // the pair's site of parity p
+  const v2d *src = sl + ((ix - ix0) * 4 + mu) * 9;
+  cd out[9];
+#pragma unroll
+  for (int e = 0; e < 9; e++) out[e] = src[e];
+  v2d *gf = g + ((size_t)p * 72 + (size_t)(2 * mu) * 9) * gs + (ix >> 1);
+#pragma unroll
+  for (int e = 0; e < 9; e++) gf[(size_t)e * gs] = out[e];
+  int jx;                                                  // x + mu, periodic
+  if (mu == 0) {
+    if (t + 1 < T) jx = ix + LX * LY * LZ;
+    else { if (split) return; jx = ix - (T - 1) * LX * LY * LZ; }
+  } else if (mu == 1) jx = (x + 1 < LX) ? ix + LY * LZ : ix - (LX - 1) * LY * LZ;
+  else if (mu == 2) jx = (y + 1 < LY) ? ix + LZ : ix - (LY - 1) * LZ;
+  else jx = (z + 1 < LZ) ? ix + 1 : ix - (LZ - 1);
+  v2d *gb = g + ((size_t)(1 - p) * 72 + (size_t)(2 * mu + 1) * 9) * gs + (jx >> 1);
+#pragma unroll
+  for (int e = 0; e < 9; e++) gb[(size_t)e * gs] = out[e];
+  (void)Vh;
+}
+
+// T-split rank: dir 1 (U_t(x - t)) of the t = 0 sites <- the t = -1 halo slab of the lexicographic field (geometry_eo.c:296-298)
+__global__ __launch_bounds__(256) void halo_backward_kernel(const v2d *__restrict__ raw, v2d *__restrict__ g, int gs, int V, int XYZ, int LX, int LY, int LZ, int toff) {
+  const int j = blockIdx.x * 256 + threadIdx.x;          // site of the t = 0 slice, lexicographic
+  if (j >= XYZ) return;
+  const int z = j % LZ;
+  int r = j / LZ;
+  const int y = r % LY, x = r / LY;
+  const int par = (x + y + z + toff) & 1;
+  const v2d *u = raw + ((size_t)(V + XYZ + j) * 4 + 0) * 9;
+  v2d *gb = g + ((size_t)par * 72 + 9) * gs + (j >> 1);
+#pragma unroll
+  for (int e = 0; e < 9; e++) gb[(size_t)e * gs] = u[e];
+  (void)LX;
+}
+
+// momenta[ix][mu][8] -= step * deriv[par][mu][8][Vh]   (update_momenta.c:67-72).  A block owns 64 consecutive lexicographic sites =
+// the e/o indices [32 b, 32 b + 32) of both parities: the derivative's 2 x 32 planes are read as 256-byte runs and transposed
+// through LDS (rows padded to 33 doubles: conflict-free), the momenta -- 16 KB of the host layout -- are updated as one contiguous run.
+__global__ __launch_bounds__(256) void update_momenta_kernel(double *__restrict__ mom, const double *__restrict__ d, int V, int Vh, int LX, int LY, int LZ, int toff, double step) {
+  __shared__ double ld[2][32][33];
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.x * 32;
+#pragma unroll
+  for (int par = 0; par < 2; par++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = j * 256 + tid, e = idx >> 5, sidx = idx & 31;
+      if (i0 + sidx < Vh) ld[par][sidx][e] = d[((size_t)par * 32 + e) * Vh + i0 + sidx];
+    }
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * 64 * 32;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int idx = j * 256 + tid;                         // double of the block's momenta run
+    const int sl = idx >> 5, e = idx & 31;
+    const int ix = blockIdx.x * 64 + sl;
+    if (ix >= V) continue;
+    const int z = ix % LZ;
+    int r = ix / LZ;
+    const int y = r % LY;
+    r /= LY;
+    const int x = r % LX, t = r / LX;
+    const int par = (t + x + y + z + toff) & 1;
+    mom[base + idx] -= step * ld[par][sl >> 1][e];
+  }
 }
 
 // t = 0 and t = T-1 slices of the lexicographic field -> the neighbours' halo slabs (xchange_gauge, geometry_eo.c:292-299)
@@ -116,6 +217,42 @@ int tmhip_exchange_gauge_halo(tmhip_ctx *ctx) {
   TMHIP_NCCL_CHECK(ncclSend(last, n, ncclDouble, up, ctx->comm_red, ctx->stream));     // our t = T-1 is the up neighbour's t = -1
   TMHIP_NCCL_CHECK(ncclRecv(slab_dn, n, ncclDouble, dn, ctx->comm_red, ctx->stream));
   TMHIP_NCCL_CHECK(ncclGroupEnd());
+  return 0;
+}
+
+// links (-> updated links) -> stencil copy on ctx->stream; `halo`: the halo slabs of a T-split rank are current, finish the t = 0 sites
+static int launch_links(tmhip_ctx *ctx, bool update, double step) {
+  const int toff = ctx->g.proc_t * ctx->g.T, split = ctx->g.nproc_t > 1 ? 1 : 0;
+  const unsigned nb = (unsigned)(((size_t)ctx->V * 4 + 255) / 256);
+  if (update)
+    hipLaunchKernelGGL(links_kernel<true>, dim3(nb), dim3(256), 0, ctx->stream, ctx->gauge_raw, (const double *)ctx->momenta, ctx->gauge, ctx->gs, ctx->V, ctx->Vh,
+                       ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, toff, split, step);
+  else
+    hipLaunchKernelGGL(links_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, ctx->gauge_raw, (const double *)nullptr, ctx->gauge, ctx->gs, ctx->V, ctx->Vh,
+                       ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, toff, split, 0.0);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+static int launch_halo_backward(tmhip_ctx *ctx) {
+  if (ctx->g.nproc_t < 2) return 0;
+  const int XYZ = ctx->g.LX * ctx->g.LY * ctx->g.LZ;
+  hipLaunchKernelGGL(halo_backward_kernel, dim3((XYZ + 255) / 256), dim3(256), 0, ctx->stream, (const v2d *)ctx->gauge_raw, ctx->gauge, ctx->gs, ctx->V, XYZ,
+                     ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.proc_t * ctx->g.T);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
+}
+static void links_changed(tmhip_ctx *ctx) {
+  ctx->gauge_set = true;
+  ctx->gauge_copy_current = true;
+  ctx->gauge32_set = false;       // the fp32 twin is rebuilt lazily from the new links
+  ctx->gauge_recon_dev = -1.0;
+}
+
+// the stencil's gauge copy (and everything derived from the links) from the device-resident lexicographic field, halo slabs included
+int tmhip_resort_gauge(tmhip_ctx *ctx) {
+  if (!ctx->gauge_raw || !ctx->gauge_raw_valid) TMHIP_FAIL("no lexicographic gauge field on the device");
+  if (launch_links(ctx, false, 0.0) || launch_halo_backward(ctx)) return 1;
+  links_changed(ctx);
   return 0;
 }
 
@@ -145,8 +282,8 @@ int tmhip_update_momenta(tmhip_ctx *ctx, double step) {
   if (!ctx->momenta) TMHIP_FAIL("tmhip_update_momenta: no momenta on the device (tmhip_momenta_upload)");
   if (!ctx->deriv) TMHIP_FAIL("tmhip_update_momenta: no derivative field on the device");
   TMHIP_CHECK(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(update_momenta_kernel, dim3((ctx->Vh + 255) / 256, 2), dim3(256), 0, ctx->stream, ctx->momenta, (const double *)ctx->deriv,
-                     ctx->Vh, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.proc_t * ctx->g.T, step);
+  hipLaunchKernelGGL(update_momenta_kernel, dim3((ctx->V + 63) / 64), dim3(256), 0, ctx->stream, ctx->momenta, (const double *)ctx->deriv,
+                     ctx->V, ctx->Vh, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.proc_t * ctx->g.T, step);
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -157,13 +294,13 @@ int tmhip_update_gauge(tmhip_ctx *ctx, double step) {
   if (!ctx->gauge_raw || !ctx->gauge_raw_valid) TMHIP_FAIL("tmhip_update_gauge: the links are not resident (tmhip_set_gauge first)");
   if (!ctx->momenta) TMHIP_FAIL("tmhip_update_gauge: no momenta on the device (tmhip_momenta_upload)");
   TMHIP_CHECK(hipSetDevice(ctx->device));
-  const size_t nlinks = (size_t)ctx->V * 4;
-  hipLaunchKernelGGL(update_gauge_kernel, dim3((unsigned)((nlinks + 255) / 256)), dim3(256), 0, ctx->stream, ctx->gauge_raw, (const double *)ctx->momenta, nlinks, step);
-  TMHIP_CHECK(hipGetLastError());
+  if (launch_links(ctx, true, step)) return 1;                 // exp(step P) U, back to the lexicographic field and into the stencil copy
   if (tmhip_exchange_gauge_halo(ctx)) return 1;
+  if (launch_halo_backward(ctx)) return 1;                     // T-split: the backward t-links of the t = 0 sites from the neighbour's updated slice
   // clover blocks belong to the old links: tmhip_sw_term (gauge = NULL: from the resident links) / tmhip_sw_invert again
   ctx->sw_set = false; ctx->clover_set = false; ctx->clover32_set = false;
-  return tmhip_resort_gauge(ctx);
+  links_changed(ctx);
+  return 0;
 }
 
 /* The same on a T-split lattice held by n contexts of one process (peer copies instead of RCCL, as tmhip_multi_sw_all): every
@@ -175,9 +312,7 @@ int tmhip_multi_update_gauge(int n, tmhip_ctx **ctxs, double step) {
     if (c->g.nproc_t != n || c->g.proc_t != r) TMHIP_FAIL("context %d is not rank %d of a %d-way T split", r, r, n);
     if (!c->gauge_raw || !c->gauge_raw_valid || !c->momenta) TMHIP_FAIL("tmhip_multi_update_gauge: rank %d has no resident links / momenta", r);
     TMHIP_CHECK(hipSetDevice(c->device));
-    const size_t nlinks = (size_t)c->V * 4;
-    hipLaunchKernelGGL(update_gauge_kernel, dim3((unsigned)((nlinks + 255) / 256)), dim3(256), 0, c->stream, c->gauge_raw, (const double *)c->momenta, nlinks, step);
-    TMHIP_CHECK(hipGetLastError());
+    if (launch_links(c, true, step)) return 1;
   }
   for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
   const size_t XYZ = (size_t)ctxs[0]->g.LX * ctxs[0]->g.LY * ctxs[0]->g.LZ, sb = XYZ * 36 * sizeof(v2d);
@@ -188,7 +323,8 @@ int tmhip_multi_update_gauge(int n, tmhip_ctx **ctxs, double step) {
     TMHIP_CHECK(hipMemcpyPeerAsync(slab_up, c->device, up->gauge_raw, up->device, sb, c->stream));                                            // the up neighbour's t = 0
     TMHIP_CHECK(hipMemcpyPeerAsync(slab_dn, c->device, dn->gauge_raw + (size_t)(dn->g.T - 1) * XYZ * 36, dn->device, sb, c->stream));         // the down neighbour's t = T-1
     c->sw_set = false; c->clover_set = false; c->clover32_set = false;
-    if (tmhip_resort_gauge(c)) return 1;
+    if (launch_halo_backward(c)) return 1;
+    links_changed(c);
   }
   for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
   return 0;

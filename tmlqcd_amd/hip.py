@@ -389,9 +389,15 @@ class Lattice:
         _ck(self.lib.tmhip_gauge_unpack_ildg(self.h, buf.ctypes.data_as(C.c_void_p), prec, sums), "tmhip_gauge_unpack_ildg")
         return int(sums[0]), int(sums[1])
 
-    def gauge_pack_ildg(self, prec):
-        """The resident links as the bytes of this rank's part of the record; returns (uint8 array, (suma, sumb))."""
-        out = np.zeros(self.V * 4 * 9 * (16 if prec == 64 else 8), dtype=np.uint8)
+    def gauge_pack_ildg(self, prec, out=None):
+        """The resident links as the bytes of this rank's part of the record; returns (uint8 array, (suma, sumb)).  `out`: a buffer
+        of the record's size to fill (a fresh numpy array is 600 MB of pages the kernel has never mapped: the copy into it
+        runs at the page-fault rate, 52 ms instead of 12 at 32^4)."""
+        n = self.V * 4 * 9 * (16 if prec == 64 else 8)
+        if out is None:
+            out = np.zeros(n, dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.size != n or not out.flags["C_CONTIGUOUS"]:
+            raise TmHipError("gauge_pack_ildg: out must be a contiguous uint8 array of %d bytes" % n)
         sums = (C.c_uint * 2)()
         _ck(self.lib.tmhip_gauge_pack_ildg(self.h, out.ctypes.data_as(C.c_void_p), prec, sums), "tmhip_gauge_pack_ildg")
         return out, (int(sums[0]), int(sums[1]))
