@@ -16,10 +16,7 @@ for L in [int(a) for a in sys.argv[1:]] or [8, 16, 24]:
     src = lat.field(syn.spinor_field_eo(3, 0, L, L, L, L))
     f0, f1, f2 = lat.field(syn.spinor_field_eo(2, 0, L, L, L, L)), lat.field(), lat.field()
     us = np.median([lat.bench_hopping(f0, f1, f2, 200) / 400 for _ in range(3)]) * 1e3
-    lat.set_option("bench_graph", 1)
-    usg = np.median([lat.bench_hopping(f0, f1, f2, 200) / 400 for _ in range(3)]) * 1e3
-    lat.set_option("bench_graph", 0)
-    print("L=%d Hopping_Matrix %.1f us/launch enqueued one by one, %.1f us/launch replayed from one hipGraph of 400 launches" % (L, us, usg), flush=True)
+    print("L=%d Hopping_Matrix %.1f us/launch" % (L, us), flush=True)     # (a hipGraph replay of the loop measured the same: profiles/r01_diagnostics.md)
     x = lat.field()
     for batch in (4, 16):
         lat.set_option("cg_batch", batch)
