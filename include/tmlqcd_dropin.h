@@ -200,8 +200,12 @@ void tmlqcd_hip_sync_momenta_to_host(hamiltonian_field_t *const hf);
  * LAZY: as RESIDENT, but the library finds out by itself: the pages of a host array whose current copy is in HBM are made
  *   inaccessible, the host's first load from one of them faults and fetches that page (or, if it keeps reading or stores, the field);
  *   arrays the device has read are write-protected, so a host store invalidates the mirror.  An UNMODIFIED host program then runs its
- *   stencil / operator loops at the HBM rate (also: environment TMLQCD_HIP_RESIDENCY=lazy).  Opt-in because system calls do not
- *   fault: a field passed to write(2) / MPI while its host copy is stale must be synchronised first (tmlqcd_hip_sync_to_host). */
+ *   stencil / operator loops at the HBM rate (also: environment TMLQCD_HIP_RESIDENCY=lazy).  Opt-in, for two reasons.  System calls
+ *   do not fault: a field passed to write(2) / MPI while its host copy is stale must be synchronised first (tmlqcd_hip_sync_to_host).
+ *   And arrays that go back to the allocator: a block the allocator unmaps (glibc: anything above its mmap threshold, which the
+ *   library pins at 128 KB when the mode is switched on) is recognised when its address comes back -- a watched mirror is probed
+ *   before it is trusted -- but a block recycled INSIDE the malloc heap must be announced with tmlqcd_hip_forget before it is freed
+ *   (free() writes its bookkeeping into the protected pages while it holds the allocator's lock). */
 enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1, TMLQCD_HIP_LAZY = 2 };
 /* Device versions of sw_term(g_gauge_field, kappa, c_sw) / sw_invert(ieo, mu) (operator/clover_term.c:88,
  * operator/clover_invert.c:170).  They carry their own names because the reference keeps other, unrelated functions in

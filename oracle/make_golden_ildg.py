@@ -19,13 +19,28 @@ from oracle import ildgbind as ib  # noqa: E402
 from tmlqcd_amd import synthetic as syn  # noqa: E402
 
 T, LX, LY, LZ = 2, 4, 2, 6
+# the "xlf-info" message exactly as write_gauge_field writes it (io/gauge_write.c:35 -> io/utils_write_xlf.c:35-55: plain text), for a
+# paramsXlfInfo as construct_paramsXlfInfo fills it (io/params_construct_xlfInfo.c: date = ctime(), trailing newline included)
+XLF = dict(plaq=0.5, counter=7, beta=3.9, kappa=0.160856, mu=0.004, c2_rec=0.0, time=1234567890, package_version="5.2.0", mubar=0.0,
+           epsilonbar=0.0, date="Fri Feb 13 23:31:30 2009\n")
+
+
+def xlf_info_text(plaq, counter, beta, kappa, mu, c2_rec, time, package_version, mubar, epsilonbar, date):
+    if kappa != 0.0:
+        return ("plaquette = %14.12f\n trajectory nr = %d\n beta = %.12f, kappa = %.12f, mu = %.12f, c2_rec = %f\n time = %d\n"
+                " hmcversion = %s\n mubar = %.12f\n epsilonbar = %.12f\n date = %s"
+                % (plaq, counter, beta, kappa, mu, c2_rec, time, package_version, mubar, epsilonbar, date))
+    return ("plaquette = %e\n trajectory nr = %d\n beta = %.12f\n kappa = %.12f\n 2*kappa*mu = %.12f\n c2_rec = %f\n date = %s"
+            % (plaq, counter, beta, kappa, mu, c2_rec, date))
+
+
 g = syn.gauge_field(41, T, LX, LY, LZ)
-out = {"lattice": [T, LX, LY, LZ], "gauge_seed": 41, "files": {}, "crc32_known_answers": []}
+out = {"lattice": [T, LX, LY, LZ], "gauge_seed": 41, "files": {}, "crc32_known_answers": [], "xlf_info": XLF, "xlf_info_text": xlf_info_text(**XLF)}
 assert ib.ref_available(), "build oracle/_ref first (make -C oracle ref)"
 for prec in (64, 32):
     name = "ildg_%dx%dx%dx%d_prec%d.lime" % (T, LX, LY, LZ, prec)
     path = os.path.join(ROOT, "tests", "golden", name)
-    xlf = "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<xlf-info>\n  <plaquette>0.5</plaquette>\n  <trajectory>7</trajectory>\n</xlf-info>" if prec == 64 else None
+    xlf = xlf_info_text(**XLF) if prec == 64 else None
     rc, sums = ib.write_gauge_field(path, g, prec, T, LX, LY, LZ, xlf)
     assert rc == 0
     rec, _ = ib.pack(g, prec, T, LX, LY, LZ)

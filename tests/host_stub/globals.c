@@ -117,3 +117,32 @@ double stub_host_sum_threads(const stub_spinor *f, int n, int nthreads) {
   for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); s += job[t].s; }
   return s;
 }
+
+/* host threads read a stale array WHILE the master thread keeps calling the library on other arrays (registry inserts and erases):
+ * the threads start first, the master then issues `ncalls` stencil calls into `nout` different output arrays, forgetting one of
+ * them after every call (an insert and an erase per call) */
+double stub_threads_read_while_master_calls(void (*hop)(int, void *, void *), void (*forget)(void *), const stub_spinor *stale, int n, int nthreads,
+                                            stub_spinor *in, stub_spinor **outs, int nout, int ncalls) {
+  pthread_t th[16];
+  stub_job job[16];
+  if (nthreads > 16) nthreads = 16;
+  for (int t = 0; t < nthreads; t++) {
+    job[t].f = stale; job[t].lo = (int)((long)n * t / nthreads); job[t].hi = (int)((long)n * (t + 1) / nthreads); job[t].s = 0.0;
+    pthread_create(&th[t], NULL, stub_sum_job, &job[t]);
+  }
+  for (int c = 0; c < ncalls; c++) {
+    hop(c & 1, outs[c % nout], in);
+    forget(outs[(c + nout / 2) % nout]);
+  }
+  double s = 0.0;
+  for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); s += job[t].s; }
+  return s;
+}
+/* a work field the way solver/solver_field.c gets one -- calloc, used, freed -- in the form glibc gives a block of that size when
+ * the heap has no free chunk for it: an anonymous mapping of its own, unmapped again by free (the user pointer 16 bytes in) */
+#include <sys/mman.h>
+void *stub_calloc(size_t bytes) {
+  char *m = mmap(NULL, bytes + 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  return m == MAP_FAILED ? NULL : m + 16;
+}
+void stub_free(void *p, size_t bytes) { munmap((char *)p - 16, bytes + 4096); }

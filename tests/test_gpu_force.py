@@ -456,9 +456,19 @@ def test_update_gauge_drop_in_keeps_the_links_in_hbm(host_stub):
     # coherent mode
     d.tmlqcd_hip_update_gauge(0.03, C.byref(hf))
     orc.update_gauge(want, mom, 0.03)
-    assert rel_err(host_links, want) < TOL and hf.update_gauge_copy == 1 and stub.stub_gauge_flag() == 1
+    # host and device links are in step and the flags are DOWN (the host's backward copy, if the program has one, was refreshed
+    # right away): a flag raised from here on is the host program's own and forces an upload
+    assert rel_err(host_links, want) < TOL and hf.update_gauge_copy == 0 and stub.stub_gauge_flag() == 0
     check_stencil(want)
+    # the reject step restores the old links on the host and raises the flag (update_tm.c) -- the next operator call
+    # must run on THOSE links, not on the ones the device update left in HBM
+    host_links[:] = g
+    stub.stub_mark_gauge_dirty()
+    check_stencil(g)
     assert stub.stub_gauge_flag() == 0                                              # consumed by the stencil call, like Hopping_Matrix.c:135-139
+    host_links[:] = want
+    stub.stub_mark_gauge_dirty()
+    check_stencil(want)
     # resident mode: two steps without the host seeing anything
     d.tmlqcd_hip_set_residency(1)
     before = host_links.copy()

@@ -29,7 +29,7 @@ def test_read_the_fixture_files(prec):
     assert "%08x" % info.suma == meta["suma"] and "%08x" % info.sumb == meta["sumb"]      # == the reference's checksum code
     assert (info.suma_stored, info.sumb_stored) == (info.suma, info.sumb)
     assert (info.prec, info.lx, info.ly, info.lz, info.lt) == (prec, LX, LY, LZ, T)
-    assert (b"<trajectory>7</trajectory>" in info.xlf_info) == (prec == 64)
+    assert (info.xlf_info == META["xlf_info_text"].encode()) if prec == 64 else not info.xlf_info       # the plain text of io/utils_write_xlf.c:35-55
     _, want, _ = ib.read_gauge_field(os.path.join(GOLD, name), prec, T, LX, LY, LZ)
     assert np.array_equal(gf[:lat.V], want)                                               # the host's g_gauge_field
     assert np.array_equal(lat.gauge_download()[:lat.V], want)                             # the links resident in HBM
@@ -69,7 +69,7 @@ def test_written_file_is_the_restatements_byte_for_byte(tmp_path):
     g = syn.gauge_field(META["gauge_seed"], T, LX, LY, LZ)
     lat = Lattice(T, LX, LY, LZ, kappa=0.125, mu=0.0)
     lat.set_gauge(g)
-    xlf = "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<xlf-info>\n  <plaquette>0.5</plaquette>\n  <trajectory>7</trajectory>\n</xlf-info>"
+    xlf = META["xlf_info_text"]
     for prec in (64, 32):
         p = tmp_path / ("w%d.lime" % prec)
         sums = lat.write_gauge_field(p, prec, xlf if prec == 64 else None)
@@ -166,7 +166,7 @@ def test_drop_in_read_and_write_gauge_field(host_stub, tmp_path):
     class GI(C.Structure):
         _fields_ = [("plaq", C.c_double), ("gaugeRead", C.c_int), ("suma", C.c_uint), ("sumb", C.c_uint), ("xlf", C.c_char_p), ("lfn", C.c_char_p)]
     gi = GI.in_dll(d, "GaugeInfo")
-    assert gi.gaugeRead == 1 and "%08x" % gi.suma == META["files"][os.path.basename(fixture)]["suma"] and b"<trajectory>7" in gi.xlf
+    assert gi.gaugeRead == 1 and "%08x" % gi.suma == META["files"][os.path.basename(fixture)]["suma"] and gi.xlf == META["xlf_info_text"].encode()
     orc = Oracle(T, LX, LY, LZ, kappa=0.125, mu=0.01, theta=(0, 0, 0, 0), threads=2)
     orc.set_gauge(g)
     k = orc.new_field(); k[:V // 2] = random_spinor(5, V // 2)
@@ -177,6 +177,23 @@ def test_drop_in_read_and_write_gauge_field(host_stub, tmp_path):
     out = tmp_path / "dropin.lime"
     assert d.write_gauge_field(str(out).encode(), 32, None) == 0
     assert out.read_bytes() == open(os.path.join(GOLD, "ildg_%dx%dx%dx%d_prec32.lime" % (T, LX, LY, LZ)), "rb").read()
+
+    # with a paramsXlfInfo (io/params.h:71-88) the first record is the plain-text message of io/utils_write_xlf.c:35-55 -- what the
+    # reference's write_gauge_field writes (io/gauge_write.c:35) -- and the file is the 64-bit fixture byte for byte
+    class Xlf(C.Structure):
+        _fields_ = [("date", C.c_char * 64), ("package_version", C.c_char * 32), ("beta", C.c_double), ("c2_rec", C.c_double), ("epsilonbar", C.c_double),
+                    ("kappa", C.c_double), ("mu", C.c_double), ("mubar", C.c_double), ("plaq", C.c_double), ("counter", C.c_int), ("time", C.c_long)]
+    x = META["xlf_info"]
+    xi = Xlf(date=x["date"].encode(), package_version=x["package_version"].encode(), beta=x["beta"], c2_rec=x["c2_rec"], epsilonbar=x["epsilonbar"],
+             kappa=x["kappa"], mu=x["mu"], mubar=x["mubar"], plaq=x["plaq"], counter=x["counter"], time=x["time"])
+    out64 = tmp_path / "dropin64.lime"
+    assert d.write_gauge_field(str(out64).encode(), 64, C.byref(xi)) == 0
+    assert out64.read_bytes() == open(fixture, "rb").read()
+    xi.kappa = 0.0                                                     # the other branch of utils_write_xlf.c
+    assert d.write_gauge_field(str(out64).encode(), 64, C.byref(xi)) == 0
+    want0 = ("plaquette = %e\n trajectory nr = %d\n beta = %.12f\n kappa = %.12f\n 2*kappa*mu = %.12f\n c2_rec = %f\n date = %s"
+             % (x["plaq"], x["counter"], x["beta"], 0.0, x["mu"], x["c2_rec"], x["date"])).encode()
+    assert want0 in out64.read_bytes()[:1024]
     stub.stub_set_io(32, 0)
     assert d.read_gauge_field(fixture.encode(), gfpp) == -1           # GaugeConfigReadPrecision = 32 against a 64-bit file
     stub.stub_set_io(64, 0)

@@ -176,3 +176,115 @@ def test_solver_and_mode_switch(prog):
     assert np.linalg.norm((ax[:N] - b).ravel()) < 1e-9 * np.linalg.norm(b.ravel())
     f[1][:] = 1.0                                            # plain stores, no fault handling involved any more
     assert f[1].sum() == N * 24
+
+
+def test_halves_then_the_full_field_at_the_same_base(prog):
+    """Hopping_Matrix into the two halves of a lexicographic field (two EO mirrors at X and X + V/2), then D_psi
+    and square_norm(., VOLUME) on the pair (a FULL mirror / a prefix at X) -- the mirror of the odd half must give way, or the same
+    host bytes have two independently valid device copies -- then an EO operation on the odd half again."""
+    stub, d, orc, f, (T, L, V, N), block = prog
+    d.D_psi.argtypes = [VP, VP]
+    d.tmlqcd_hip_set_residency(LAZY)
+    src = random_spinor(76, N)
+    f[4][:] = src
+    k = orc.new_field(); k[:N] = src
+    r0, r1 = orc.new_field(), orc.new_field()
+    d.Hopping_Matrix(1, _p(f[0]), _p(f[4])); orc.Hopping_Matrix(1, r0, k)        # even half of the pair (f0, f1) <- H_oe... written by the device
+    d.Hopping_Matrix(0, _p(f[1]), _p(f[4])); orc.Hopping_Matrix(0, r1, k)        # odd half: a second EO mirror at X + V/2
+    pair = np.frombuffer(block, dtype=np.float64, count=V * 24, offset=f[0].ctypes.data - block.ctypes.data).reshape(V, 4, 3, 2)
+    outp = np.frombuffer(block, dtype=np.float64, count=V * 24, offset=f[2].ctypes.data - block.ctypes.data).reshape(V, 4, 3, 2)
+    want_pair = np.concatenate([r0[:N], r1[:N]])
+    nrm = d.square_norm(_p(f[0]), V, 1)                                           # a prefix of VOLUME sites at the base of the even half
+    assert abs(nrm - (want_pair ** 2).sum()) <= 1e-12 * nrm
+    d.D_psi(_p(outp), _p(pair))                                                   # FULL mirror at the same base
+    q = orc.new_field(orc.VPR); q[:V] = want_pair
+    want = np.zeros_like(q); orc.D_psi(want, q)
+    assert rel_err(outp, want[:V]) < TOL
+    assert rel_err(pair, want_pair) < TOL                                         # the host sees the halves the device wrote, not a stale page
+    # the host changes the odd half, then an EO operation on it: must see the new data, not the old EO mirror's
+    f[1][:] = 2.0 * r1[:N]
+    d.Hopping_Matrix(1, _p(f[4]), _p(f[1]))
+    k1 = orc.new_field(); k1[:N] = 2.0 * r1[:N]
+    r4 = orc.new_field(); orc.Hopping_Matrix(1, r4, k1)
+    assert rel_err(f[4], r4[:N]) < TOL
+
+
+def test_upload_next_to_a_stale_full_field(prog):
+    """the upload's host -> staging copy faults on the page it shares with a neighbouring FULL field whose host
+    copy is stale; the handler fetches that whole field -- through a staging buffer of its own, not the one being filled."""
+    stub, d, orc, f, (T, L, V, N), block = prog
+    d.D_psi.argtypes = [VP, VP]
+    d.tmlqcd_hip_set_residency(LAZY)
+    pin = np.frombuffer(block, dtype=np.float64, count=V * 24, offset=f[0].ctypes.data - block.ctypes.data).reshape(V, 4, 3, 2)
+    pout = np.frombuffer(block, dtype=np.float64, count=V * 24, offset=f[2].ctypes.data - block.ctypes.data).reshape(V, 4, 3, 2)
+    src = random_spinor(77, V)
+    pin[:] = src
+    d.D_psi(_p(pout), _p(pin))                               # pout = (f2, f3): written by the device, stale on the host, its last page shared with f4
+    q = orc.new_field(orc.VPR); q[:V] = src
+    want = np.zeros_like(q); orc.D_psi(want, q)
+    x = random_spinor(78, N)
+    f[4][:] = x                                              # host-modified neighbour (its first page is pout's last: the store fetched pout? no -- only that page's owner decides)
+    d.Hopping_Matrix(0, _p(f[0]), _p(f[4]))                  # upload of f4: memcpy reads the shared page
+    k = orc.new_field(); k[:N] = x
+    r = orc.new_field(); orc.Hopping_Matrix(0, r, k)
+    assert rel_err(f[0], r[:N]) < TOL
+    assert rel_err(pout, want[:V]) < TOL and np.array_equal(f[4], x)
+
+
+def test_work_field_freed_and_allocated_again_between_calls(prog):
+    """solver/solver_field.c allocates its work fields per solve -- a large calloc is unmapped by free and the
+    next one gets the same address back, readable and writable, so no fault tells the library.  A watched mirror is therefore
+    probed before it is trusted; the second round must compute from the NEW contents.  (The stub maps and unmaps the blocks itself,
+    as glibc does for a block of this size that no free heap chunk can serve; a block recycled INSIDE the heap has to be announced
+    with tmlqcd_hip_forget -- free() would write its bookkeeping into a protected page while holding the allocator's lock.)"""
+    stub, d, orc, f, (T, L, V, N), _ = prog
+    stub.stub_calloc.restype = VP; stub.stub_calloc.argtypes = [C.c_size_t]
+    stub.stub_free.argtypes = [VP, C.c_size_t]
+    d.tmlqcd_hip_set_residency(LAZY)
+    nb = N * 192
+    seen = set()
+    same = 0
+    for rnd in range(3):
+        px, py = stub.stub_calloc(nb), stub.stub_calloc(nb)
+        same += (px in seen) + (py in seen)
+        seen.update((px, py))
+        x = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_double)), shape=(N, 4, 3, 2))
+        y = np.ctypeslib.as_array(C.cast(py, C.POINTER(C.c_double)), shape=(N, 4, 3, 2))
+        src = random_spinor(80 + rnd, N)
+        x[:] = src
+        d.Hopping_Matrix(0, py, px)                          # x uploaded (write-protected), y stale on the host (inaccessible)
+        k = orc.new_field(); k[:N] = src
+        r = orc.new_field(); orc.Hopping_Matrix(0, r, k)
+        if rnd == 1:
+            assert rel_err(y, r[:N]) < TOL                   # (one round reads the result, the others free it unread)
+        nrm = d.square_norm(py, N, 1)
+        assert abs(nrm - orc.square_norm(r, N)) <= 1e-12 * nrm, rnd
+        del x, y
+        stub.stub_free(py, nb); stub.stub_free(px, nb)
+    assert same >= 2, "the allocator did not hand the same addresses out again: the test did not exercise the probe"
+
+
+def test_threads_fault_while_the_master_thread_changes_the_registry(prog):
+    """host threads read a stale field WHILE the master thread issues drop-in calls on other fields (an insert
+    and an erase of the registry per call): 100 rounds, no crash, every sum equal to the oracle's."""
+    stub, d, orc, f, (T, L, V, N), _ = prog
+    fn = stub.stub_threads_read_while_master_calls
+    fn.restype = C.c_double
+    fn.argtypes = [VP, VP, VP, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int]
+    d.tmlqcd_hip_forget.argtypes = [VP]
+    d.tmlqcd_hip_set_residency(LAZY)
+    src = random_spinor(79, N)
+    f[0][:] = src
+    k = orc.new_field(); k[:N] = src
+    outs = [np.zeros((N, 4, 3, 2)) for _ in range(6)]
+    arr = (VP * 6)(*[o.ctypes.data for o in outs])
+    r = [orc.new_field(), orc.new_field()]
+    for ieo in (0, 1):
+        orc.Hopping_Matrix(ieo, r[ieo], k)
+    want = [float((r[i][:N, :, :, 0] - r[i][:N, :, :, 1]).sum()) for i in (0, 1)]
+    for rnd in range(100):
+        d.Hopping_Matrix(rnd & 1, _p(f[1]), _p(f[0]))        # f1 stale on the host
+        got = fn(C.cast(d.Hopping_Matrix, VP), C.cast(d.tmlqcd_hip_forget, VP), _p(f[1]), N, 8, _p(f[0]), arr, 6, 7)
+        assert abs(got - want[rnd & 1]) < 1e-9 * max(1.0, abs(want[rnd & 1])), rnd
+    d.Hopping_Matrix(0, _p(outs[0]), _p(f[0]))
+    assert rel_err(outs[0], r[0][:N]) < TOL

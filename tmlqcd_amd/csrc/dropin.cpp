@@ -14,6 +14,9 @@
 #include <vector>
 
 #include <atomic>
+#include <cerrno>
+#include <fcntl.h>
+#include <malloc.h>
 #include <pthread.h>
 #include <signal.h>
 #include <stdint.h>
@@ -28,6 +31,7 @@ extern int g_nproc_t, g_nproc_x, g_nproc_y, g_nproc_z;           /* global.h:206
 extern int g_proc_coords[4];                                      /* global.h:207 */
 extern su3 **g_gauge_field;                                       /* global.h:176 */
 extern int g_update_gauge_copy;                                   /* global.h:73  */
+extern int g_update_gauge_copy_32 __attribute__((weak));          /* global.h:74: the host's fp32 gauge copy is refreshed by host code when it needs it */
 extern double g_mu;                                               /* global.h:198 */
 extern double g_mu3 __attribute__((weak));                        /* global.h:197: odd-odd twist of the e/o clover operators is g_mu + g_mu3 */
 extern TM_COMPLEX ka0, ka1, ka2, ka3;                             /* boundary.h:25 */
@@ -77,11 +81,32 @@ int g_mode = TMLQCD_HIP_COHERENT;
 int g_dims[6] = {0, 0, 0, 0, 0, 0};
 std::unordered_map<const void *, Mirror> g_reg;
 bool g_gauge_uploaded = false;   // the current context holds a gauge copy
-bool g_dev_links_current = false; // tmlqcd_hip_update_gauge has just brought host and device links to the same state (coherent mode): the next refresh skips the upload
 bool g_dev_links_newer = false;   // resident mode: the device links are ahead of g_gauge_field until tmlqcd_hip_sync_gauge_to_host
 bool g_momenta_resident = false;  // the momenta live on the device (tmlqcd_hip_update_momenta), not re-uploaded by tmlqcd_hip_update_gauge
 bool g_clover_uploaded = false;
 tmhip_field *g_full_tmp = nullptr; // FULL-lattice scratch of Q_pm_psi / D_dagg_psi (tm_operators.c:380-397)
+
+// ONE lock for the registry: taken around every structural change of g_reg (insert, erase, rehash) by the entry points and for
+// the whole body of the SIGSEGV handler of the lazy mode, which walks the map -- a host thread faulting on a stale field while the
+// master thread is inside a drop-in call must never see a rehash in progress.  Recursive per thread (mirror() -> evict; a fault of
+// the thread that holds it, e.g. in the memcpy of an upload, is served in place: no structural change is in progress then).
+// A spin lock: pthread mutexes are not async-signal-safe.
+std::atomic<int> g_reg_lock(0);
+pthread_t g_reg_owner;
+volatile int g_reg_depth = 0;
+struct RegLock {
+  RegLock() {
+    if (g_reg_depth > 0 && pthread_equal(g_reg_owner, pthread_self())) { g_reg_depth = g_reg_depth + 1; return; }
+    int expected = 0;
+    while (!g_reg_lock.compare_exchange_weak(expected, 1, std::memory_order_acquire)) expected = 0;
+    g_reg_owner = pthread_self();
+    g_reg_depth = 1;
+  }
+  ~RegLock() {
+    g_reg_depth = g_reg_depth - 1;
+    if (g_reg_depth == 0) g_reg_lock.store(0, std::memory_order_release);
+  }
+};
 
 [[noreturn]] void die(const char *what) {
   fprintf(stderr, "[tmlqcd_dropin] fatal: %s\n", what);
@@ -121,13 +146,14 @@ tmhip_ctx *refresh(bool need_gauge) {
   CK(tmhip_set_mu(c, g_mu));
   CK(tmhip_set_mu3(c, &g_mu3 ? g_mu3 : 0.));
   if (need_gauge && (g_update_gauge_copy || !g_gauge_uploaded)) {   /* Hopping_Matrix.c:135-139 */
+    // A raised flag always means "the host's links changed since the device last saw them": the device paths that bring both sides
+    // to the same state (tmlqcd_hip_update_gauge, read_gauge_field, tmlqcd_hip_sync_gauge_to_host) clear it themselves
+    // (links_in_step), so a raise that follows -- the reject step restoring the old links (update_tm.c), a host-side
+    // reunitarisation -- is never mistaken for our own.
     if (update_backward_gauge) update_backward_gauge(g_gauge_field);  // host copy + flag, as the reference
     else g_update_gauge_copy = 0;
-    if (!g_dev_links_current) {                                       // (else: the device already holds exactly these links)
-      CK(tmhip_set_gauge(c, &g_gauge_field[0][0]));
-      g_dev_links_newer = false;                                      // the host's links are the truth again
-    }
-    g_dev_links_current = false;
+    CK(tmhip_set_gauge(c, &g_gauge_field[0][0]));
+    g_dev_links_newer = false;                                        // the host's links are the truth again
     g_gauge_uploaded = true;
   }
   return c;
@@ -147,6 +173,8 @@ uintptr_t g_page = 4096;
 struct sigaction g_old_segv;
 bool g_handler_installed = false;
 volatile int g_in_handler = 0;
+pthread_t g_handler_thread;                       // valid while g_in_handler: the thread the SIGSEGV handler is running on
+inline bool in_handler_here() { return g_in_handler && pthread_equal(g_handler_thread, pthread_self()); }
 unsigned long g_lazy_stats[4] = {0, 0, 0, 0};   // faults served, pages fetched one by one, whole-field fetches, stores noticed (tmlqcd_hip_lazy_stats)
 
 inline uintptr_t span_lo(const void *h) { return (uintptr_t)h & ~(g_page - 1); }
@@ -226,16 +254,20 @@ int nsites(int kind) { return kind == TMHIP_FIELD_FULL ? VOLUME : VOLUME / 2; }
 // Lazy mode never lets the runtime touch the program's own pages: a copy from / to pageable memory registers those pages with the
 // driver, and every later mprotect on them goes through its MMU notifier (measured: 28 ms per call instead of microseconds).  Data
 // moves through a page-locked bounce buffer instead; uploads and whole-field downloads are the rare events in this mode.
-void *g_bounce = nullptr;
-size_t g_bounce_bytes = 0;
+// Two of them: the entry points' and the fault handler's.  An upload copies host -> bounce with memcpy, and that copy can itself
+// fault (an edge page shared with a neighbouring field whose host copy is stale, a stale mirror overlapping the span); the handler's
+// whole-field download of that neighbour must not land in -- or re-allocate -- the buffer the interrupted copy is filling.
+void *g_bounce[2] = {nullptr, nullptr};
+size_t g_bounce_bytes[2] = {0, 0};
 void *bounce(size_t bytes) {
-  if (g_bounce_bytes < bytes) {
-    if (g_bounce) tmhip_pinned_free(g_bounce);
-    g_bounce = nullptr; g_bounce_bytes = 0;
-    CK(tmhip_pinned_alloc(bytes, &g_bounce));
-    g_bounce_bytes = bytes;
+  const int k = in_handler_here() ? 1 : 0;
+  if (g_bounce_bytes[k] < bytes) {
+    if (g_bounce[k]) tmhip_pinned_free(g_bounce[k]);
+    g_bounce[k] = nullptr; g_bounce_bytes[k] = 0;
+    CK(tmhip_pinned_alloc(bytes, &g_bounce[k]));
+    g_bounce_bytes[k] = bytes;
   }
-  return g_bounce;
+  return g_bounce[k];
 }
 
 // host <-> device for a mirror of any shape (KIND_LIN: the two halves are plain prefixes, no site permutation)
@@ -262,8 +294,19 @@ void download(tmhip_ctx *c, const void *host_user, Mirror &m) {
   m.host_valid = true;
   if (m.prot != P_RW) { m.prot = -1; set_prot(host_user, m, g_mode == TMLQCD_HIP_LAZY ? P_RO : P_RW, g_reg); }   // both copies current: watch for host stores
 }
+// the host array of a mirror is gone (freed and not handed out again: mincore says ENOMEM for an unmapped page): nothing to bring up to date
+bool host_unmapped(const void *host, const Mirror &m) {
+  if (!m.bytes) return false;
+  unsigned char vec;
+  const uintptr_t pg = span_lo((const char *)host + m.bytes / 2);
+  return mincore((void *)pg, g_page, &vec) != 0 && errno == ENOMEM;
+}
 // a mirror is about to go away (or to stop being watched): bring the host up to date and give it its pages back
 void release_host(tmhip_ctx *c, const void *host, Mirror &m) {
+  if (g_mode == TMLQCD_HIP_LAZY && m.prot != P_RW && host_unmapped(host, m)) {   // freed by the program: there is no host copy to bring up to date
+    m.prot = P_RW; m.page_ok.clear(); m.dev_valid = false; m.host_valid = true;
+    return;
+  }
   if (m.f && m.dev_valid && !m.host_valid) download(c, host, m);
   if (m.prot != P_RW) set_prot(host, m, P_RW, g_reg);
 }
@@ -272,6 +315,7 @@ void release_host(tmhip_ctx *c, const void *host, Mirror &m) {
 void evict_if_crowded(tmhip_ctx *c, const void *keep) {
   static bool read_env = false;
   if (!read_env) { const char *e = getenv("TMLQCD_HIP_MAX_MIRRORS"); if (e && atoi(e) > 8) g_mirror_cap = (size_t)atoi(e); read_env = true; }
+  RegLock lk;
   while (g_reg.size() > g_mirror_cap) {
     const void *victim = nullptr;
     unsigned long long oldest = ~0ull;
@@ -284,21 +328,61 @@ void evict_if_crowded(tmhip_ctx *c, const void *keep) {
   }
 }
 
+// Lazy mode trusts a mirror across calls because it expects to SEE every host store (write-protected pages) and every host load of
+// stale data (inaccessible pages).  That breaks when the program frees the array and gets the same address back: a large calloc is
+// munmap'ed and mmap'ed again (solver/solver_field.c does this per solve in the solvers this library does not replace), the new
+// pages are readable and writable, and nothing faults.  So before a watched mirror is trusted, one page of its span that this
+// mirror alone protects is probed with system calls that fail with EFAULT instead of raising SIGSEGV:
+//   P_NONE: write(2) FROM the page must fail;   P_RO: read(2) INTO the page (of the byte it already holds) must fail.
+// If the probe succeeds the mapping is not the one this library protected: the host copy is the truth, the mirror starts over.
+int g_probe_pipe[2] = {-1, -1};
+bool mapping_replaced(const void *host, const Mirror &m) {
+  if (m.prot == P_RW || !m.bytes) return false;
+  const uintptr_t base = (uintptr_t)host, first = (base + g_page - 1) & ~(g_page - 1), last = (base + m.bytes) & ~(g_page - 1);   // interior pages [first, last)
+  if (first >= last) return false;                                    // the field owns no whole page: its edge pages cannot have been unmapped alone
+  uintptr_t pg = first + ((last - first) / g_page / 2) * g_page;      // a page in the middle
+  if (m.prot == P_NONE) {                                             // ... that the host has not fetched meanwhile (those are read-only)
+    const size_t i0 = (first - span_lo(host)) / g_page, i1 = (last - span_lo(host)) / g_page;
+    size_t i = (pg - span_lo(host)) / g_page;
+    if (i < m.page_ok.size() && m.page_ok[i]) {
+      for (i = i0; i < i1 && i < m.page_ok.size() && m.page_ok[i]; i++) {}
+      if (i >= i1 || i >= m.page_ok.size()) return false;             // every interior page already fetched: nothing left to tell by
+      pg = span_lo(host) + i * g_page;
+    }
+  }
+  if (g_probe_pipe[0] < 0 && pipe2(g_probe_pipe, O_NONBLOCK | O_CLOEXEC)) die("pipe() for the lazy mode's mapping probe failed");   // (non-blocking: a probe never waits)
+  if (m.prot == P_NONE) {
+    if (write(g_probe_pipe[1], (const void *)pg, 1) == 1) { char b; (void)!read(g_probe_pipe[0], &b, 1); return true; }
+    return false;                                                     // EFAULT: still inaccessible, still ours
+  }
+  const char b = *(const volatile char *)pg;                          // P_RO: readable by construction
+  if (write(g_probe_pipe[1], &b, 1) != 1) return false;               // (cannot probe: trust the mirror as before)
+  if (read(g_probe_pipe[0], (void *)pg, 1) == 1) return true;         // the kernel could store into the page (the same byte): not write-protected any more
+  char d; (void)!read(g_probe_pipe[0], &d, 1);                        // EFAULT: take the byte back out (if the kernel left it there)
+  return false;
+}
+
 Mirror &mirror(tmhip_ctx *c, const void *host, int kind, int n = 0) {
+  RegLock lk;
   const size_t bytes = (size_t)(kind == KIND_LIN ? n : nsites(kind)) * sizeof(spinor);
-  if (g_reg.find(host) == g_reg.end()) {
-    evict_if_crowded(c, host);
-    if (g_mode == TMLQCD_HIP_LAZY) {
-      // one device mirror per host byte: an array the program now addresses from another base (the halves of a full field, a
-      // block inside a field) must not have a second, independently valid copy of the same bytes in HBM
-      std::vector<const void *> overlap;
-      for (auto &kv : g_reg)
-        if ((uintptr_t)kv.first < (uintptr_t)host + bytes && (uintptr_t)host < (uintptr_t)kv.first + kv.second.bytes) overlap.push_back(kv.first);
-      for (const void *o : overlap) {
-        release_host(c, o, g_reg[o]);
-        if (g_reg[o].f) tmhip_field_free(c, g_reg[o].f);
-        g_reg.erase(o);
-      }
+  const bool known = g_reg.find(host) != g_reg.end();
+  if (!known) evict_if_crowded(c, host);
+  if (g_mode == TMLQCD_HIP_LAZY) {
+    // One device mirror per host byte, checked on EVERY call: an array the program now addresses from another base (the halves of
+    // a full field, a block inside a field) or with another extent at the SAME base (the even half at X becomes the full field at
+    // X, a prefix grows) must not leave a second, independently valid copy of some of its bytes in HBM -- e.g. Hopping_Matrix into
+    // g_spinor_field[k] and [k+1], then D_psi or square_norm(., VOLUME) on the pair.
+    std::vector<const void *> overlap;
+    for (auto &kv : g_reg)
+      if (kv.first != host && (uintptr_t)kv.first < (uintptr_t)host + bytes && (uintptr_t)host < (uintptr_t)kv.first + kv.second.bytes) overlap.push_back(kv.first);
+    for (const void *o : overlap) {
+      release_host(c, o, g_reg[o]);
+      if (g_reg[o].f) tmhip_field_free(c, g_reg[o].f);
+      g_reg.erase(o);
+    }
+    if (known && mapping_replaced(host, g_reg[host])) {   // freed and re-allocated at the same address: the host copy is the truth
+      Mirror &old = g_reg[host];
+      old.dev_valid = false; old.host_valid = true; old.prot = P_RW; old.page_ok.clear(); old.faults = 0;
     }
   }
   Mirror &m = g_reg[host];
@@ -343,15 +427,13 @@ void done(tmhip_ctx *c, const void *host) {
 void lazy_fault(int sig, siginfo_t *si, void *uctx) {
   const uintptr_t addr = (uintptr_t)si->si_addr, page = addr & ~(g_page - 1);
   bool ours = false;
-  // Host threads (an OpenMP loop over a stale field) may fault at the same time: one at a time in here.  A fault of the thread that
-  // already is in here would be a bug of this handler: let it crash instead of spinning on itself.
-  static std::atomic<int> lock(0);
-  static pthread_t owner;
-  const bool nested = g_in_handler && pthread_equal(owner, pthread_self());
+  // Host threads (an OpenMP loop over a stale field) may fault at the same time, and the master thread may be inside an entry point
+  // that changes the registry: one at a time in here, under the registry's lock.  A fault of the thread that already is in the
+  // handler would be a bug of this handler: let it crash instead of recursing.
+  const bool nested = in_handler_here();
   if (g_ctx && si->si_code == SEGV_ACCERR && !nested) {
-    int expected = 0;
-    while (!lock.compare_exchange_weak(expected, 1, std::memory_order_acquire)) expected = 0;
-    owner = pthread_self();
+    RegLock lk;
+    g_handler_thread = pthread_self();
     g_in_handler = 1;
     const bool store = (((ucontext_t *)uctx)->uc_mcontext.gregs[REG_ERR] & 2) != 0;
     for (auto &kv : g_reg) {
@@ -386,7 +468,6 @@ void lazy_fault(int sig, siginfo_t *si, void *uctx) {
     }
     if (ours) { g_lazy_stats[0]++; mprotect((void *)page, g_page, prot_flags(page_need(page, g_reg))); }
     g_in_handler = 0;
-    lock.store(0, std::memory_order_release);
   }
   if (ours) return;                                  // the faulting instruction runs again
   if (g_old_segv.sa_flags & SA_SIGINFO) { if (g_old_segv.sa_sigaction) { g_old_segv.sa_sigaction(sig, si, uctx); return; } }
@@ -396,6 +477,13 @@ void lazy_fault(int sig, siginfo_t *si, void *uctx) {
 void install_lazy_handler() {
   if (g_handler_installed) return;
   g_page = (uintptr_t)sysconf(_SC_PAGESIZE);
+  // Arrays the library watches must never be recycled INSIDE the malloc heap: free() of a heap chunk writes its bookkeeping into the
+  // chunk, i.e. into a protected page, and the fault would be taken while the allocator holds its lock -- the handler's own
+  // allocations (HIP runtime) then wait for that lock for ever.  glibc serves requests above M_MMAP_THRESHOLD by mmap and gives
+  // them back by munmap, but RAISES the threshold to the size of every mmap'ed block it frees (up to 32 MB): a second work field
+  // of the same size would then come from the heap.  Setting the threshold explicitly switches that adjustment off, so every
+  // field-sized block stays an mmap of its own (and a freed one is recognised by mapping_replaced / host_unmapped).
+  mallopt(M_MMAP_THRESHOLD, 128 * 1024);
   struct sigaction sa;
   memset(&sa, 0, sizeof(sa));
   sa.sa_sigaction = lazy_fault;
@@ -445,6 +533,7 @@ void tmlqcd_hip_host_modified(spinor *field) {
   }
 }
 void tmlqcd_hip_forget(spinor *field) {
+  RegLock lk;
   auto it = g_reg.find(field);
   if (it == g_reg.end()) return;
   if (it->second.prot != P_RW) { it->second.host_valid = true; set_prot(field, it->second, P_RW, g_reg); }   // (the array is being freed: nothing to fetch)
@@ -454,16 +543,17 @@ void tmlqcd_hip_forget(spinor *field) {
 void tmlqcd_hip_comm_init(const char unique_id[128]) { CK(tmhip_comm_init(ctx(), unique_id)); }
 void tmlqcd_hip_finalize(void) {
   if (!g_ctx) return;
+  RegLock lk;
   tmlqcd_hip_sync_all_to_host();
   for (auto &kv : g_reg) { if (kv.second.prot != P_RW) set_prot(kv.first, kv.second, P_RW, g_reg); if (kv.second.f) tmhip_field_free(g_ctx, kv.second.f); }
   g_reg.clear();
   if (g_full_tmp) { tmhip_field_free(g_ctx, g_full_tmp); g_full_tmp = nullptr; }
-  if (g_bounce) { tmhip_pinned_free(g_bounce); g_bounce = nullptr; g_bounce_bytes = 0; }
+  for (int k = 0; k < 2; k++) if (g_bounce[k]) { tmhip_pinned_free(g_bounce[k]); g_bounce[k] = nullptr; g_bounce_bytes[k] = 0; }
   tmhip_destroy(g_ctx);
   g_ctx = nullptr;
   g_gauge_uploaded = false;
   g_clover_uploaded = false;
-  g_dev_links_current = g_dev_links_newer = g_momenta_resident = false;
+  g_dev_links_newer = g_momenta_resident = false;
 }
 
 // ------------------------------------------------------------------ stencil
@@ -1138,6 +1228,18 @@ void tmlqcd_hip_flush_derivative(hamiltonian_field_t *const hf) {
  * are raised (update_gauge.c:104-106) -- the next stencil call refreshes the HOST's backward copy if the program has one, but
  * does not upload again.  Resident mode: g_gauge_field stays behind until tmlqcd_hip_sync_gauge_to_host.
  * The clover blocks become stale exactly as in the reference (the monomials call sw_term / sw_invert again). */
+// Host links and device links have just been brought to the same state by a download.  update_gauge.c:104-106 raises the flags
+// here and leaves the refresh of the host's backward copy to the next consumer; this library IS the next consumer of
+// g_update_gauge_copy, and it must be able to tell its own raise from a later one by the host program (which means "my links
+// changed: upload them").  So the host's backward copy is refreshed right away (update_backward_gauge clears the flag) and the
+// flag stays down: whoever raises it afterwards forces an upload.  The host's fp32 copy is host business: its flag is raised.
+static void links_in_step(su3 **gf, hamiltonian_field_t *hf) {
+  if (update_backward_gauge) update_backward_gauge(gf);
+  g_update_gauge_copy = 0;
+  if (hf) hf->update_gauge_copy = 0;
+  if (&g_update_gauge_copy_32) g_update_gauge_copy_32 = 1;
+  g_gauge_uploaded = true;
+}
 void tmlqcd_hip_update_gauge(const double step, hamiltonian_field_t *const hf) {
   tmhip_ctx *c = refresh(true);                                   // first call of a trajectory: the host's links go up once
   if (!g_momenta_resident) CK(tmhip_momenta_upload(c, &hf->momenta[0][0]));
@@ -1145,9 +1247,7 @@ void tmlqcd_hip_update_gauge(const double step, hamiltonian_field_t *const hf) {
   g_clover_uploaded = false;
   if (g_mode != TMLQCD_HIP_RESIDENT) {
     CK(tmhip_gauge_download(c, &hf->gaugefield[0][0]));
-    hf->update_gauge_copy = 1;
-    g_update_gauge_copy = 1;
-    g_dev_links_current = true;
+    links_in_step(hf->gaugefield, hf);
   } else {
     g_dev_links_newer = true;
   }
@@ -1155,9 +1255,7 @@ void tmlqcd_hip_update_gauge(const double step, hamiltonian_field_t *const hf) {
 void tmlqcd_hip_sync_gauge_to_host(hamiltonian_field_t *const hf) {
   if (!g_dev_links_newer) return;
   CK(tmhip_gauge_download(ctx(), &hf->gaugefield[0][0]));
-  hf->update_gauge_copy = 1;
-  g_update_gauge_copy = 1;                                        // host-side consumers of the backward copy refresh it
-  g_dev_links_current = true;
+  links_in_step(hf->gaugefield, hf);                              // host-side consumers find the backward copy current
   g_dev_links_newer = false;
 }
 /* update_momenta.c:67-72 for a force that was accumulated on the device only (deriv_Sb / tmlqcd_hip_sw_all in resident mode,
@@ -1181,8 +1279,7 @@ paramsGaugeInfo GaugeInfo = {0., 0, {0, 0}, NULL, NULL};
 
 /* io/gauge_read.c:28-198 read_gauge_field(filename, gf): LIME records walked on the host, the binary record unpacked and
  * check-summed in HBM; gf (the host's g_gauge_field) is filled, GaugeInfo set, g_update_gauge_copy raised; returns 0 or -1 with the
- * reference's messages.  The device keeps the links it has just unpacked, so the refresh that g_update_gauge_copy triggers at the
- * next operator call does not upload them again (gf == g_gauge_field only). */
+ * reference's messages. */
 int read_gauge_field(char *filename, su3 **const gf) {
   tmhip_ctx *c = ctx();      // (T-split ranks: every rank reads its part of the record, tmlqcd_hip_comm_init must have been called)
   g_calls++;
@@ -1199,7 +1296,9 @@ int read_gauge_field(char *filename, su3 **const gf) {
   if (info.ildg_data_lfn[0]) { free(GaugeInfo.ildg_data_lfn); GaugeInfo.ildg_data_lfn = strdup(info.ildg_data_lfn); }
   g_update_gauge_copy = 1;                                          /* gauge_read.c:190 */
   g_clover_uploaded = false;
-  if (gf == g_gauge_field && info.gauge_read) { g_gauge_uploaded = true; g_dev_links_current = true; g_dev_links_newer = false; }
+  // (the flag stays raised exactly as the reference leaves it: the host program still has its xchange_gauge to do, and the next
+  // operator call uploads g_gauge_field once more -- 11 ms per configuration read at 32^4 -- rather than guess that nothing changed)
+  if (gf == g_gauge_field && info.gauge_read) g_dev_links_newer = false;
   return 0;
 }
 
@@ -1212,16 +1311,14 @@ int write_gauge_field(char *filename, const int prec, paramsXlfInfo const *xlfIn
   if (!g_dev_links_newer) { CK(tmhip_set_gauge(c, &g_gauge_field[0][0])); g_gauge_uploaded = true; g_clover_uploaded = false; }
   char msg[1024];
   msg[0] = 0;
-  if (xlfInfo) {                                                    /* io/utils_write_xlf_xml.c:30-63 */
+  if (xlfInfo) {                                                    /* io/utils_write_xlf.c:35-55: plain text, what write_gauge_field (io/gauge_write.c:35) writes */
     if (xlfInfo->kappa != 0.0)
-      snprintf(msg, sizeof(msg), "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<xlf-info>\n  <plaquette>%14.12f</plaquette>\n  <trajectory>%d</trajectory>\n"
-               "  <beta>%.12f</beta>\n  <kappa>%.12f</kappa>\n  <mu>%.12f</mu>\n  <c2_rec>%f</c2_rec>\n  <time>%ld</time>\n  <hmcversion>%s</hmcversion>\n"
-               "  <mubar>%.12f</mubar>\n  <epsilonbar>%.12f</epsilonbar>\n  <date>%s</date>\n</xlf-info>",
+      snprintf(msg, sizeof(msg), "plaquette = %14.12f\n trajectory nr = %d\n beta = %.12f, kappa = %.12f, mu = %.12f, c2_rec = %f\n time = %ld\n"
+               " hmcversion = %s\n mubar = %.12f\n epsilonbar = %.12f\n date = %s",
                xlfInfo->plaq, xlfInfo->counter, xlfInfo->beta, xlfInfo->kappa, xlfInfo->mu, xlfInfo->c2_rec, xlfInfo->time, xlfInfo->package_version,
                xlfInfo->mubar, xlfInfo->epsilonbar, xlfInfo->date);
     else
-      snprintf(msg, sizeof(msg), "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<xlf-info>\n  <plaquette>%e</plaquette>\n  <trajectory>%d</trajectory>\n"
-               "  <beta>%.12f</beta>\n  <kappa>%.12f</kappa>\n  <2kappamu>%.12f</2kappamu>\n  <c2_rec>%f</c2_rec>\n  <date>%s</date>\n</xlf-info>",
+      snprintf(msg, sizeof(msg), "plaquette = %e\n trajectory nr = %d\n beta = %.12f\n kappa = %.12f\n 2*kappa*mu = %.12f\n c2_rec = %f\n date = %s",
                xlfInfo->plaq, xlfInfo->counter, xlfInfo->beta, xlfInfo->kappa, xlfInfo->mu, xlfInfo->c2_rec, xlfInfo->date);
   }
   unsigned cs[2];
