@@ -299,8 +299,9 @@ int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_
 /* generic event slots (0..15) recorded on the context's compute stream */
 int tmhip_event_record(tmhip_ctx *ctx, int slot);
 int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double *ms);
-/* Kernel variant selection for A/B measurements; the defaults are the measured best.
- *   "block" 0|256|64 threads per block (0: automatic, 64 on small local lattices)         "nt" 1|0 non-temporal link loads / output stores
+/* Launch-shape and scheduling options; the defaults are the measured best.  Apart from "gauge_recon" (below) none of
+ * them changes a result beyond rounding (reduction order, FMA contraction); unknown names are refused.
+ *   "block" 0|256|64 threads per block (0: automatic, 64 on small local lattices)
  *   "xcd"   block order: 2 automatic (default; tile order up to L = 32, slab order above), 0 none, 1 one chunk per XCD,
  *           3 slab, 4 tile;  "tgrp" time-slices per tile group (0 = automatic)
  *   "occ" / "occ32"  waves per SIMD allowed by a dynamic-LDS cap for the fp64 / fp32 stencil (3 / 0 = no cap)
@@ -316,7 +317,6 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "gauge_cache" -1 (automatic) / 0 / 1: the 64-thread stencil launches of small unsplit lattices load the links with (0) or without (1) the
  *                  streaming hint; automatic = without while the gauge copy is <= 200 MB (it then stays in the Infinity Cache between calls)
  *   "swall_order" 0 / 1: block order of the owner-computes sw_all (one chunk per XCD / slab order, default)
- *   "swall_atomic" 1: tmhip_sw_all in the scatter form of the reference (fp64 atomics) instead of the owner-computes kernel (A/B only)
  * One option changes what is read from memory:
  * "gauge_recon" = 12 makes the twisted-mass stencil launches (fp64 and fp32) fetch only the first two rows of every link and
  * rebuild the third as conj(row0 x row1) in registers (the 12-real compression the reference exposes for its external

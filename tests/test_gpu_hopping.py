@@ -36,16 +36,16 @@ def test_hopping_matrix_16(setup16, ieo):
     dk.free(); dl.free()
 
 
-@pytest.mark.parametrize("block,nt,xcd,minw,occ", [(64, 0, 0, 0, 0), (64, 1, 2, 4, 2), (256, 1, 1, 0, 3), (256, 0, 2, 4, 0), (256, 1, 3, 0, 3), (64, 1, 3, 0, 0)])
-def test_kernel_variants_agree(setup16, block, nt, xcd, minw, occ):
+@pytest.mark.parametrize("block,xcd,minw,occ", [(64, 0, 0, 0), (64, 2, 4, 2), (256, 1, 0, 3), (256, 2, 4, 0), (256, 3, 0, 3), (64, 3, 0, 0), (256, 4, 0, 3)])
+def test_kernel_variants_agree(setup16, block, xcd, minw, occ):
     orc, lat = setup16
     lat.set_option("hopsplit", 0)          # the one-thread-per-site kernels (the automatic choice at 16^4 is the hop-split kernel)
     N = orc.Vh
     k = random_spinor(9, N)
     ref = orc.new_field()
     orc.Hopping_Matrix(1, ref, k)
-    defaults = dict(block=256, nt=1, xcd=2, minw=0, occ=3)
-    for name, val in dict(block=block, nt=nt, xcd=xcd, minw=minw, occ=occ).items():
+    defaults = dict(block=0, xcd=2, minw=0, occ=3)
+    for name, val in dict(block=block, xcd=xcd, minw=minw, occ=occ).items():
         lat.set_option(name, val)
     dk, dl = lat.field(k), lat.field()
     lat.Hopping_Matrix(1, dl, dk)

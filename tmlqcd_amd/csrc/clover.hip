@@ -331,104 +331,9 @@ __device__ __forceinline__ M3 m3_dag(const M3 &a) {
     for (int j = 0; j < 3; j++) r.e[3 * i + j] = m3_conj(a.e[3 * j + i]);
   return r;
 }
-// su3adj.h:164-172 scattered with atomics: neighbouring sites contribute to the same link (the reference's _nonlocal update).
-// `site` is a lexicographic index; on a T-split rank it may lie in the t = T / t = -1 halo slabs (site >= V): those
-// contributions belong to links of the ring neighbours and are collected in `halo` [2 slabs][4 mu][8][XYZ] for the exchange
-// (xchange_deri.c, both directions).
-__device__ __forceinline__ void tl_atomic_add(double *deriv, double *halo, const LexGeom &g, int Vh, int par, int site, int mu, double c, const M3 &a) {
-  double *d;
-  size_t st;
-  if (site >= g.V) {
-    const int XYZ = g.LX * g.LY * g.LZ, slab = (site - g.V) / XYZ, sp = (site - g.V) - slab * XYZ;
-    d = halo + ((size_t)slab * 32 + (size_t)mu * 8) * XYZ + sp;
-    st = XYZ;
-  } else {
-    d = deriv + ((size_t)par * 32 + (size_t)mu * 8) * Vh + (site >> 1);
-    st = Vh;
-  }
-  atomicAdd(d + 0 * st, c * (-a.e[3].y - a.e[1].y));
-  atomicAdd(d + 1 * st, c * (+a.e[3].x - a.e[1].x));
-  atomicAdd(d + 2 * st, c * (-a.e[0].y + a.e[4].y));
-  atomicAdd(d + 3 * st, c * (-a.e[6].y - a.e[2].y));
-  atomicAdd(d + 4 * st, c * (+a.e[6].x - a.e[2].x));
-  atomicAdd(d + 5 * st, c * (-a.e[7].y - a.e[5].y));
-  atomicAdd(d + 6 * st, c * (+a.e[7].x - a.e[5].x));
-  atomicAdd(d + 7 * st, c * ((-a.e[0].y - a.e[4].y + 2.0 * a.e[8].y) * 0.577350269189625));
-}
-
-// operator/clover_accumulate_deriv.c:58-205: thread = (lexicographic site x, plane (k,l)); sixteen link derivatives from the
-// four leaves with the insertion matrix vis[k][l]
-__global__ __launch_bounds__(64) void sw_all_kernel(const v2d *__restrict__ raw, const v2d *__restrict__ swpm, double *__restrict__ deriv,
-                                                    double *__restrict__ halo, LexGeom g, int Vh, double c) {
-  const int x = blockIdx.x * 64 + threadIdx.x;
-  if (x >= g.V) return;
-  const int p = blockIdx.y;
-  const int k = p < 3 ? 0 : (p < 5 ? 1 : 2), l = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
-  int cd[4];
-  int r = x;
-  cd[3] = r % g.LZ; r /= g.LZ; cd[2] = r % g.LY; r /= g.LY; cd[1] = r % g.LX; cd[0] = r / g.LX;
-  const int p0 = (cd[0] + cd[1] + cd[2] + cd[3]) & 1, p1 = 1 - p0;
-  auto at = [&](int dk, int dl) {
-    int d[4] = {cd[0], cd[1], cd[2], cd[3]};
-    d[k] += dk; d[l] += dl;
-    return lex_index(g, d[0], d[1], d[2], d[3]);
-  };
-  const int xpk = at(1, 0), xpl = at(0, 1), xmk = at(-1, 0), xml = at(0, -1), xpkml = at(1, -1), xplmk = at(-1, 1), xmkml = at(-1, -1);
-  // vis[k][l] (clover_accumulate_deriv.c:73-96): (a, b, mode) = which two of the four matrices of swm (planes 0l) / swp (planes kl, k>0)
-  const size_t s = (size_t)p0 * Vh + (x >> 1);
-  const int set = p < 3 ? 0 : 1;
-  auto ld = [&](int n) { M3 mtx; for (int e = 0; e < 9; e++) mtx.e[e] = swpm[((size_t)(set * 4 + n) * 9 + e) * g.V + s]; return mtx; };
-  M3 V;
-  {
-    // p: 0 (01) -i(m1+m3), 1 (02) m1-m3, 2 (03) i(m2-m0), 3 (12) i(p2-p0), 4 (13) p3-p1, 5 (23) -i(p1+p3)
-    const bool diag = (p == 2 || p == 3);
-    const M3 A = ld(diag ? 2 : (p == 4 ? 3 : 1)), B = ld(diag ? 0 : (p == 4 ? 1 : 3));
-#pragma unroll
-    for (int e = 0; e < 9; e++) {
-      const v2d sum = A.e[e] + B.e[e], dif = A.e[e] - B.e[e];
-      if (p == 0 || p == 5) V.e[e] = v2d{sum.y, -sum.x};            // -i (A + B)
-      else if (p == 1 || p == 4) V.e[e] = dif;                        //  A - B
-      else V.e[e] = v2d{-dif.y, dif.x};                               //  i (A - B)
-    }
-    const M3 Vd = m3_dag(V);
-#pragma unroll
-    for (int e = 0; e < 9; e++) V.e[e] -= Vd.e[e];
-  }
-  M3 v1, v2, vv1, vv2, plaq, w1, w2, w3, w4;
-  // leaf 1
-  w1 = m3_load(raw, x, k); w2 = m3_load(raw, xpk, l); w3 = m3_load(raw, xpl, k); w4 = m3_load(raw, x, l);
-  v1 = m3_mul<false, false>(w1, w2); v2 = m3_mul<false, false>(w4, w3); plaq = m3_mul<false, true>(v1, v2);
-  vv1 = m3_mul<false, false>(plaq, V);                                           tl_atomic_add(deriv, halo, g, Vh, p0, x, k, c, vv1);
-  vv2 = m3_mul<true, false>(w1, vv1); vv1 = m3_mul<false, false>(vv2, w1);       tl_atomic_add(deriv, halo, g, Vh, p1, xpk, l, c, vv1);
-  vv2 = m3_mul<false, false>(V, plaq); vv1 = m3_dag(vv2);                        tl_atomic_add(deriv, halo, g, Vh, p0, x, l, c, vv1);
-  vv2 = m3_mul<true, false>(w4, vv1); vv1 = m3_mul<false, false>(vv2, w4);       tl_atomic_add(deriv, halo, g, Vh, p1, xpl, k, c, vv1);
-  // leaf 2
-  w1 = m3_load(raw, x, l); w2 = m3_load(raw, xplmk, k); w3 = m3_load(raw, xmk, l); w4 = m3_load(raw, xmk, k);
-  v1 = m3_mul<false, true>(w1, w2); v2 = m3_mul<true, false>(w3, w4); plaq = m3_mul<false, false>(v1, v2);
-  vv1 = m3_mul<false, false>(plaq, V);                                           tl_atomic_add(deriv, halo, g, Vh, p0, x, l, c, vv1);
-  vv1 = m3_dag(v1); vv2 = m3_mul<false, true>(vv1, V); vv1 = m3_mul<false, true>(vv2, v2);   tl_atomic_add(deriv, halo, g, Vh, p0, xplmk, k, c, vv1);
-  vv2 = m3_mul<false, false>(w3, vv1); vv1 = m3_mul<false, true>(vv2, w3);       tl_atomic_add(deriv, halo, g, Vh, p1, xmk, l, c, vv1);
-  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, halo, g, Vh, p1, xmk, k, c, vv2);
-  // leaf 3
-  w1 = m3_load(raw, xmk, k); w2 = m3_load(raw, xmkml, l); w3 = m3_load(raw, xmkml, k); w4 = m3_load(raw, xml, l);
-  v2 = m3_mul<false, false>(w3, w4);
-  vv1 = m3_mul<false, true>(w1, V); vv2 = m3_mul<false, true>(vv1, v2); vv1 = m3_mul<false, false>(vv2, w2);   tl_atomic_add(deriv, halo, g, Vh, p1, xmk, k, c, vv1);
-  vv2 = m3_mul<false, false>(w2, vv1); vv1 = m3_mul<false, true>(vv2, w2);       tl_atomic_add(deriv, halo, g, Vh, p0, xmkml, l, c, vv1);
-  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, halo, g, Vh, p0, xmkml, k, c, vv2);
-  vv1 = m3_mul<true, false>(w3, vv2); vv2 = m3_mul<false, false>(vv1, w3);       tl_atomic_add(deriv, halo, g, Vh, p1, xml, l, c, vv2);
-  // leaf 4
-  w1 = m3_load(raw, xml, l); w2 = m3_load(raw, xml, k); w3 = m3_load(raw, xpkml, l); w4 = m3_load(raw, x, k);
-  v1 = m3_mul<true, false>(w1, w2); v2 = m3_mul<false, true>(w3, w4);
-  vv1 = m3_mul<false, true>(w1, V); vv2 = m3_mul<false, true>(vv1, v2); vv1 = m3_mul<false, true>(vv2, w2);    tl_atomic_add(deriv, halo, g, Vh, p1, xml, l, c, vv1);
-  vv2 = m3_dag(vv1);                                                             tl_atomic_add(deriv, halo, g, Vh, p1, xml, k, c, vv2);
-  vv1 = m3_mul<true, false>(w2, vv2); vv2 = m3_mul<false, false>(vv1, w2);       tl_atomic_add(deriv, halo, g, Vh, p0, xpkml, l, c, vv2);
-  vv2 = m3_dag(v2); vv1 = m3_mul<false, true>(vv2, v1); vv2 = m3_mul<false, true>(vv1, V);   tl_atomic_add(deriv, halo, g, Vh, p0, x, k, c, vv2);
-}
-
-
 // ------------------------------------------------------------------ sw_all, owner-computes (no atomics)
-// The reference walks (site x, plane kl) and scatters sixteen su3adj contributions (clover_accumulate_deriv.c:100-201, the kernel
-// above with 96 fp64 atomics per thread: 4.3 ms at 32^4).  Turned inside out like deriv_Sb: one thread OWNS the link (y, mu) and
+// The reference walks (site x, plane kl) and scatters sixteen su3adj contributions (clover_accumulate_deriv.c:100-201; written that
+// way for the GPU -- 96 fp64 atomics per thread -- it took 4.3 ms at 32^4, profiles/r02_swall_ab.log; that form is not kept).  Turned inside out like deriv_Sb: one thread OWNS the link (y, mu) and
 // collects everything that reaches it.  Every contribution of the reference is a closed plaquette loop that starts with U_mu(y)
 // and carries the insertion matrix W_kl(z) = vis[k][l](z) - h.c. (:73-99) at one of its four corners z -- with +W when the loop runs
 // k -> l -> -k -> -l and W^dagger = -W (W is anti-hermitian bit for bit) the other way round; the transports the reference writes
@@ -964,20 +869,6 @@ int tmhip_sw_deriv(tmhip_ctx *ctx, int ieo, double mu) {
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }
-// what the ring neighbours computed for OUR links: slab 0 of the down neighbour is our t = 0 slice, slab 1 of the up neighbour our t = T-1
-__global__ __launch_bounds__(256) void deriv_halo_add_kernel(double *__restrict__ deriv, const double *__restrict__ recv, LexGeom g, int Vh) {
-  const int XYZ = g.LX * g.LY * g.LZ;
-  const int sp = blockIdx.x * 256 + threadIdx.x;
-  if (sp >= XYZ) return;
-  const int w = blockIdx.y;                         // 0: t = 0 (from below), 1: t = T-1 (from above)
-  const int t = w ? g.T - 1 : 0;
-  const int z = sp % g.LZ, y = (sp / g.LZ) % g.LY, x = sp / (g.LZ * g.LY);
-  const int par = (t + x + y + z) & 1;              // local T is even: local and global parity agree
-  const int idx = (t * XYZ + sp) >> 1;
-#pragma unroll 4
-  for (int m = 0; m < 32; m++) deriv[((size_t)par * 32 + m) * Vh + idx] += recv[((size_t)w * 32 + m) * XYZ + sp];
-}
-
 static int sw_all_prepare(tmhip_ctx *ctx, const void *gauge_host) {
   if (!ctx->swpm) TMHIP_FAIL("sw_all called before sw_spinor_eo / sw_deriv");
   TMHIP_CHECK(hipSetDevice(ctx->device));
@@ -992,15 +883,6 @@ static int sw_all_prepare(tmhip_ctx *ctx, const void *gauge_host) {
   }
   if (!ctx->deriv && tmhip_derivative_zero(ctx)) return 1;
   const size_t XYZ = (size_t)ctx->g.LX * ctx->g.LY * ctx->g.LZ;
-  if (ctx->opt_swall_atomic) {
-    if (ctx->g.nproc_t > 1) {
-      const size_t hb = (size_t)2 * 32 * XYZ * sizeof(double);
-      if (!ctx->deriv_halo) TMHIP_CHECK(hipMalloc((void **)&ctx->deriv_halo, hb));
-      if (!ctx->deriv_halo_recv) TMHIP_CHECK(hipMalloc((void **)&ctx->deriv_halo_recv, hb));
-      TMHIP_CHECK(hipMemsetAsync(ctx->deriv_halo, 0, hb, ctx->stream));
-    }
-    return 0;
-  }
   // owner-computes form: the interior (or the whole unsplit lattice) reads the stencil's gauge copy -- it must come from the same links
   if (!ctx->gauge_copy_current && (ctx->g.nproc_t == 1 || ctx->g.T > 2) && tmhip_resort_gauge(ctx)) return 1;
   // pass 1: the six insertion matrices of every site, compact (30 complex planes)
@@ -1021,12 +903,6 @@ static int sw_all_prepare(tmhip_ctx *ctx, const void *gauge_host) {
 static int sw_all_launch(tmhip_ctx *ctx, double kappa, double c_sw) {
   LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, ctx->g.nproc_t > 1 ? 1 : 0};
   const double c = -2. * (kappa * c_sw / 8.);
-  if (ctx->opt_swall_atomic) {
-    hipLaunchKernelGGL(sw_all_kernel, dim3((ctx->V + 63) / 64, 6), dim3(64), 0, ctx->stream, (const v2d *)ctx->gauge_raw, (const v2d *)ctx->swpm, ctx->deriv,
-                       ctx->deriv_halo, g, ctx->Vh, c);
-    TMHIP_CHECK(hipGetLastError());
-    return 0;
-  }
   const bool split = ctx->g.nproc_t > 1;
   const int ib = split ? ctx->face : 0, ie = split ? ctx->Vh - ctx->face : ctx->Vh;      // sites whose plaquettes stay on this rank
   if (ie > ib && (!split || ctx->g.T > 2)) {
@@ -1052,37 +928,16 @@ static int sw_all_launch(tmhip_ctx *ctx, double kappa, double c_sw) {
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }
-static int sw_all_add_received(tmhip_ctx *ctx) {
-  LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, 1};
-  const int XYZ = ctx->g.LX * ctx->g.LY * ctx->g.LZ;
-  hipLaunchKernelGGL(deriv_halo_add_kernel, dim3((XYZ + 255) / 256, 2), dim3(256), 0, ctx->stream, ctx->deriv, (const double *)ctx->deriv_halo_recv, g, ctx->Vh);
-  TMHIP_CHECK(hipGetLastError());
-  return 0;
-}
-
 /* operator/clover_accumulate_deriv.c:58 sw_all(hf, kappa, c_sw): adds the clover-leaf derivatives to the device-resident derivative
  * field (the one tmhip_deriv_Sb accumulates into).  gauge_field: host links as for tmhip_set_gauge (with the halo slabs on a
  * T-split rank), or NULL to reuse the links resident in HBM.  Every link is owned by one thread that gathers its 24 contributions
  * (sw_all_gather_kernel).  On T-split ranks the plaquettes next to the t-faces contain links and insertion matrices of both ring
  * neighbours: the links are in the halo slabs, the neighbours' t-slices of swm / swp are exchanged over RCCL first (what
- * xchange_deri.c does for the derivative in one direction only, :88-89, is not needed: nothing is computed for foreign links).
- * Option "swall_atomic" 1 selects the scatter form of the reference instead (atomics, derivative halos exchanged afterwards). */
+ * xchange_deri.c does for the derivative in one direction only, :88-89, is not needed: nothing is computed for foreign links). */
 int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_sw) {
   if (sw_all_prepare(ctx, gauge_host)) return 1;
   const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
   if (np > 1 && !ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
-  if (ctx->opt_swall_atomic) {
-    if (sw_all_launch(ctx, kappa, c_sw)) return 1;
-    if (np == 1) return 0;
-    const size_t n = (size_t)32 * ctx->g.LX * ctx->g.LY * ctx->g.LZ;   // doubles per slab
-    TMHIP_NCCL_CHECK(ncclGroupStart());
-    TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo, n, ncclDouble, up, ctx->comm_red, ctx->stream));            // our t = T slab  -> up neighbour's t = 0
-    TMHIP_NCCL_CHECK(ncclSend(ctx->deriv_halo + n, n, ncclDouble, dn, ctx->comm_red, ctx->stream));        // our t = -1 slab -> down neighbour's t = T-1
-    TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv, n, ncclDouble, dn, ctx->comm_red, ctx->stream));       // the down neighbour's t = T slab is our t = 0
-    TMHIP_NCCL_CHECK(ncclRecv(ctx->deriv_halo_recv + n, n, ncclDouble, up, ctx->comm_red, ctx->stream));   // the up neighbour's t = -1 slab is our t = T-1
-    TMHIP_NCCL_CHECK(ncclGroupEnd());
-    return sw_all_add_received(ctx);
-  }
   if (np > 1) {
     const size_t n = (size_t)2 * 30 * ctx->g.LX * ctx->g.LY * ctx->g.LZ;   // doubles per slice of insertion matrices
     double *snd = (double *)ctx->swpm_halo_send, *rcv = (double *)ctx->swpm_halo_recv;
@@ -1098,29 +953,20 @@ int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_
 /* The same on a T-split lattice held by n contexts of one process (peer copies instead of RCCL), as tmhip_multi_deriv_Sb. */
 int tmhip_multi_sw_all(int n, tmhip_ctx **ctxs, double kappa, double c_sw) {
   if (n < 2) TMHIP_FAIL("tmhip_multi_sw_all needs >= 2 contexts");
-  const bool atomic = ctxs[0]->opt_swall_atomic != 0;
   for (int r = 0; r < n; r++) {
     tmhip_ctx *c = ctxs[r];
     if (c->g.nproc_t != n || c->g.proc_t != r) TMHIP_FAIL("context %d is not rank %d of a %d-way T split", r, r, n);
-    if ((c->opt_swall_atomic != 0) != atomic) TMHIP_FAIL("tmhip_multi_sw_all: the contexts disagree on the swall_atomic option");
     if (sw_all_prepare(c, nullptr)) return 1;
-    if (atomic && sw_all_launch(c, kappa, c_sw)) return 1;
   }
   for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
   const size_t XYZ = (size_t)ctxs[0]->g.LX * ctxs[0]->g.LY * ctxs[0]->g.LZ;
-  const size_t sb = atomic ? (size_t)32 * XYZ * sizeof(double) : (size_t)30 * XYZ * sizeof(v2d);
+  const size_t sb = (size_t)30 * XYZ * sizeof(v2d);
   for (int r = 0; r < n; r++) {
     tmhip_ctx *c = ctxs[r], *up = ctxs[(r + 1) % n], *dn = ctxs[(r + n - 1) % n];
     TMHIP_CHECK(hipSetDevice(c->device));
-    if (atomic) {
-      TMHIP_CHECK(hipMemcpyPeerAsync(c->deriv_halo_recv, c->device, dn->deriv_halo, dn->device, sb, c->stream));
-      TMHIP_CHECK(hipMemcpyPeerAsync((char *)c->deriv_halo_recv + sb, c->device, (char *)up->deriv_halo + sb, up->device, sb, c->stream));
-      if (sw_all_add_received(c)) return 1;
-    } else {
-      TMHIP_CHECK(hipMemcpyPeerAsync(c->swpm_halo_recv, c->device, up->swpm_halo_send, up->device, sb, c->stream));                                  // t = T  <- up's t = 0
-      TMHIP_CHECK(hipMemcpyPeerAsync((char *)c->swpm_halo_recv + sb, c->device, (char *)dn->swpm_halo_send + sb, dn->device, sb, c->stream));        // t = -1 <- down's t = T-1
-      if (sw_all_launch(c, kappa, c_sw)) return 1;
-    }
+    TMHIP_CHECK(hipMemcpyPeerAsync(c->swpm_halo_recv, c->device, up->swpm_halo_send, up->device, sb, c->stream));                                  // t = T  <- up's t = 0
+    TMHIP_CHECK(hipMemcpyPeerAsync((char *)c->swpm_halo_recv + sb, c->device, (char *)dn->swpm_halo_send + sb, dn->device, sb, c->stream));        // t = -1 <- down's t = T-1
+    if (sw_all_launch(c, kappa, c_sw)) return 1;
   }
   for (int r = 0; r < n; r++) { TMHIP_CHECK(hipSetDevice(ctxs[r]->device)); TMHIP_CHECK(hipStreamSynchronize(ctxs[r]->stream)); }
   return 0;

@@ -144,7 +144,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->V = g.T * g.LX * g.LY * g.LZ; ctx->Vh = ctx->V / 2; ctx->face = g.LX * g.LY * g.LZ / 2;
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
-  ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_nt = 1; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
+  ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
   ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0;
   {
     // bound of the device-side waits for the neighbours' faces: TMLQCD_HIP_FLAG_TIMEOUT_S in the environment (0 = none), default 120 s
@@ -217,8 +217,6 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->momenta) (void)hipFree(ctx->momenta);
   if (ctx->force_send) (void)hipFree(ctx->force_send);
   if (ctx->force_recv) (void)hipFree(ctx->force_recv);
-  if (ctx->deriv_halo) (void)hipFree(ctx->deriv_halo);
-  if (ctx->deriv_halo_recv) (void)hipFree(ctx->deriv_halo_recv);
   if (ctx->sw_ins) (void)hipFree(ctx->sw_ins);
   if (ctx->io_sums) (void)hipFree(ctx->io_sums);
   if (ctx->swpm_halo_send) (void)hipFree(ctx->swpm_halo_send);
@@ -281,14 +279,12 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "minw")) { if (value < 0 || value > 8) TMHIP_FAIL("minw must be in [0, 8] waves per SIMD"); ctx->opt_minw = value; }
   else if (!strcmp(name, "occ")) { if (value < 0 || value > 8) TMHIP_FAIL("occ must be in [0, 8] waves per SIMD (0 = no cap)"); ctx->opt_occ = value; }
   else if (!strcmp(name, "xcd")) { if (value < 0 || value > 4) TMHIP_FAIL("xcd must be 0 (none), 1 (chunk), 2 (automatic), 3 (slab) or 4 (tile)"); ctx->opt_xcd = value; }
-  else if (!strcmp(name, "nt")) ctx->opt_nt = value;
   else if (!strcmp(name, "tgrp")) { if (value < 0 || value > ctx->g.T) TMHIP_FAIL("tgrp must be in [0, T]"); ctx->opt_tgrp = value; }
   else if (!strcmp(name, "split_sync")) { if (value < 0 || value > 1) TMHIP_FAIL("split_sync must be 0 (boundary hop in the stencil kernel, behind a flag) or 1 (HIP events + exterior kernel)"); ctx->opt_split_sync = value; }
   else if (!strcmp(name, "flag_timeout_ms")) { if (value < 0) TMHIP_FAIL("flag_timeout_ms must be >= 0 (0 = wait without bound)"); ctx->flag_timeout_ticks = (unsigned long long)value * 100000ull; }
   else if (!strcmp(name, "comm_split")) { if (ctx->comm_ready) TMHIP_FAIL("comm_split must be set before the communicator is created"); ctx->opt_comm_split = value != 0; }
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
   else if (!strcmp(name, "gauge_cache")) { if (value < -1 || value > 1) TMHIP_FAIL("gauge_cache must be -1 (automatic), 0 or 1"); ctx->opt_gauge_cache = value; }
-  else if (!strcmp(name, "swall_atomic")) ctx->opt_swall_atomic = value != 0;
   else if (!strcmp(name, "swall_order")) { if (value < 0 || value > 1) TMHIP_FAIL("swall_order must be 0 (chunk per XCD) or 1 (slab order, default)"); ctx->opt_swall_order = value; }
   else if (!strcmp(name, "occ32")) { if (value < 0 || value > 8) TMHIP_FAIL("occ32 must be in [0, 8]"); ctx->opt_occ32 = value; }
   else if (!strcmp(name, "gauge_recon")) {

@@ -108,7 +108,6 @@ struct tmhip_ctx {
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
   double *deriv;
   double *momenta;     // hamiltonian_field_t::momenta, su3adj [V][4] = double [V][4][8], resident for tmhip_update_gauge (md_update.hip)
-  double *deriv_halo, *deriv_halo_recv;   // T-split sw_all: [2 slabs (t = T, t = -1)][4 mu][8][LX LY LZ] contributions to the neighbours' links / theirs to ours
   v2d *sw_ins;         // sw_all: the six anti-hermitian insertion matrices of every site, compact [6][5][V] (clover.hip, sw_insertion_kernel)
   v2d *swpm_halo_send, *swpm_halo_recv;   // T-split sw_all (owner-computes): [2 slices][30][LX LY LZ] our t = 0 / T-1 slices of sw_ins / the neighbours' t = T, -1
   v2d *force_send, *force_recv;   // T-split deriv_Sb: [24][face] t=0 slices of (l, k), ours / the up-neighbour's
@@ -116,7 +115,7 @@ struct tmhip_ctx {
   void *cg_state; double *cg_hist; int cg_hist_len;
   int mixed_trace[256]; int mixed_trace_n;   // inner iteration count of every outer iteration of the last tmhip_mixed_cg_her
   // options
-  int opt_block, opt_xcd, opt_nt, opt_minw, opt_occ, opt_occ32;        // stencil launch shape (tmhip_set_option, include/tmlqcd_hip.h)
+  int opt_block, opt_xcd, opt_minw, opt_occ, opt_occ32;        // stencil launch shape (tmhip_set_option, include/tmlqcd_hip.h)
   int opt_tgrp;
   int opt_gauge_cache;                                                  // -1 automatic; 0 / 1: small-lattice launches load the links with / without the streaming hint
   int opt_hopsplit;                                                     // -1 automatic, 0 / 1: the eight hops of a site spread over four waves (small unsplit lattices)
@@ -127,7 +126,6 @@ struct tmhip_ctx {
   int opt_comm_split;                                                   // 0: do not split off a second communicator (exercises the one-communicator fallback)
   int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot;                      // cg_her
   int opt_swall_order;                                                  // block order of the owner-computes sw_all: 0 one contiguous chunk per XCD, 1 slab order
-  int opt_swall_atomic;                                                 // 1 = sw_all in the reference's scatter form (fp64 atomics), A/B only
   double gauge_recon_dev;   // max |U_row2 - conj(row0 x row1)| over all links of the resident gauge field (-1: not measured)
 };
 

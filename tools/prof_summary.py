@@ -57,7 +57,7 @@ for name, calls, avg, pct, mn, mx in stats:
     js["kernels"][name] = {"calls": calls, "avg_us": avg / 1e3, "read_bytes": rdb, "write_bytes": wrb, "traffic_bytes": tot}
 md = "\n".join(lines) + "\n"
 open(os.path.join(out, "%s_summary.md" % tag), "w").write(md)
-hop = [k for k in js["kernels"] if k.startswith("void hop_kernel<0, 0")]
+hop = [k for k in js["kernels"] if "hop_kernel<0, 0, true, 256, 3, -1, 64>" in k]
 if hop and js["kernels"][hop[0]]["traffic_bytes"]:
     js["bytes_per_launch"] = js["kernels"][hop[0]]["traffic_bytes"]
     js["kernel"] = hop[0]

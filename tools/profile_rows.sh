@@ -15,7 +15,7 @@ rows = []
 for d in ("/tmp/rows_a", "/tmp/rows_b"):
     for f in glob.glob(d + "/*/*_kernel_stats.csv"):
         rows += list(csv.DictReader(open(f)))
-keep = ("sw_", "deriv_Sb", "update_", "ildg_", "gauge_sort", "swpm", "clover_site")
+keep = ("sw_", "deriv_Sb", "update_", "links_kernel", "halo_backward", "ildg_", "swpm", "clover_site")
 with open(sys.argv[1], "w") as o:
     o.write("kernel,calls,avg_us,min_us,max_us\n")
     for r in rows:

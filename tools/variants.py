@@ -20,8 +20,8 @@ lat.set_gauge(syn.gauge_field(1, T, L, L, L))
 f0 = lat.field(syn.spinor_field_eo(2, 0, T, L, L, L))
 f1, f2 = lat.field(), lat.field()
 print("setup %.1fs  V=%d" % (time.time() - t0, lat.V), flush=True)
-keys = ("block", "nt", "minw", "xcd", "occ")
-grid = list(itertools.product((64, 256), (0, 1), (0, 4), (1, 2), (0, 2, 3)))
+keys = ("block", "minw", "xcd", "occ")
+grid = list(itertools.product((64, 256), (0, 4), (1, 2), (0, 2, 3)))
 res = {v: ([], []) for v in grid}
 iters = 10
 for rnd in range(3):
