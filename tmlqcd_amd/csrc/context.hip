@@ -145,7 +145,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
-  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0;
+  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1;
   {
     // bound of the device-side waits for the neighbours' faces: TMLQCD_HIP_FLAG_TIMEOUT_S in the environment (0 = none), default 120 s
     double sec = 120.0;
@@ -282,6 +282,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "tgrp")) { if (value < 0 || value > ctx->g.T) TMHIP_FAIL("tgrp must be in [0, T]"); ctx->opt_tgrp = value; }
   else if (!strcmp(name, "split_sync")) { if (value < 0 || value > 1) TMHIP_FAIL("split_sync must be 0 (boundary hop in the stencil kernel, behind a flag) or 1 (HIP events + exterior kernel)"); ctx->opt_split_sync = value; }
   else if (!strcmp(name, "flag_timeout_ms")) { if (value < 0) TMHIP_FAIL("flag_timeout_ms must be >= 0 (0 = wait without bound)"); ctx->flag_timeout_ticks = (unsigned long long)value * 100000ull; }
+  else if (!strcmp(name, "prepack")) { ctx->opt_prepack = value != 0; ctx->prepacked = nullptr; }
   else if (!strcmp(name, "comm_split")) { if (ctx->comm_ready) TMHIP_FAIL("comm_split must be set before the communicator is created"); ctx->opt_comm_split = value != 0; }
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
   else if (!strcmp(name, "gauge_cache")) { if (value < -1 || value > 1) TMHIP_FAIL("gauge_cache must be -1 (automatic), 0 or 1"); ctx->opt_gauge_cache = value; }
@@ -487,7 +488,7 @@ static int hop_tm_sub_g5(tmhip_ctx *ctx, v2d *l, const v2d *p, const v2d *k, int
   return tmhip_launch_hopping(ctx, ieo, l, k, p, EPI_TM_SUB_G5, 1., (_sign < 0. ? -1. : 1.) * ctx->mu, flags);
 }
 #define HOP_FIRST HOP_COMM
-#define HOP_NEXT HOP_COMM
+#define HOP_NEXT (HOP_COMM | HOP_CHAINED)
 /* l may alias k for these (invert_eo.c:270 calls Qtm_minus_psi in place): the last stencil reads
  * k only through the element-wise epilogue `p`, never as a gathered neighbour field. */
 /* tm_operators.c:172-177 */
@@ -642,6 +643,7 @@ int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
   if (ctx->g.nproc_t > 1) TMHIP_FAIL("loopback is a single-rank self-test");
   ctx->loopback = on != 0;
   ctx->loopback_rccl = on == 2;
+  ctx->prepacked = nullptr;
   if (on < 0 || on > 2) TMHIP_FAIL("loopback: 0 off, 1 device-to-device copies, 2 one-rank RCCL communicator");
   if (on == 2 && !ctx->comm_ready) {  // one-rank RCCL communicator: faces travel through ncclSend/ncclRecv to self
     TMHIP_CHECK(hipSetDevice(ctx->device));
@@ -698,7 +700,7 @@ int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_
   if (tmhip_event_record(ctx, 14)) return 1;
   for (int j = 0; j < iters; j++) {
     if (tmhip_launch_hopping(ctx, 0, f1->d, f0->d, nullptr, EPI_STORE, 0, 0, HOP_COMM)) return 1;   // benchmark.c:295-296
-    if (tmhip_launch_hopping(ctx, 1, f2->d, f1->d, nullptr, EPI_STORE, 0, 0, HOP_COMM)) return 1;
+    if (tmhip_launch_hopping(ctx, 1, f2->d, f1->d, nullptr, EPI_STORE, 0, 0, HOP_COMM | HOP_CHAINED)) return 1;   // f1 is the previous stencil's output
   }
   if (tmhip_event_record(ctx, 15)) return 1;
   return tmhip_event_elapsed_ms(ctx, 14, 15, ms_total);

@@ -29,6 +29,21 @@ typedef int v4i __attribute__((ext_vector_type(4)));
   template <bool NT> __device__ __forceinline__ void st6(ET *f, size_t stride, int j, int blk, const V2T *s) {                    \
     _Pragma("unroll") for (int c = 0; c < 6; c++) stc<NT>(f + (size_t)(6 * blk + c) * stride + j, s[c]);                          \
   }                                                                                                                               \
+  /* the same six components with agent-scope loads (sc1: served by L2, never by this CU's L1): data another kernel has just      \
+     written while this one was already running (the exchanged faces) without paying an L1 invalidate for the whole CU */          \
+  __device__ __forceinline__ void ld6_fresh(V2T *s, const ET *f, size_t stride, int j, int blk) {                                 \
+    _Pragma("unroll") for (int c = 0; c < 6; c++) {                                                                               \
+      const ET *p = f + (size_t)(6 * blk + c) * stride + j;                                                                       \
+      if constexpr (sizeof(ET) == 16) {                                                                                           \
+        const double *q = reinterpret_cast<const double *>(p);                                                                    \
+        s[c].x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                                \
+        s[c].y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                            \
+      } else {                                                                                                                    \
+        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        __builtin_memcpy(&s[c], &w, 8);                                                                                           \
+      }                                                                                                                           \
+    }                                                                                                                             \
+  }                                                                                                                               \
   constexpr int HOP_STAGE_BYTES = 12 * 64 * (int)sizeof(V2T); /* per wave */                                                      \
   __device__ __forceinline__ void stage_put(unsigned char *region, int lid, const ET *f, size_t ns, int i) {                      \
     V2T *st = reinterpret_cast<V2T *>(region);                                                                                    \
@@ -50,5 +65,5 @@ typedef int v4i __attribute__((ext_vector_type(4)));
   namespace NS {                                                                                                               \
   int launch_hopping(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi, double cre, double cim, int comm, const v2f *cw); \
   int launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv, double cre, double cim, \
-                         int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw);                              \
+                         int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw, int chained);                              \
   }

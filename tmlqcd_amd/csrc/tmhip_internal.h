@@ -105,6 +105,7 @@ struct tmhip_ctx {
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
   unsigned int *sync_flags; unsigned int hop_seq;  // [0] main stream reached stencil n, [1] faces of stencil n received, [2] a bounded wait gave up
   unsigned long long flag_timeout_ticks;           // bound of the device-side flag waits in ticks of the 100 MHz clock (0 = none)
+  const void *prepacked;                           // the field whose boundary-slice projections sit in the send buffers (written by the last exterior kernel), or nullptr
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
   double *deriv;
   double *momenta;     // hamiltonian_field_t::momenta, su3adj [V][4] = double [V][4][8], resident for tmhip_update_gauge (md_update.hip)
@@ -123,6 +124,7 @@ struct tmhip_ctx {
   int opt_stg;                                                          // 1 = LDS-staged stencil (own-block input spinors staged once, y/z neighbours read from LDS)
   int opt_recon;                                                        // 12 = rebuild the third row of every link in registers (opt-in)
   int opt_split_sync;                                                   // 0: the exterior kernel / the pack kernel wait for a flag of the other stream (default); 1: HIP events, no device-side wait
+  int opt_prepack;                                                      // 1 (default): the exterior kernel projects the faces of its output for the next stencil of a chain
   int opt_comm_split;                                                   // 0: do not split off a second communicator (exercises the one-communicator fallback)
   int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot;                      // cg_her
   int opt_swall_order;                                                  // block order of the owner-computes sw_all: 0 one contiguous chunk per XCD, 1 slab order
@@ -150,19 +152,21 @@ static inline bool tmhip_reduce_over_ranks(const tmhip_ctx *ctx) { return ctx->c
 enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4, EPI_CLOVER_INV = 5, EPI_CLOVER_G5 = 6, EPI_CLOVER = 7,
        EPI_TM_SUB_G5_NRM = 8 /* + partials of |out|^2 */, EPI_TM_SUB_G5_RES = 9 /* resid -= alpha out, partials of |resid|^2; out not stored */,
        EPI_CLOVER_G5_NRM = 10, EPI_CLOVER_G5_RES = 11 /* the same two on top of the clover_gamma5 epilogue */ };
-// `comm`: 0 no halo exchange (Hopping_Matrix_nocom), HOP_COMM exchange the faces of `in` first
-enum { HOP_COMM = 1 };
+// `comm`: 0 no halo exchange (Hopping_Matrix_nocom), HOP_COMM exchange the faces of `in` first, HOP_COMM | HOP_CHAINED additionally
+// promises that `in` is the output of this context's previous split-phase stencil and has not been written since (a composition
+// like Qtm_pm_psi, the stencils of a fused CG iteration): its faces were projected by that stencil's exterior kernel already
+enum { HOP_COMM = 1, HOP_CHAINED = 2 };
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
                          double cre, double cim, int comm, const v2d *cw = nullptr);
 // mode 0: partials of <dotv, out>; 1: of |out|^2; 2: resid -= (*scal) * out without storing out, partials of |resid|^2
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
                              double cre, double cim, int *npartials, int mode = 0, v2d *resid = nullptr, const double *scal = nullptr,
-                             const v2d *cw = nullptr);   // cw: clover blocks => clover_gamma5 epilogue (modes 1, 2 only)
+                             const v2d *cw = nullptr, int chained = 0);   // cw: clover blocks => clover_gamma5 epilogue (modes 1, 2 only); chained: HOP_CHAINED
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
                            double cre, double cim, int comm, const v2f *cw = nullptr);
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
                                double cre, double cim, int *npartials, int mode = 0, v2f *resid = nullptr, const double *scal = nullptr,
-                               const v2f *cw = nullptr);
+                               const v2f *cw = nullptr, int chained = 0);
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx);
 int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out);
 // After a host-visible synchronisation of a T-split rank: non-zero (with a message) when a bounded device-side wait for the
