@@ -309,6 +309,8 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "split_sync" 0 (default) | 1: T-split ranks -- 0: the exterior kernel (main stream) and the pack kernel (comm stream) wait on the device for a
  *                flag of the other stream; 1: the two streams are ordered by HIP events, no wait on the device at all (slower: two events on the
  *                main stream per stencil)
+ *   "prepack" 1 (default) | 0: T-split ranks -- the exterior kernel also projects the completed boundary slices of its output into the send buffers, so
+ *                the next stencil of a chain (Qtm_pm_psi, a fused CG iteration) starts its exchange without a pack kernel
  *   "flag_timeout_ms" bound of those device-side waits (default 120 s, or TMLQCD_HIP_FLAG_TIMEOUT_S in the environment; 0 = none): a late
  *                neighbour is waited for, a dead one becomes an error of the next synchronising call (reported once, then cleared)
  *   "comm_split" 1|0 (before tmhip_comm_init / tmhip_comm_set_loopback(2)): 0 keeps the reductions on the face communicator (the fallback of an RCCL without ncclCommSplit)

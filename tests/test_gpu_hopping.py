@@ -74,17 +74,19 @@ def test_fused_epilogues(setup16, ieo):
         f.free()
 
 
-@pytest.mark.parametrize("mode,split_sync", [(1, 0), (2, 0), (1, 1), (2, 1)])
-def test_loopback_split_path_matches(setup16, mode, split_sync):
+@pytest.mark.parametrize("mode,split_sync,prepack", [(1, 0, 1), (2, 0, 1), (1, 1, 1), (2, 1, 1), (1, 0, 0), (2, 1, 0)])
+def test_loopback_split_path_matches(setup16, mode, split_sync, prepack):
     """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self, the stencil over all sites with the hop
     across the cut taken from the received faces -- inside the stencil kernel behind a flag (split_sync 0, default) or by the
-    exterior kernel behind a HIP event (1) -- must equal the plain periodic stencil."""
+    exterior kernel behind a HIP event (1) -- must equal the plain periodic stencil.  prepack 1 (default): the stencils of a chain
+    (Qtm_pm_psi below) take their faces from the previous stencil's exterior kernel instead of a pack kernel."""
     orc, lat = setup16
     N = orc.Vh
     k = random_spinor(31, N)
     ref = orc.new_field()
     dk, dl = lat.field(k), lat.field()
     lat.set_option("split_sync", split_sync)
+    lat.set_option("prepack", prepack)
     lat.set_loopback(mode)  # 1: D2D copies, 2: one-rank RCCL communicator (ncclSend/Recv to self)
     try:
         for rep in range(3):       # repeated calls re-use the face buffers: a stale-cache bug would show here
@@ -114,10 +116,18 @@ def test_loopback_split_path_matches(setup16, mode, split_sync):
         qref = orc.new_field(); orc.op("Qtm_pm_psi", qref, k.copy())
         assert rel_err(q.download(), qref[:N]) < TOL
         q.free()
+        # a chain whose promise would be wrong if the library took it on faith: the field between two stencils is rewritten by another
+        # kernel (the twists of Mtm_plus_sym_dagg_psi) -- those stencils must not be treated as chained
+        for name in ("Mtm_plus_sym_dagg_psi", "Qtm_plus_sym_psi", "Qtm_minus_psi"):
+            dk.upload(k)
+            lat.op(name, dl, dk)
+            orc.op(name, ref, k.copy())
+            assert rel_err(dl.download(), ref[:N]) < TOL, name
         lat.sync()
     finally:
         lat.set_loopback(0)
         lat.set_option("split_sync", 0)
+        lat.set_option("prepack", 1)
     dk.free(); dl.free()
 
 

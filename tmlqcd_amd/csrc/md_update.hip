@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void links_kernel(v2d *__restrict__ raw, const
   for (int e = 0; e < 9; e++) out[e] = src[e];
   v2d *gf = g + ((size_t)p * 72 + (size_t)(2 * mu) * 9) * gs + (ix >> 1);
 #pragma unroll
-  for (int e = 0; e < 9; e++) gf[(size_t)e * gs] = out[e];
+  for (int e = 0; e < 9; e++) __builtin_nontemporal_store(out[e], gf + (size_t)e * gs);   // (written once, read by the next stencil at the earliest)
   int jx;                                                  // x + mu, periodic
   if (mu == 0) {
     if (t + 1 < T) jx = ix + LX * LY * LZ;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void links_kernel(v2d *__restrict__ raw, const
   else jx = (z + 1 < LZ) ? ix + 1 : ix - (LZ - 1);
   v2d *gb = g + ((size_t)(1 - p) * 72 + (size_t)(2 * mu + 1) * 9) * gs + (jx >> 1);
 #pragma unroll
-  for (int e = 0; e < 9; e++) gb[(size_t)e * gs] = out[e];
+  for (int e = 0; e < 9; e++) __builtin_nontemporal_store(out[e], gb + (size_t)e * gs);
   (void)Vh;
 }
 
