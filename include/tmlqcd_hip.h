@@ -315,6 +315,8 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *                neighbour is waited for, a dead one becomes an error of the next synchronising call (reported once, then cleared)
  *   "comm_split" 1|0 (before tmhip_comm_init / tmhip_comm_set_loopback(2)): 0 keeps the reductions on the face communicator (the fallback of an RCCL without ncclCommSplit)
  *   "cg_fused_dot" 2 (default: alpha / residual / norm in the stencil epilogues), 1 scalar product only, 0 plain linalg kernels
+ *   "cg_self" 1 (default) | 0: small unsplit lattices (the hop-split stencil) -- the fused CG iteration adds up its partial sums inside the residual stencil
+ *                (alpha) and the (P, p) kernel (stopping test, beta) instead of two one-block sum + scalar kernels in between
  *   "cg_sync" 1: host-side scalars as in the reference loop;  "cg_batch" n: iterations enqueued between two polls of `done`
  *   "gauge_cache" -1 (automatic) / 0 / 1: the 64-thread stencil launches of small unsplit lattices load the links with (0) or without (1) the
  *                  streaming hint; automatic = without while the gauge copy is <= 200 MB (it then stays in the Infinity Cache between calls)

@@ -23,6 +23,15 @@ struct CgState {
   int x_pending;
 };
 
+// two copies of the state (the self-summing small-lattice iteration reads one and writes the other) and {pro, alpha} of the running iteration
+static int cg_state_alloc(tmhip_ctx *ctx) {
+  if (ctx->cg_state) return 0;
+  TMHIP_CHECK(hipMalloc(&ctx->cg_state, 2 * sizeof(CgState) + 2 * sizeof(double)));
+  TMHIP_CHECK(hipMemsetAsync(ctx->cg_state, 0, 2 * sizeof(CgState) + 2 * sizeof(double), ctx->stream));
+  return 0;
+}
+
+
 __device__ __forceinline__ double cg_wave_reduce(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -128,6 +137,53 @@ __global__ __launch_bounds__(LA_BS) void cg_xp_kernel(V *__restrict__ X, V *__re
       const V pv = p[i];
       if (upd_x) x[i] = x[i] + alpha * pv;
       if (upd_p) p[i] = beta * pv + r[i];
+    }
+  }
+}
+
+// The tail of a fused iteration on SMALL lattices without the sum + scalar kernel in front: every block adds up the partial sums of
+// |r|^2 the residual stencil left (tmhip_block_sum256: the same value in every block), applies the stopping test of cg_her.c:108 and
+// the beta of :121 itself, and does its share of  P += alpha p ; p = beta p + r  (cg_her.c:95,122).  The state is read from `cur` by
+// everybody and written -- complete -- to `nxt` by block 0 only (a block that starts late must not see a half-updated state); the host
+// alternates the two copies.  alpha was left in pa[1] by the residual stencil (HopSelfAlpha).  After convergence nothing changes any more.
+__global__ __launch_bounds__(LA_BS) void cg_xp_self_kernel(v2d *__restrict__ X, v2d *__restrict__ Pd, const v2d *__restrict__ Rr, int ns, int N,
+                                                           const double *__restrict__ partials, int n, const double *__restrict__ pa,
+                                                           const CgState *__restrict__ cur, CgState *__restrict__ nxt, double *hist, int hist_len) {
+  __shared__ double wsum[4];
+  // the fields first (they do not depend on the sum), the partial sums behind them: one memory round trip instead of two
+  const size_t off = (size_t)blockIdx.y * ns;
+  v2d *x = X + off, *p = Pd + off;
+  const v2d *r = Rr + off;
+  const int base = blockIdx.x * LA_BS * LA_UNROLL + threadIdx.x;
+  v2d pv[LA_UNROLL], xv[LA_UNROLL], rv[LA_UNROLL];
+#pragma unroll
+  for (int u = 0; u < LA_UNROLL; u++) {
+    const int i = base + u * LA_BS;
+    if (i < N) { pv[u] = p[i]; xv[u] = x[i]; rv[u] = r[i]; }
+  }
+  const double err = tmhip_block_sum256(partials, n, wsum);
+  const int done = cur->done;
+  const double normsq = cur->normsq, alpha = pa[1];
+  const bool conv = ((err <= cur->eps_sq) && (cur->rel_prec == 0)) || ((err <= cur->eps_sq * cur->squarenorm) && (cur->rel_prec == 1));
+  const double beta = err / normsq;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    CgState s = *cur;
+    if (!done) {
+      s.pro = pa[0]; s.alpha = alpha; s.err = err;
+      s.it += 1;
+      if (hist && s.it - 1 < hist_len) hist[s.it - 1] = err;
+      if (conv) { s.done = 1; s.iters = s.it; }
+      else { s.beta = beta; s.normsq = err; }
+    }
+    *nxt = s;
+  }
+  if (done) return;
+#pragma unroll
+  for (int u = 0; u < LA_UNROLL; u++) {
+    const int i = base + u * LA_BS;
+    if (i < N) {
+      x[i] = xv[u] + alpha * pv[u];
+      if (!conv) p[i] = beta * pv[u] + rv[u];
     }
   }
 }
@@ -320,7 +376,7 @@ static int cg_reduce_update(tmhip_ctx *ctx, int n, CgState *st, double *hist, in
 //   P += alpha p ; p = beta p + r              one pass
 // i.e. cg_her.c:91-126 with 960 B/site of vector traffic next to the four stencils instead of 1728.
 static int cg_enqueue_fused_qtm(tmhip_ctx *ctx, bool fp32, tmhip_field *x, tmhip_field *p, tmhip_field *r, CgState *st, double *hist,
-                                int hist_len, int N, bool clover = false) {
+                                int hist_len, int N, bool clover = false, int self_parity = -1) {
   const double mu = ctx->mu, nrm = 1. / (1. + mu * mu);
   const dim3 g = fp32 ? la_grid32(N) : la_grid(N);
   const size_t gs = ctx->gs;
@@ -353,6 +409,20 @@ static int cg_enqueue_fused_qtm(tmhip_ctx *ctx, bool fp32, tmhip_field *x, tmhip
       if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
       if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_CLOVER_INV, 0, 0, HOP_COMM | HOP_CHAINED, wip)) return 1;
       if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 0, +(mu + ctx->mu3), &n2, 2, r->d, &st->alpha, wo, 1)) return 1;
+    } else if (self_parity >= 0) {
+      // small unsplit lattices (tmhip_hopping_self_alpha_ok): no sum + scalar kernels -- the residual stencil adds up the partials of
+      // |Q_- p|^2 itself (alpha), the (P, p) kernel those of |r|^2 (stopping test, beta); `st` is the pair of state copies
+      double *pa = reinterpret_cast<double *>(st + 2);
+      const CgState *cur = st + self_parity;
+      CgState *nxt = st + (1 - self_parity);
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
+      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 1., -mu, &n1, 1, nullptr, nullptr, nullptr, 1)) return 1;
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, HOP_COMM | HOP_CHAINED)) return 1;
+      const HopSelfAlpha self = {ctx->partials, n1, &cur->normsq, pa};
+      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d, nullptr, nullptr, 1, &self)) return 1;
+      hipLaunchKernelGGL(cg_xp_self_kernel, g, dim3(LA_BS), 0, ctx->stream, x->d, p->d, (const v2d *)r->d, p->ns, N,
+                         (const double *)(ctx->partials + ctx->max_partials / 2), n2, (const double *)pa, cur, nxt, hist, hist_len);
+      return 0;
     } else {
       if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
       if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 1., -mu, &n1, 1, nullptr, nullptr, nullptr, 1)) return 1;
@@ -372,7 +442,7 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
   if (N != ctx->Vh) TMHIP_FAIL("cg_her: N must be VOLUME/2");
   if (ctx->opt_cg_sync) return cg_her_sync(ctx, P, Q, max_iter, eps_sq, rel_prec, N, op, iters, res_hist, hist_len);
   TMHIP_CHECK(hipSetDevice(ctx->device));
-  if (!ctx->cg_state) TMHIP_CHECK(hipMalloc(&ctx->cg_state, sizeof(CgState)));
+  if (cg_state_alloc(ctx)) return 1;
   if (max_iter > ctx->cg_hist_len) {
     if (ctx->cg_hist) TMHIP_CHECK(hipFree(ctx->cg_hist));
     TMHIP_CHECK(hipMalloc((void **)&ctx->cg_hist, sizeof(double) * (size_t)max_iter));
@@ -398,6 +468,10 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
                        (!split || (ctx->face % 256 == 0 && ctx->g.T >= 3));
   const bool fused = fusable && !split && op == TMHIP_OP_QTM_PM;                            // scalar product in the last stencil (cg_fused_dot = 1)
   const bool fused_full = fusable && ctx->opt_cg_fused_dot >= 2 && (op == TMHIP_OP_QTM_PM || op == TMHIP_OP_QSW_PM);
+  // small unsplit lattices: the iteration that adds up its partial sums inside the stencil and the (P, p) kernel (two state copies,
+  // read / written alternately: iteration j reads copy j & 1); "cg_self" 0 keeps the sum + scalar kernels
+  const bool self = fused_full && !split && op == TMHIP_OP_QTM_PM && ctx->opt_cg_self && tmhip_hopping_self_alpha_ok(ctx);
+  if (self) TMHIP_CHECK(hipMemcpyAsync(st + 1, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
   int enq = 0, done = 0;
   int *flag = (int *)(ctx->result_host + 2);
   double *err_host = ctx->result_host + 3;
@@ -409,7 +483,7 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
     for (int b = 0; b < nb; b++) {
       int ndot = nblk;
       if (fused_full) {   // default: everything but the (P, p) update rides in stencil epilogues
-        if (cg_enqueue_fused_qtm(ctx, false, P, sf2, sf1, st, ctx->cg_hist, max_iter, N, op == TMHIP_OP_QSW_PM)) return 1;
+        if (cg_enqueue_fused_qtm(ctx, false, P, sf2, sf1, st, ctx->cg_hist, max_iter, N, op == TMHIP_OP_QSW_PM, self ? ((enq + b) & 1) : -1)) return 1;
         continue;
       }
       if (fused) {
@@ -431,6 +505,7 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
       stmp = sf0; sf0 = sf1; sf1 = stmp;
     }
     enq += nb;
+    if (self) st = (CgState *)ctx->cg_state + (enq & 1);   // the copy the last enqueued iteration wrote
     TMHIP_CHECK(hipGetLastError());
     TMHIP_CHECK(hipMemcpyAsync(flag, &st->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     TMHIP_CHECK(hipMemcpyAsync(err_host, &st->err, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -438,7 +513,9 @@ extern "C" int tmhip_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int 
     done = *flag;
     if (tmhip_check_async_error(ctx)) return 1;   // T-split rank: a halo exchange that never completed must not yield a result
     near = *err_host <= 1.0e3 * target;
+    if (self) st = (CgState *)ctx->cg_state;       // (cg_enqueue_fused_qtm takes the base of the pair)
   }
+  if (self) st = (CgState *)ctx->cg_state + (enq & 1);
   TMHIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   *iters = h.done ? h.iters : -1;
@@ -462,7 +539,7 @@ extern "C" int tmhip_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q
   if (tmhip_prepare_fp32(ctx)) return 1;
   const bool clover = op == TMHIP_OP_QSW_PM;
   if (clover && tmhip_prepare_clover32(ctx)) return 1;
-  if (!ctx->cg_state) TMHIP_CHECK(hipMalloc(&ctx->cg_state, sizeof(CgState)));
+  if (cg_state_alloc(ctx)) return 1;
   CgState *st = (CgState *)ctx->cg_state;
   int N_outer = max_iter / (max_inner_it > 0 ? max_inner_it : 1);
   if (N_outer < 10) N_outer = 10;                                   /* mixed_cg_her.c:83-85 */
@@ -669,7 +746,7 @@ extern "C" int tmhip_rg_mixed_cg_her(tmhip_ctx *ctx, tmhip_field *P, tmhip_field
   if (tmhip_prepare_fp32(ctx)) return 1;
   const bool clover = op == TMHIP_OP_QSW_PM;
   if (clover && tmhip_prepare_clover32(ctx)) return 1;
-  if (!ctx->cg_state) TMHIP_CHECK(hipMalloc(&ctx->cg_state, sizeof(CgState)));
+  if (cg_state_alloc(ctx)) return 1;
   if (!ctx->sf_extra && tmhip_field_alloc(ctx, TMHIP_FIELD_EO, &ctx->sf_extra)) return 1;
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;
   const bool fused = ctx->opt_cg_fused_dot && tmhip_fused_dot32_ok(ctx) && (!split || ctx->opt_cg_fused_dot >= 2);   // the older mode-0 fusion is unsplit only

@@ -145,7 +145,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
-  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1;
+  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1;
   {
     // bound of the device-side waits for the neighbours' faces: TMLQCD_HIP_FLAG_TIMEOUT_S in the environment (0 = none), default 120 s
     double sec = 120.0;
@@ -169,7 +169,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   {
     // fused stencil+reduction: one per wave of the (padded) grid, plus -- on the split path -- one per wave of the exterior kernel
     int need = 4 * ((ctx->ns + 255) / 256 + 8 + 7 * ctx->g.T) + 4 * 128;
-    if (ctx->ns <= 262144 && need < ctx->ns / 16 + 64) need = ctx->ns / 16 + 64;   // hop-split kernel on small lattices: four partials per 64 sites
+    if (ctx->ns <= 262144 && need < 2 * (ctx->ns / 16 + 64)) need = 2 * (ctx->ns / 16 + 64);   // hop-split kernel on small lattices: four partials per 64 sites, twice (the self-summing CG iteration keeps two sets)
     if (ctx->max_partials < need) ctx->max_partials = need;
   }
   TMHIP_CHECK(hipMalloc((void **)&ctx->partials, ctx->max_partials * sizeof(double)));
@@ -296,6 +296,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "hopsplit")) { if (value < -1 || value > 1) TMHIP_FAIL("hopsplit must be -1 (automatic), 0 or 1"); ctx->opt_hopsplit = value; }
   else if (!strcmp(name, "lds32")) { if (value < 0 || value > 1) TMHIP_FAIL("lds32 must be 0 or 1"); ctx->opt_stg32 = value; }
   else if (!strcmp(name, "lds")) { if (value < 0 || value > 1) TMHIP_FAIL("lds must be 0 (gather kernel) or 1 (per-wave LDS staging of the own-site spinors)"); ctx->opt_stg = value; }
+  else if (!strcmp(name, "cg_self")) ctx->opt_cg_self = value != 0;
   else if (!strcmp(name, "cg_sync")) ctx->opt_cg_sync = value;
   else if (!strcmp(name, "cg_batch")) ctx->opt_cg_batch = value > 0 ? value : 1;
   else TMHIP_FAIL("unknown option %s", name);

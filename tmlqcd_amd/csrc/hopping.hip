@@ -42,8 +42,8 @@ int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const
   return hop64::launch_hopping(ctx, ieo, out, in, p, epi, cre, cim, comm, cw);
 }
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
-                             double cre, double cim, int *npartials, int mode, v2d *resid, const double *scal, const v2d *cw, int chained) {
-  return hop64::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
+                             double cre, double cim, int *npartials, int mode, v2d *resid, const double *scal, const v2d *cw, int chained, const HopSelfAlpha *self) {
+  return hop64::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained, self);
 }
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
                            double cre, double cim, int comm, const v2f *cw) {
@@ -52,6 +52,9 @@ int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, con
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
                                double cre, double cim, int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw, int chained) {
   return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
+}
+bool tmhip_hopping_self_alpha_ok(const tmhip_ctx *ctx) {
+  return hop64::use_split4(ctx) && ctx->opt_recon != 12 && ctx->Vh % 64 == 0 && ctx->Vh / 64 <= ctx->max_partials / 2;
 }
 bool tmhip_fused_dot32_ok(const tmhip_ctx *ctx) {
   const bool split = ctx->g.nproc_t > 1 || ctx->loopback;

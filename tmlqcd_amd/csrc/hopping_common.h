@@ -65,5 +65,5 @@ typedef int v4i __attribute__((ext_vector_type(4)));
   namespace NS {                                                                                                               \
   int launch_hopping(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi, double cre, double cim, int comm, const v2f *cw); \
   int launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv, double cre, double cim, \
-                         int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw, int chained);                              \
+                         int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw, int chained, const HopSelfAlpha *self = nullptr);                              \
   }

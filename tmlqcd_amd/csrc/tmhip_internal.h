@@ -126,7 +126,7 @@ struct tmhip_ctx {
   int opt_split_sync;                                                   // 0: the exterior kernel / the pack kernel wait for a flag of the other stream (default); 1: HIP events, no device-side wait
   int opt_prepack;                                                      // 1 (default): the exterior kernel projects the faces of its output for the next stencil of a chain
   int opt_comm_split;                                                   // 0: do not split off a second communicator (exercises the one-communicator fallback)
-  int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot;                      // cg_her
+  int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot, opt_cg_self;         // cg_her
   int opt_swall_order;                                                  // block order of the owner-computes sw_all: 0 one contiguous chunk per XCD, 1 slab order
   double gauge_recon_dev;   // max |U_row2 - conj(row0 x row1)| over all links of the resident gauge field (-1: not measured)
 };
@@ -158,10 +158,27 @@ enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_T
 enum { HOP_COMM = 1, HOP_CHAINED = 2 };
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
                          double cre, double cim, int comm, const v2d *cw = nullptr);
+// Small unsplit lattices (the hop-split kernel): mode 2 can compute its coefficient itself -- EVERY block adds up the `n` per-wave partial
+// sums the previous reducing stencil left in `partials` (fixed order: the same value in every block, bitwise reproducible) and uses
+// alpha = *normsq / sum; block 0 leaves sum and alpha in out2[0..1].  No sum + scalar kernel between the two stencils
+// (a ~4.7 us floor each at any size: the difference between 14.8k and 17k CG iterations per second at 16^4).
+struct HopSelfAlpha { const double *partials; int n; const double *normsq; double *out2; };
+bool tmhip_hopping_self_alpha_ok(const tmhip_ctx *ctx);   // the launch below would take the hop-split kernel
+// fixed-order sum of n doubles by a 256-thread block (every thread returns the total); wsum: 4 doubles of shared memory.  Shared by
+// the stencil above and cg_xp_self_kernel (cg.hip): both must add in exactly the same order.
+__device__ __forceinline__ double tmhip_block_sum256(const double *__restrict__ v, int n, double *wsum) {
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) acc += v[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  return (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
 // mode 0: partials of <dotv, out>; 1: of |out|^2; 2: resid -= (*scal) * out without storing out, partials of |resid|^2
 int tmhip_launch_hopping_dot(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, const v2d *dotv,
                              double cre, double cim, int *npartials, int mode = 0, v2d *resid = nullptr, const double *scal = nullptr,
-                             const v2d *cw = nullptr, int chained = 0);   // cw: clover blocks => clover_gamma5 epilogue (modes 1, 2 only); chained: HOP_CHAINED
+                             const v2d *cw = nullptr, int chained = 0, const HopSelfAlpha *self = nullptr);   // cw: clover blocks => clover_gamma5 epilogue (modes 1, 2 only); chained: HOP_CHAINED
 int tmhip_launch_hopping32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, int epi,
                            double cre, double cim, int comm, const v2f *cw = nullptr);
 int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in, const v2f *p, const v2f *dotv,
