@@ -13,6 +13,7 @@ from tests.util import TOL, random_gauge, random_spinor, rel_err
 pytestmark = pytest.mark.gpu
 VP = C.c_void_p
 LAZY, RESIDENT, COHERENT = 2, 1, 0
+_LAZY_BLOCKS = 0
 
 
 def _p(a):
@@ -46,7 +47,23 @@ def prog(host_stub):
     # init_spinor_field.c:48: one calloc for all fields, base aligned to ALIGN_BASE (32 bytes) only
     N = V // 2
     nf = 5
-    block = np.zeros(nf * N * 192 + 4096 + 64, dtype=np.uint8)
+    # The block lives in a mapping of its own at an address range nothing in this process has used before: a range that once held an
+    # array the HIP runtime copied from / to directly (the big pageable numpy arrays of the full-size tests that run earlier in the
+    # same process) stays registered with the driver after it has been freed, and every mprotect on a reused part of it then goes
+    # through the driver's MMU notifier -- 28 ms per call instead of microseconds.  A tmLQCD process allocates its
+    # spinor fields once and, in lazy mode, never lets the runtime touch them: that is the situation this fixture reproduces.
+    import os
+    libc = C.CDLL(None, use_errno=True)
+    libc.mmap.restype = C.c_void_p
+    libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
+    libc.munmap.argtypes = [C.c_void_p, C.c_size_t]
+    nbytes = (nf * N * 192 + 4096 + 64 + 4095) // 4096 * 4096
+    global _LAZY_BLOCKS
+    hint = 0x6a0000000000 + (os.getpid() % 4096) * (1 << 32) + _LAZY_BLOCKS * (1 << 30)
+    _LAZY_BLOCKS += 1
+    addr = libc.mmap(hint, nbytes, 3, 0x22, -1, 0)            # PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS (zero-filled)
+    assert addr not in (None, C.c_void_p(-1).value), "mmap failed"
+    block = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(addr))
     base = (block.ctypes.data + 31) // 32 * 32 + 32           # 32-byte aligned, NOT page aligned
     off = base - block.ctypes.data
     fields = [np.frombuffer(block, dtype=np.float64, count=N * 24, offset=off + i * N * 192).reshape(N, 4, 3, 2) for i in range(nf)]
@@ -54,6 +71,8 @@ def prog(host_stub):
     yield stub, d, orc, fields, (T, L, V, N), block
     d.tmlqcd_hip_set_residency(COHERENT)
     d.tmlqcd_hip_finalize()
+    del fields, block
+    libc.munmap(addr, nbytes)
 
 
 def test_unmodified_benchmark_loop_runs_resident_and_stays_correct(prog):
