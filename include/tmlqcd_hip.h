@@ -309,6 +309,9 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "split_sync" 0 (default) | 1: T-split ranks -- 0: the exterior kernel (main stream) and the pack kernel (comm stream) wait on the device for a
  *                flag of the other stream; 1: the two streams are ordered by HIP events, no wait on the device at all (slower: two events on the
  *                main stream per stencil)
+ *   "split_early" 0 (default) | 1: T-split ranks -- the boundary time-slices are dispatched last and take the hop across the cut inside the stencil kernel
+ *                when the faces have already arrived (one look at the flag, never a wait); what came too early is left to the exterior kernel.
+ *                +3-4 % with a copy-engine-like exchange, neutral to -1 % behind RCCL's kernels, which start late (profiles/r03_split_early_ab.log)
  *   "prepack" 1 (default) | 0: T-split ranks -- the exterior kernel also projects the completed boundary slices of its output into the send buffers, so
  *                the next stencil of a chain (Qtm_pm_psi, a fused CG iteration) starts its exchange without a pack kernel
  *   "flag_timeout_ms" bound of those device-side waits (default 120 s, or TMLQCD_HIP_FLAG_TIMEOUT_S in the environment; 0 = none): a late

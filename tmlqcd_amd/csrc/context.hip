@@ -145,7 +145,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
-  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1;
+  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_split_early = 0;
   {
     // bound of the device-side waits for the neighbours' faces: TMLQCD_HIP_FLAG_TIMEOUT_S in the environment (0 = none), default 120 s
     double sec = 120.0;
@@ -182,6 +182,8 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   TMHIP_CHECK(hipMalloc((void **)&ctx->recv_up, 2 * fb));
   ctx->send_up = ctx->send_dn + (size_t)6 * ctx->face;
   ctx->recv_dn = ctx->recv_up + (size_t)6 * ctx->face;
+  TMHIP_CHECK(hipMalloc((void **)&ctx->bmark, (size_t)(2 * (ctx->face / 64) + 2) * sizeof(int)));
+  TMHIP_CHECK(hipMemsetAsync(ctx->bmark, 0, (size_t)(2 * (ctx->face / 64) + 2) * sizeof(int), ctx->stream));
   TMHIP_CHECK(hipMalloc((void **)&ctx->sync_flags, 64));
   TMHIP_CHECK(hipMemsetAsync(ctx->sync_flags, 0, 64, ctx->stream));
   TMHIP_CHECK(hipMemsetAsync(ctx->recv_up, 0, 2 * fb, ctx->stream));
@@ -225,6 +227,7 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
   (void)hipFree(ctx->sync_flags);
+  if (ctx->bmark) (void)hipFree(ctx->bmark);
   (void)hipFree(ctx->send_dn); (void)hipFree(ctx->recv_up);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->cg_state) (void)hipFree(ctx->cg_state);
@@ -282,6 +285,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "tgrp")) { if (value < 0 || value > ctx->g.T) TMHIP_FAIL("tgrp must be in [0, T]"); ctx->opt_tgrp = value; }
   else if (!strcmp(name, "split_sync")) { if (value < 0 || value > 1) TMHIP_FAIL("split_sync must be 0 (boundary hop in the stencil kernel, behind a flag) or 1 (HIP events + exterior kernel)"); ctx->opt_split_sync = value; }
   else if (!strcmp(name, "flag_timeout_ms")) { if (value < 0) TMHIP_FAIL("flag_timeout_ms must be >= 0 (0 = wait without bound)"); ctx->flag_timeout_ticks = (unsigned long long)value * 100000ull; }
+  else if (!strcmp(name, "split_early")) { ctx->opt_split_early = value != 0; ctx->prepacked = nullptr; }
   else if (!strcmp(name, "prepack")) { ctx->opt_prepack = value != 0; ctx->prepacked = nullptr; }
   else if (!strcmp(name, "comm_split")) { if (ctx->comm_ready) TMHIP_FAIL("comm_split must be set before the communicator is created"); ctx->opt_comm_split = value != 0; }
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;

@@ -105,6 +105,7 @@ struct tmhip_ctx {
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
   unsigned int *sync_flags; unsigned int hop_seq;  // [0] main stream reached stencil n, [1] faces of stencil n received, [2] a bounded wait gave up
   unsigned long long flag_timeout_ticks;           // bound of the device-side flag waits in ticks of the 100 MHz clock (0 = none)
+  int *bmark;                                      // per 64 face sites: 1 = the stencil kernel took the hop across the cut itself ("split_early"), 0 = left to the exterior kernel
   const void *prepacked;                           // the field whose boundary-slice projections sit in the send buffers (written by the last exterior kernel), or nullptr
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
   double *deriv;
@@ -124,6 +125,7 @@ struct tmhip_ctx {
   int opt_stg;                                                          // 1 = LDS-staged stencil (own-block input spinors staged once, y/z neighbours read from LDS)
   int opt_recon;                                                        // 12 = rebuild the third row of every link in registers (opt-in)
   int opt_split_sync;                                                   // 0: the exterior kernel / the pack kernel wait for a flag of the other stream (default); 1: HIP events, no device-side wait
+  int opt_split_early;                                                  // 1: boundary slices last, hop across the cut in the stencil kernel when the faces are already there
   int opt_prepack;                                                      // 1 (default): the exterior kernel projects the faces of its output for the next stencil of a chain
   int opt_comm_split;                                                   // 0: do not split off a second communicator (exercises the one-communicator fallback)
   int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot, opt_cg_self;         // cg_her
