@@ -69,8 +69,10 @@ void tmhip_field_free(tmhip_ctx *ctx, tmhip_field *f);
  * geometry_eo.c:869-885.  FULL fields: nsites = V, lexicographic order. */
 int tmhip_field_upload(tmhip_ctx *ctx, tmhip_field *f, const void *host_spinors, int nsites);
 int tmhip_field_download(tmhip_ctx *ctx, tmhip_field *f, void *host_spinors, int nsites);
-/* sites [first, first + count) of a one-parity fp64 field -> host_spinors[0 .. count) (page-wise synchronisation of the drop-in's lazy mode) */
-int tmhip_field_download_range(tmhip_ctx *ctx, tmhip_field *f, void *host_spinors, int first, int count);
+/* sites [first, first + count) of an fp64 field -> pinned_spinors[0 .. count), which must be page-locked memory (tmhip_pinned_alloc):
+ * the kernel writes there directly and no staging buffer of the context is used, so this transfer alone may be issued from a second
+ * host thread while another call is in progress (the fault handler of the drop-in's lazy mode).  FULL fields: first = 0, count = V. */
+int tmhip_field_download_range(tmhip_ctx *ctx, tmhip_field *f, void *pinned_spinors, int first, int count);
 /* page-locked host buffers (hipHostMalloc): staging for callers that keep the runtime away from their own pages */
 int tmhip_pinned_alloc(unsigned long bytes, void **out);
 int tmhip_pinned_free(void *p);

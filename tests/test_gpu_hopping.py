@@ -74,8 +74,8 @@ def test_fused_epilogues(setup16, ieo):
         f.free()
 
 
-@pytest.mark.parametrize("mode,split_sync,prepack", [(1, 0, 1), (2, 0, 1), (1, 1, 1), (2, 1, 1), (1, 0, 0), (2, 1, 0)])
-def test_loopback_split_path_matches(setup16, mode, split_sync, prepack):
+@pytest.mark.parametrize("mode,split_sync,prepack,early", [(1, 0, 1, 0), (2, 0, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (1, 0, 0, 0), (2, 1, 0, 0), (1, 0, 1, 1), (2, 0, 1, 1)])
+def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, early):
     """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self, the stencil over all sites with the hop
     across the cut taken from the received faces -- inside the stencil kernel behind a flag (split_sync 0, default) or by the
     exterior kernel behind a HIP event (1) -- must equal the plain periodic stencil.  prepack 1 (default): the stencils of a chain
@@ -87,6 +87,7 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack):
     dk, dl = lat.field(k), lat.field()
     lat.set_option("split_sync", split_sync)
     lat.set_option("prepack", prepack)
+    lat.set_option("split_early", early)   # boundary slices last; they take the hop across the cut themselves if the faces are already there
     lat.set_loopback(mode)  # 1: D2D copies, 2: one-rank RCCL communicator (ncclSend/Recv to self)
     try:
         for rep in range(3):       # repeated calls re-use the face buffers: a stale-cache bug would show here
@@ -128,6 +129,7 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack):
         lat.set_loopback(0)
         lat.set_option("split_sync", 0)
         lat.set_option("prepack", 1)
+        lat.set_option("split_early", 0)
     dk.free(); dl.free()
 
 

@@ -427,15 +427,24 @@ __global__ __launch_bounds__(256) void soa_to_aos_range_kernel(const v2d *__rest
   const int site = tid / 12, c = tid % 12;
   aos[tid] = soa[(size_t)c * ns + first + site];
 }
+/* Writes straight into PAGE-LOCKED host memory (tmhip_pinned_alloc): no staging buffer of the context is involved, so this is the
+ * one transfer that may run on a thread other than the one driving the context -- the drop-in's fault handler serves host threads
+ * while the master thread is inside another call.  EO fields: sites [first, first + count); FULL fields: all of it (first = 0). */
 int tmhip_field_download_range(tmhip_ctx *ctx, tmhip_field *f, void *host, int first, int count) {
-  if (!f || !host || f->kind != TMHIP_FIELD_EO || f->prec != 0) TMHIP_FAIL("tmhip_field_download_range: needs a one-parity fp64 field and a host buffer");
-  if (first < 0 || count <= 0 || first + count > ctx->Vh) TMHIP_FAIL("tmhip_field_download_range: sites [%d, %d) outside [0, %d)", first, first + count, ctx->Vh);
+  if (!f || !host || f->prec != 0) TMHIP_FAIL("tmhip_field_download_range: needs an fp64 field and a page-locked host buffer");
+  const int maxn = f->kind == TMHIP_FIELD_FULL ? ctx->V : ctx->Vh;
+  if (first < 0 || count <= 0 || first + count > maxn) TMHIP_FAIL("tmhip_field_download_range: sites [%d, %d) outside [0, %d)", first, first + count, maxn);
+  if (f->kind == TMHIP_FIELD_FULL && (first != 0 || count != ctx->V)) TMHIP_FAIL("tmhip_field_download_range: FULL fields are taken whole");
   TMHIP_CHECK(hipSetDevice(ctx->device));
-  const size_t bytes = (size_t)count * 12 * sizeof(v2d);
-  if (tmhip_stage_reserve(ctx, bytes)) return 1;
-  hipLaunchKernelGGL(soa_to_aos_range_kernel, dim3((12 * count + 255) / 256), dim3(256), 0, ctx->stream, (const v2d *)f->d, (v2d *)ctx->stage, f->ns, first, count);
+  void *dst = nullptr;
+  if (hipHostGetDevicePointer(&dst, host, 0) != hipSuccess || !dst) { (void)hipGetLastError(); TMHIP_FAIL("tmhip_field_download_range: the host buffer is not page-locked memory of this process"); }
+  const int nb = (int)((12L * count + 255) / 256);
+  if (f->kind == TMHIP_FIELD_EO)
+    hipLaunchKernelGGL(soa_to_aos_range_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const v2d *)f->d, (v2d *)dst, f->ns, first, count);
+  else
+    hipLaunchKernelGGL(lexic_eo_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, (v2d *)dst, f->d, f->ns, ctx->V,
+                       ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.proc_t * ctx->g.T);
   TMHIP_CHECK(hipGetLastError());
-  TMHIP_CHECK(hipMemcpyAsync(host, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   return 0;
 }

@@ -86,25 +86,25 @@ bool g_momenta_resident = false;  // the momenta live on the device (tmlqcd_hip_
 bool g_clover_uploaded = false;
 tmhip_field *g_full_tmp = nullptr; // FULL-lattice scratch of Q_pm_psi / D_dagg_psi (tm_operators.c:380-397)
 
-// ONE lock for the registry: taken around every structural change of g_reg (insert, erase, rehash) by the entry points and for
-// the whole body of the SIGSEGV handler of the lazy mode, which walks the map -- a host thread faulting on a stale field while the
-// master thread is inside a drop-in call must never see a rehash in progress.  Recursive per thread (mirror() -> evict; a fault of
-// the thread that holds it, e.g. in the memcpy of an upload, is served in place: no structural change is in progress then).
-// A spin lock: pthread mutexes are not async-signal-safe.
-std::atomic<int> g_reg_lock(0);
-pthread_t g_reg_owner;
-volatile int g_reg_depth = 0;
+// ONE lock for the registry: taken around every change of g_reg or of a mirror's state by the entry points and for the whole body of
+// the SIGSEGV handler of the lazy mode, which walks the map -- a host thread faulting on a stale field while the master thread is
+// inside a drop-in call must never see a rehash in progress.  Recursive per thread (mirror() -> evict; a fault of the thread that
+// holds it, e.g. in the memcpy of an upload, is served in place: no structural change is in progress then).  A spin lock: pthread
+// mutexes are not async-signal-safe.  The owner's thread id IS the lock word (0: free): "do I hold it already" is then one atomic
+// load that only the asking thread itself can have made true -- an owner id kept next to a separate flag can be read stale by a
+// thread that held the lock before, which then walks in beside the new owner.
+std::atomic<uintptr_t> g_reg_owner(0);
+int g_reg_depth = 0;                              // touched by the owner only
 struct RegLock {
   RegLock() {
-    if (g_reg_depth > 0 && pthread_equal(g_reg_owner, pthread_self())) { g_reg_depth = g_reg_depth + 1; return; }
-    int expected = 0;
-    while (!g_reg_lock.compare_exchange_weak(expected, 1, std::memory_order_acquire)) expected = 0;
-    g_reg_owner = pthread_self();
+    const uintptr_t me = (uintptr_t)pthread_self();
+    if (g_reg_owner.load(std::memory_order_relaxed) == me) { g_reg_depth++; return; }
+    uintptr_t expected = 0;
+    while (!g_reg_owner.compare_exchange_weak(expected, me, std::memory_order_acquire)) { expected = 0; __builtin_ia32_pause(); }
     g_reg_depth = 1;
   }
   ~RegLock() {
-    g_reg_depth = g_reg_depth - 1;
-    if (g_reg_depth == 0) g_reg_lock.store(0, std::memory_order_release);
+    if (--g_reg_depth == 0) g_reg_owner.store(0, std::memory_order_release);
   }
 };
 
@@ -172,9 +172,8 @@ tmhip_ctx *refresh(bool need_gauge) {
 uintptr_t g_page = 4096;
 struct sigaction g_old_segv;
 bool g_handler_installed = false;
-volatile int g_in_handler = 0;
-pthread_t g_handler_thread;                       // valid while g_in_handler: the thread the SIGSEGV handler is running on
-inline bool in_handler_here() { return g_in_handler && pthread_equal(g_handler_thread, pthread_self()); }
+std::atomic<uintptr_t> g_handler_thread(0);       // the thread the SIGSEGV handler is running on (0: none) -- one word, see RegLock
+inline bool in_handler_here() { return g_handler_thread.load(std::memory_order_relaxed) == (uintptr_t)pthread_self(); }
 unsigned long g_lazy_stats[4] = {0, 0, 0, 0};   // faults served, pages fetched one by one, whole-field fetches, stores noticed (tmlqcd_hip_lazy_stats)
 
 inline uintptr_t span_lo(const void *h) { return (uintptr_t)h & ~(g_page - 1); }
@@ -279,20 +278,83 @@ void upload(tmhip_ctx *c, const void *host_user, Mirror &m) {
   CK(tmhip_field_upload(c, tmhip_field_even(m.f), host, pt.cnt[0]));
   if (pt.n > 1) CK(tmhip_field_upload(c, tmhip_field_odd(m.f), (const spinor *)host + VOLUME / 2, pt.cnt[1]));
 }
+// Other host threads may be reading the very field that is being brought up to date (an OpenMP loop over it: one thread's fault
+// triggers the fetch, the others read on).  A page must therefore never be readable before its new contents are in place: opening
+// the span, then copying, lets those threads read the old data for as long as the copy takes.  The new contents are assembled in a
+// private mapping nobody else knows and moved over the program's pages with mremap(MREMAP_FIXED), which swaps the pages in one step:
+// a reader sees a closed page (faults, waits for the lock, runs again) or the new one.  A page the field shares with other data is
+// first taken out with MREMAP_DONTUNMAP (its address stays mapped, closed and empty), completed in private and moved back.
+// [host, host + bytes) lies in the pages [lo, hi); src holds its new contents; the caller has already recorded the mirror's new
+// state, so page_need() gives the protection every page ends up with.  false: this memory cannot be moved (not private anonymous
+// memory, or a kernel before 5.7) and nothing was changed -- the caller falls back to open-then-copy.
+bool g_install_ok = true;
+bool take_page(uintptr_t page, char *to) {
+  if (mprotect((void *)page, g_page, PROT_NONE)) return false;
+  if (mremap((void *)page, g_page, g_page, MREMAP_MAYMOVE | MREMAP_FIXED | MREMAP_DONTUNMAP, to) != (void *)to) return false;
+  return mprotect(to, g_page, PROT_READ | PROT_WRITE) == 0;
+}
+bool move_over(char *from, uintptr_t to, size_t len) {
+  if (mprotect(from, len, prot_flags(page_need(to, g_reg)))) return false;
+  return mremap(from, len, len, MREMAP_MAYMOVE | MREMAP_FIXED, (void *)to) == (void *)to;
+}
+bool install_pages(uintptr_t host, size_t bytes, uintptr_t lo, uintptr_t hi, const char *src) {
+  if (!g_install_ok) return false;
+  const size_t len = hi - lo;
+  char *sc = (char *)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (sc == MAP_FAILED) return false;
+  const uintptr_t last = hi - g_page;
+  const bool head = host > lo, tail = host + bytes < hi && (last != lo || !head);
+  bool took_head = false;
+  if (head) {
+    if (!take_page(lo, sc)) { g_install_ok = false; munmap(sc, len); return false; }
+    took_head = true;
+  }
+  if (tail && !take_page(last, sc + (last - lo))) {
+    g_install_ok = false;
+    if (took_head) { mprotect(sc, g_page, PROT_NONE); mremap(sc, g_page, g_page, MREMAP_MAYMOVE | MREMAP_FIXED, (void *)lo); munmap(sc + g_page, len - g_page); }
+    else munmap(sc, len);
+    return false;
+  }
+  memcpy(sc + (host - lo), src, bytes);
+  // up to three pieces (the two shared pages are mappings of their own by now); each move is one step for every other thread
+  bool ok = true;
+  uintptr_t a = lo, b = hi;
+  if (head) { ok = move_over(sc, lo, g_page) && ok; a = lo + g_page; }
+  if (tail) { ok = move_over(sc + (last - lo), last, g_page) && ok; b = last; }
+  if (a < b) ok = move_over(sc + (a - lo), a, b - a) && ok;
+  if (!ok) die("lazy mode: mremap failed half-way while bringing a host array up to date");
+  return true;
+}
+
 void download(tmhip_ctx *c, const void *host_user, Mirror &m) {
-  if (m.prot != P_RW) mprotect((void *)span_lo(host_user), span_hi(host_user, m.bytes) - span_lo(host_user), PROT_READ | PROT_WRITE);   // lazy mode: the copy below stores to these pages
-  const bool staged = g_mode == TMLQCD_HIP_LAZY || m.prot != P_RW;
+  const bool watched = m.prot != P_RW;                                  // lazy mode: the span is (partly) closed
+  const bool staged = g_mode == TMLQCD_HIP_LAZY || watched;
   const void *host = staged ? bounce(m.bytes) : host_user;
-  if (m.kind != KIND_LIN) {
+  const Parts pt = parts_of(m.kind == KIND_LIN ? KIND_LIN : TMHIP_FIELD_EO, m.n);
+  if (staged) {
+    // straight into the page-locked bounce buffer: nothing of the context's own staging is touched, so the fault handler can do this
+    // on a host thread while the master thread is inside another call
+    if (m.kind != KIND_LIN) {
+      CK(tmhip_field_download_range(c, m.f, const_cast<void *>(host), 0, nsites(m.kind)));
+    } else {
+      CK(tmhip_field_download_range(c, tmhip_field_even(m.f), const_cast<void *>(host), 0, pt.cnt[0]));
+      if (pt.n > 1) CK(tmhip_field_download_range(c, tmhip_field_odd(m.f), (spinor *)const_cast<void *>(host) + VOLUME / 2, 0, pt.cnt[1]));
+    }
+  } else if (m.kind != KIND_LIN) {
     CK(tmhip_field_download(c, m.f, const_cast<void *>(host), nsites(m.kind)));
   } else {
-    const Parts pt = parts_of(KIND_LIN, m.n);
     CK(tmhip_field_download(c, tmhip_field_even(m.f), const_cast<void *>(host), pt.cnt[0]));
     if (pt.n > 1) CK(tmhip_field_download(c, tmhip_field_odd(m.f), (spinor *)const_cast<void *>(host) + VOLUME / 2, pt.cnt[1]));
   }
-  if (staged) memcpy(const_cast<void *>(host_user), host, m.bytes);
   m.host_valid = true;
-  if (m.prot != P_RW) { m.prot = -1; set_prot(host_user, m, g_mode == TMLQCD_HIP_LAZY ? P_RO : P_RW, g_reg); }   // both copies current: watch for host stores
+  if (!watched) { if (staged) memcpy(const_cast<void *>(host_user), host, m.bytes); return; }
+  m.prot = g_mode == TMLQCD_HIP_LAZY ? P_RO : P_RW;                     // both copies current: watch for host stores
+  m.page_ok.clear(); m.faults = 0;
+  const uintptr_t lo = span_lo(host_user), hi = span_hi(host_user, m.bytes);
+  if (install_pages((uintptr_t)host_user, m.bytes, lo, hi, (const char *)host)) return;
+  mprotect((void *)lo, hi - lo, PROT_READ | PROT_WRITE);                // (memory that cannot be moved: open, copy, close)
+  memcpy(const_cast<void *>(host_user), host, m.bytes);
+  apply_prot(host_user, m, g_reg);
 }
 // the host array of a mirror is gone (freed and not handed out again: mincore says ENOMEM for an unmapped page): nothing to bring up to date
 bool host_unmapped(const void *host, const Mirror &m) {
@@ -301,9 +363,12 @@ bool host_unmapped(const void *host, const Mirror &m) {
   const uintptr_t pg = span_lo((const char *)host + m.bytes / 2);
   return mincore((void *)pg, g_page, &vec) != 0 && errno == ENOMEM;
 }
+bool mapping_replaced(const void *host, const Mirror &m);
 // a mirror is about to go away (or to stop being watched): bring the host up to date and give it its pages back
 void release_host(tmhip_ctx *c, const void *host, Mirror &m) {
-  if (g_mode == TMLQCD_HIP_LAZY && m.prot != P_RW && host_unmapped(host, m)) {   // freed by the program: there is no host copy to bring up to date
+  // freed by the program (and possibly mapped again for something else, which a download would overwrite): there is no host copy
+  // to bring up to date
+  if (g_mode == TMLQCD_HIP_LAZY && m.prot != P_RW && (host_unmapped(host, m) || mapping_replaced(host, m))) {
     m.prot = P_RW; m.page_ok.clear(); m.dev_valid = false; m.host_valid = true;
     return;
   }
@@ -400,6 +465,7 @@ Mirror &mirror(tmhip_ctx *c, const void *host, int kind, int n = 0) {
 }
 
 tmhip_field *in(tmhip_ctx *c, const void *host, int kind, int n = 0) {
+  RegLock lk;   // a mirror's state changes under the lock too: the fault handler reads it on other threads
   Mirror &m = mirror(c, host, kind, n);
   if (g_mode == TMLQCD_HIP_COHERENT || !m.dev_valid) {
     if (!(m.dev_valid && !m.host_valid))   // never overwrite newer device data with a stale host copy
@@ -413,6 +479,7 @@ tmhip_field *in(tmhip_ctx *c, const void *host, int kind, int n = 0) {
 tmhip_field *out(tmhip_ctx *c, const void *host, int kind, int n = 0) { return mirror(c, host, kind, n).f; }
 
 void done(tmhip_ctx *c, const void *host) {
+  RegLock lk;
   Mirror &m = g_reg[host];
   m.dev_valid = true; m.host_valid = false;
   if (g_mode == TMLQCD_HIP_COHERENT) {
@@ -433,8 +500,7 @@ void lazy_fault(int sig, siginfo_t *si, void *uctx) {
   const bool nested = in_handler_here();
   if (g_ctx && si->si_code == SEGV_ACCERR && !nested) {
     RegLock lk;
-    g_handler_thread = pthread_self();
-    g_in_handler = 1;
+    g_handler_thread.store((uintptr_t)pthread_self(), std::memory_order_relaxed);
     const bool store = (((ucontext_t *)uctx)->uc_mcontext.gregs[REG_ERR] & 2) != 0;
     for (auto &kv : g_reg) {
       Mirror &m = kv.second;
@@ -459,15 +525,18 @@ void lazy_fault(int sig, siginfo_t *si, void *uctx) {
           static void *tmp = nullptr;                 // page-locked: see bounce()
           if (!tmp) CK(tmhip_pinned_alloc(64 * sizeof(spinor), &tmp));
           if (tmhip_field_download_range(g_ctx, m.f, tmp, s0, s1 - s0)) die("lazy synchronisation of a page failed");
-          mprotect((void *)page, g_page, PROT_READ | PROT_WRITE);
-          memcpy((void *)lo, (const char *)tmp + (lo - (base + (size_t)s0 * sizeof(spinor))), hi - lo);
           m.page_ok[idx] = 1;
+          const char *from = (const char *)tmp + (lo - (base + (size_t)s0 * sizeof(spinor)));
+          if (!install_pages(lo, hi - lo, page, page + g_page, from)) {
+            mprotect((void *)page, g_page, PROT_READ | PROT_WRITE);
+            memcpy((void *)lo, from, hi - lo);
+          }
           g_lazy_stats[1]++;
         }
       }
     }
     if (ours) { g_lazy_stats[0]++; mprotect((void *)page, g_page, prot_flags(page_need(page, g_reg))); }
-    g_in_handler = 0;
+    g_handler_thread.store(0, std::memory_order_relaxed);
   }
   if (ours) return;                                  // the faulting instruction runs again
   if (g_old_segv.sa_flags & SA_SIGINFO) { if (g_old_segv.sa_sigaction) { g_old_segv.sa_sigaction(sig, si, uctx); return; } }
@@ -507,6 +576,7 @@ void tmlqcd_hip_set_device(int device) { g_device = device; }
 void tmlqcd_hip_lazy_stats(unsigned long out[4]) { for (int k = 0; k < 4; k++) out[k] = g_lazy_stats[k]; }
 void tmlqcd_hip_set_residency(int mode) {
   if (mode != TMLQCD_HIP_COHERENT && mode != TMLQCD_HIP_RESIDENT && mode != TMLQCD_HIP_LAZY) die("tmlqcd_hip_set_residency: unknown mode");
+  RegLock lk;
   if (mode == TMLQCD_HIP_COHERENT && g_mode == TMLQCD_HIP_RESIDENT) tmlqcd_hip_sync_all_to_host();
   if (g_mode == TMLQCD_HIP_LAZY && mode != TMLQCD_HIP_LAZY)        // leaving lazy mode: every host array current and unwatched again
     for (auto &kv : g_reg) release_host(ctx(), kv.first, kv.second);
@@ -517,15 +587,18 @@ void tmlqcd_hip_set_residency(int mode) {
   g_mode = mode;
 }
 void tmlqcd_hip_sync_to_host(spinor *field) {
+  RegLock lk;
   auto it = g_reg.find(field);
   if (it == g_reg.end() || !it->second.f) return;
   if (it->second.dev_valid && !it->second.host_valid) download(ctx(), field, it->second);
 }
 void tmlqcd_hip_sync_all_to_host(void) {
+  RegLock lk;
   for (auto &kv : g_reg)
     if (kv.second.f && kv.second.dev_valid && !kv.second.host_valid) download(ctx(), kv.first, kv.second);
 }
 void tmlqcd_hip_host_modified(spinor *field) {
+  RegLock lk;
   auto it = g_reg.find(field);
   if (it != g_reg.end()) {
     it->second.dev_valid = false; it->second.host_valid = true;
@@ -1328,6 +1401,7 @@ int write_gauge_field(char *filename, const int prec, paramsXlfInfo const *xlfIn
 // ------------------------------------------------------------------ benchmark helper
 /* benchmark.c:291-300 with the three fields resident in HBM */
 double tmlqcd_hip_benchmark_loop(spinor *f0, spinor *f1, spinor *f2, int iters) {
+  RegLock lk;
   tmhip_ctx *c = refresh(true);
   const int saved = g_mode;
   g_mode = TMLQCD_HIP_RESIDENT;
