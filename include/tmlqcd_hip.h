@@ -303,6 +303,8 @@ int tmhip_event_record(tmhip_ctx *ctx, int slot);
 int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double *ms);
 /* Launch-shape and scheduling options; the defaults are the measured best.  Apart from "gauge_recon" (below) none of
  * them changes a result beyond rounding (reduction order, FMA contraction); unknown names are refused.
+ * TMLQCD_HIP_OPTIONS="name=value,name=value" in the environment applies them when the context is created (executables linked against
+ * the drop-in unmodified); a malformed or unknown entry fails tmhip_create.
  *   "block" 0|256|64 threads per block (0: automatic, 64 on small local lattices)
  *   "xcd"   block order: 2 automatic (default; tile order up to L = 32, slab order above), 0 none, 1 one chunk per XCD,
  *           3 slab, 4 tile;  "tgrp" time-slices per tile group (0 = automatic)

@@ -287,6 +287,32 @@ def test_gauge_recon_12_is_exact_for_su3_links_and_refused_otherwise(setup16):
         f.free()
 
 
+def test_options_from_the_environment(monkeypatch):
+    """TMLQCD_HIP_OPTIONS applies tmhip_set_option at context creation (unmodified executables); a malformed or unknown entry
+    fails the creation instead of being ignored."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T = L = 8
+    for bad in ("bogus=1", "occ", "occ=two"):
+        monkeypatch.setenv("TMLQCD_HIP_OPTIONS", bad)
+        with pytest.raises(RuntimeError):
+            Lattice(T, L, L, L)
+    monkeypatch.setenv("TMLQCD_HIP_OPTIONS", "gauge_recon=12, occ=2,block=64")
+    orc = Oracle(T, L, L, L, kappa=0.13, mu=0.02, threads=4)
+    lat = Lattice(T, L, L, L, kappa=0.13, mu=0.02)
+    monkeypatch.delenv("TMLQCD_HIP_OPTIONS")
+    g = random_gauge(5, orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    N = orc.Vh
+    k = random_spinor(6, N)
+    ref = orc.new_field()
+    dk, dl = lat.field(k), lat.field()
+    for ieo in (0, 1):
+        orc.Hopping_Matrix(ieo, ref, k); lat.Hopping_Matrix(ieo, dl, dk)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+    lat.close()
+
+
 def test_slab_block_order_with_uneven_slabs():
     """xcd = 3 (XCD j owns the j-th eighth of every time-slice): 9 blocks per slice do not split into 8 equal slabs, so
     the last slab is short and its spare block slots exit -- also in the fused stencil+dot launch of cg_her, whose

@@ -195,6 +195,19 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   tmhip_set_boundary(ctx, 0.125, th);
   ctx->mu = 0.0;
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  // TMLQCD_HIP_OPTIONS="gauge_recon=12,prepack=0": tmhip_set_option for executables that are linked against the drop-in unmodified
+  if (const char *e = getenv("TMLQCD_HIP_OPTIONS")) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s", e);
+    for (char *save = nullptr, *tok = strtok_r(buf, ",; ", &save); tok; tok = strtok_r(nullptr, ",; ", &save)) {
+      char *eq = strchr(tok, '=');
+      char *end = nullptr;
+      const long v = eq ? strtol(eq + 1, &end, 10) : 0;
+      if (!eq || end == eq + 1 || *end) { tmhip_destroy(ctx); TMHIP_FAIL("TMLQCD_HIP_OPTIONS: '%s' is not of the form name=integer", tok); }
+      *eq = 0;
+      if (tmhip_set_option(ctx, tok, (int)v)) { tmhip_destroy(ctx); return 1; }
+    }
+  }
   *out = ctx;
   return 0;
 }
