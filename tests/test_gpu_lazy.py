@@ -180,6 +180,12 @@ def test_full_lattice_fields_and_site_prefixes(prog):
     y0 = f[4].copy()
     d.assign_add_mul_r(_p(f[4]), _p(f[2]), 0.5, 1000)
     assert rel_err(f[4][:1000], y0[:1000] + 0.5 * a[:1000]) < TOL and np.array_equal(f[4][1000:], y0[1000:])
+    # a prefix LONGER than VOLUME/2 (a block volume): two parts on the device, fetched whole into the bounce buffer and its second half
+    M = N + 1000
+    p0, q0 = Pp[:M].copy(), Pq[:M].copy()
+    d.assign_add_mul_r(_p(Pp), _p(Pq), -0.25, M)
+    assert rel_err(Pp[:M], p0 - 0.25 * q0) < TOL and np.array_equal(Pq[:M], q0)
+    assert rel_err(Pp[M:N + 2000], want[M:N + 2000]) < TOL    # behind the prefix: D_psi's result, untouched
 
 
 def test_solver_and_mode_switch(prog):
