@@ -74,7 +74,7 @@ def test_fused_epilogues(setup16, ieo):
         f.free()
 
 
-@pytest.mark.parametrize("mode,split_sync,prepack,early", [(1, 0, 1, 0), (2, 0, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (1, 0, 0, 0), (2, 1, 0, 0), (1, 0, 1, 1), (2, 0, 1, 1)])
+@pytest.mark.parametrize("mode,split_sync,prepack,early", [(1, 0, 1, 0), (2, 0, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (1, 0, 0, 0), (2, 1, 0, 0), (1, 0, 1, 1), (2, 0, 1, 1), (1, 0, 1, 2), (2, 0, 1, 2)])
 def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, early):
     """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self, the stencil over all sites with the hop
     across the cut taken from the received faces -- inside the stencil kernel behind a flag (split_sync 0, default) or by the
@@ -87,7 +87,8 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, early):
     dk, dl = lat.field(k), lat.field()
     lat.set_option("split_sync", split_sync)
     lat.set_option("prepack", prepack)
-    lat.set_option("split_early", early)   # boundary slices last; they take the hop across the cut themselves if the faces are already there
+    lat.set_option("split_early", 1 if early == 1 else 0)   # boundary slices last; they take the hop across the cut themselves if the faces are already there
+    lat.set_option("split_pipe", 2 if early == 2 else 0)    # boundary slices first, exterior kernel beside the stencil kernel, faces of a chain exchanged ahead
     lat.set_loopback(mode)  # 1: D2D copies, 2: one-rank RCCL communicator (ncclSend/Recv to self)
     try:
         for rep in range(3):       # repeated calls re-use the face buffers: a stale-cache bug would show here
@@ -117,6 +118,15 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, early):
         qref = orc.new_field(); orc.op("Qtm_pm_psi", qref, k.copy())
         assert rel_err(q.download(), qref[:N]) < TOL
         q.free()
+        # the benchmark loop (benchmark.c:291-300): f1 = H_eo f0, f2 = H_oe f1, many times back to back -- every second stencil gathers
+        # the output of the one before (with split_pipe: its faces are exchanged while that one is still running)
+        dk.upload(k)
+        f1, f2 = lat.field(), lat.field()
+        lat.bench_hopping(dk, f1, f2, 7)
+        r1, r2 = orc.new_field(), orc.new_field()
+        orc.Hopping_Matrix(0, r1, k); orc.Hopping_Matrix(1, r2, r1)
+        assert rel_err(f1.download(), r1[:N]) < TOL and rel_err(f2.download(), r2[:N]) < TOL
+        f1.free(); f2.free()
         # a chain whose promise would be wrong if the library took it on faith: the field between two stencils is rewritten by another
         # kernel (the twists of Mtm_plus_sym_dagg_psi) -- those stencils must not be treated as chained
         for name in ("Mtm_plus_sym_dagg_psi", "Qtm_plus_sym_psi", "Qtm_minus_psi"):
@@ -130,6 +140,7 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, early):
         lat.set_option("split_sync", 0)
         lat.set_option("prepack", 1)
         lat.set_option("split_early", 0)
+        lat.set_option("split_pipe", 0)
     dk.free(); dl.free()
 
 

@@ -386,16 +386,16 @@ static int cg_enqueue_fused_qtm(tmhip_ctx *ctx, bool fp32, tmhip_field *x, tmhip
     v2f *s0 = ctx->scratch32[0]->d32, *s1 = ctx->scratch32[1]->d32;
     if (clover) {   // Qsw_pm_psi_32 (clovertm_operators_32.c): clover_inv / clover_gamma5 epilogues instead of the twists
       const v2f *wim = ctx->sw_inv32 + (size_t)(fabs(mu) > 0 ? 1 : 0) * 72 * gs, *wip = ctx->sw_inv32, *wo = ctx->sw32 + (size_t)54 * gs;
-      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, p->d32, nullptr, EPI_CLOVER_INV, 0, 0, true, wim)) return 1;
-      if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, s0, s1, p->d32, nullptr, 0, -(mu + ctx->mu3), &n1, 1, nullptr, nullptr, wo, 1)) return 1;
+      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, p->d32, nullptr, EPI_CLOVER_INV, 0, 0, HOP_COMM | HOP_FEED, wim)) return 1;
+      if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, s0, s1, p->d32, nullptr, 0, -(mu + ctx->mu3), &n1, 1, nullptr, nullptr, wo, 3)) return 1;
       if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
-      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_CLOVER_INV, 0, 0, HOP_COMM | HOP_CHAINED, wip)) return 1;
+      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_CLOVER_INV, 0, 0, HOP_COMM | HOP_CHAINED | HOP_FEED, wip)) return 1;
       if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 0, +(mu + ctx->mu3), &n2, 2, r->d32, &st->alpha, wo, 1)) return 1;
     } else {
-      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, p->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
-      if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, s0, s1, p->d32, nullptr, 1., -mu, &n1, 1, nullptr, nullptr, nullptr, 1)) return 1;
+      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, p->d32, nullptr, EPI_TM_TIMES, nrm, nrm * mu, HOP_COMM | HOP_FEED)) return 1;
+      if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, s0, s1, p->d32, nullptr, 1., -mu, &n1, 1, nullptr, nullptr, nullptr, 3)) return 1;
       if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
-      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, HOP_COMM | HOP_CHAINED)) return 1;
+      if (tmhip_launch_hopping32(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, HOP_COMM | HOP_CHAINED | HOP_FEED)) return 1;
       if (tmhip_launch_hopping_dot32(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d32, &st->alpha, nullptr, 1)) return 1;
     }
     if (cg_reduce_update<1>(ctx, n2, st, hist, hist_len)) return 1;
@@ -404,10 +404,10 @@ static int cg_enqueue_fused_qtm(tmhip_ctx *ctx, bool fp32, tmhip_field *x, tmhip
     v2d *s0 = ctx->scratch[0]->d, *s1 = ctx->scratch[1]->d;
     if (clover) {   // Qsw_pm_psi (clovertm_operators.c:233-245)
       const v2d *wim = ctx->sw_inv + (size_t)(fabs(mu) > 0 ? 1 : 0) * 72 * gs, *wip = ctx->sw_inv, *wo = ctx->sw + (size_t)54 * gs;
-      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_CLOVER_INV, 0, 0, true, wim)) return 1;
-      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 0, -(mu + ctx->mu3), &n1, 1, nullptr, nullptr, wo, 1)) return 1;
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_CLOVER_INV, 0, 0, HOP_COMM | HOP_FEED, wim)) return 1;
+      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 0, -(mu + ctx->mu3), &n1, 1, nullptr, nullptr, wo, 3)) return 1;
       if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
-      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_CLOVER_INV, 0, 0, HOP_COMM | HOP_CHAINED, wip)) return 1;
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_CLOVER_INV, 0, 0, HOP_COMM | HOP_CHAINED | HOP_FEED, wip)) return 1;
       if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 0, +(mu + ctx->mu3), &n2, 2, r->d, &st->alpha, wo, 1)) return 1;
     } else if (self_parity >= 0) {
       // small unsplit lattices (tmhip_hopping_self_alpha_ok): no sum + scalar kernels -- the residual stencil adds up the partials of
@@ -415,19 +415,19 @@ static int cg_enqueue_fused_qtm(tmhip_ctx *ctx, bool fp32, tmhip_field *x, tmhip
       double *pa = reinterpret_cast<double *>(st + 2);
       const CgState *cur = st + self_parity;
       CgState *nxt = st + (1 - self_parity);
-      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
-      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 1., -mu, &n1, 1, nullptr, nullptr, nullptr, 1)) return 1;
-      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, HOP_COMM | HOP_CHAINED)) return 1;
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_TM_TIMES, nrm, nrm * mu, HOP_COMM | HOP_FEED)) return 1;
+      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 1., -mu, &n1, 1, nullptr, nullptr, nullptr, 3)) return 1;
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, HOP_COMM | HOP_CHAINED | HOP_FEED)) return 1;
       const HopSelfAlpha self = {ctx->partials, n1, &cur->normsq, pa};
       if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d, nullptr, nullptr, 1, &self)) return 1;
       hipLaunchKernelGGL(cg_xp_self_kernel, g, dim3(LA_BS), 0, ctx->stream, x->d, p->d, (const v2d *)r->d, p->ns, N,
                          (const double *)(ctx->partials + ctx->max_partials / 2), n2, (const double *)pa, cur, nxt, hist, hist_len);
       return 0;
     } else {
-      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_TM_TIMES, nrm, nrm * mu, true)) return 1;
-      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 1., -mu, &n1, 1, nullptr, nullptr, nullptr, 1)) return 1;
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, p->d, nullptr, EPI_TM_TIMES, nrm, nrm * mu, HOP_COMM | HOP_FEED)) return 1;
+      if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, s0, s1, p->d, nullptr, 1., -mu, &n1, 1, nullptr, nullptr, nullptr, 3)) return 1;
       if (cg_reduce_update<0>(ctx, n1, st, hist, hist_len)) return 1;
-      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, HOP_COMM | HOP_CHAINED)) return 1;
+      if (tmhip_launch_hopping(ctx, TMHIP_EO, s1, s0, nullptr, EPI_TM_TIMES, nrm, -nrm * mu, HOP_COMM | HOP_CHAINED | HOP_FEED)) return 1;
       if (tmhip_launch_hopping_dot(ctx, TMHIP_OE, nullptr, s1, s0, nullptr, 1., mu, &n2, 2, r->d, &st->alpha, nullptr, 1)) return 1;
     }
     if (cg_reduce_update<1>(ctx, n2, st, hist, hist_len)) return 1;

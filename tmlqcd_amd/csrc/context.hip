@@ -300,6 +300,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "flag_timeout_ms")) { if (value < 0) TMHIP_FAIL("flag_timeout_ms must be >= 0 (0 = wait without bound)"); ctx->flag_timeout_ticks = (unsigned long long)value * 100000ull; }
   else if (!strcmp(name, "split_early")) { ctx->opt_split_early = value != 0; ctx->prepacked = nullptr; }
   else if (!strcmp(name, "prepack")) { ctx->opt_prepack = value != 0; ctx->prepacked = nullptr; }
+  else if (!strcmp(name, "split_pipe")) { if (value < 0 || value > 2) TMHIP_FAIL("split_pipe must be 0 (off), 1 (local lattices of >= 262144 sites per parity) or 2 (every size)"); ctx->opt_split_pipe = value; ctx->prepacked = nullptr; ctx->ahead_field = nullptr; }
   else if (!strcmp(name, "comm_split")) { if (ctx->comm_ready) TMHIP_FAIL("comm_split must be set before the communicator is created"); ctx->opt_comm_split = value != 0; }
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
   else if (!strcmp(name, "gauge_cache")) { if (value < -1 || value > 1) TMHIP_FAIL("gauge_cache must be -1 (automatic), 0 or 1"); ctx->opt_gauge_cache = value; }
@@ -521,13 +522,13 @@ static int hop_tm_sub_g5(tmhip_ctx *ctx, v2d *l, const v2d *p, const v2d *k, int
 /* tm_operators.c:172-177 */
 int tmhip_Qtm_plus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
   if (need_eo(l, "Qtm_plus_psi") || need_eo(k, "Qtm_plus_psi")) return 1;
-  return hop_tm_inv(ctx, ctx->scratch[1]->d, k->d, TMHIP_EO, +1., HOP_FIRST) ||
+  return hop_tm_inv(ctx, ctx->scratch[1]->d, k->d, TMHIP_EO, +1., HOP_FIRST | HOP_FEED) ||
          hop_tm_sub_g5(ctx, l->d, k->d, ctx->scratch[1]->d, TMHIP_OE, +1., HOP_NEXT);
 }
 /* tm_operators.c:216-221 */
 int tmhip_Qtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
   if (need_eo(l, "Qtm_minus_psi") || need_eo(k, "Qtm_minus_psi")) return 1;
-  return hop_tm_inv(ctx, ctx->scratch[1]->d, k->d, TMHIP_EO, -1., HOP_FIRST) ||
+  return hop_tm_inv(ctx, ctx->scratch[1]->d, k->d, TMHIP_EO, -1., HOP_FIRST | HOP_FEED) ||
          hop_tm_sub_g5(ctx, l->d, k->d, ctx->scratch[1]->d, TMHIP_OE, -1., HOP_NEXT);
 }
 /* tm_operators.c:245-250 */
@@ -546,8 +547,8 @@ int tmhip_Mtm_minus_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
 int tmhip_Qtm_pm_psi(tmhip_ctx *ctx, tmhip_field *l, tmhip_field *k) {
   if (need_eo(l, "Qtm_pm_psi") || need_eo(k, "Qtm_pm_psi")) return 1;
   v2d *s0 = ctx->scratch[0]->d, *s1 = ctx->scratch[1]->d;
-  return hop_tm_inv(ctx, s1, k->d, TMHIP_EO, -1., HOP_FIRST) || hop_tm_sub_g5(ctx, s0, k->d, s1, TMHIP_OE, -1., HOP_NEXT) ||
-         hop_tm_inv(ctx, s1, s0, TMHIP_EO, +1., HOP_NEXT) || hop_tm_sub_g5(ctx, l->d, s0, s1, TMHIP_OE, +1., HOP_NEXT);
+  return hop_tm_inv(ctx, s1, k->d, TMHIP_EO, -1., HOP_FIRST | HOP_FEED) || hop_tm_sub_g5(ctx, s0, k->d, s1, TMHIP_OE, -1., HOP_NEXT | HOP_FEED) ||
+         hop_tm_inv(ctx, s1, s0, TMHIP_EO, +1., HOP_NEXT | HOP_FEED) || hop_tm_sub_g5(ctx, l->d, s0, s1, TMHIP_OE, +1., HOP_NEXT);
 }
 /* The "symmetric" e/o preconditioning family (tm_operators.c:186-192,223-229,259-265,296-302):
  *   X_sym = k - (1 +- i mu g5)^-1 H_oe (1 +- i mu g5)^-1 H_eo k.
@@ -670,7 +671,7 @@ int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
   if (ctx->g.nproc_t > 1) TMHIP_FAIL("loopback is a single-rank self-test");
   ctx->loopback = on != 0;
   ctx->loopback_rccl = on == 2;
-  ctx->prepacked = nullptr;
+  ctx->prepacked = nullptr; ctx->ahead_field = nullptr;
   if (on < 0 || on > 2) TMHIP_FAIL("loopback: 0 off, 1 device-to-device copies, 2 one-rank RCCL communicator");
   if (on == 2 && !ctx->comm_ready) {  // one-rank RCCL communicator: faces travel through ncclSend/ncclRecv to self
     TMHIP_CHECK(hipSetDevice(ctx->device));
@@ -726,7 +727,7 @@ int tmhip_bench_hopping(tmhip_ctx *ctx, tmhip_field *f0, tmhip_field *f1, tmhip_
   if (need_eo(f0, "bench") || need_eo(f1, "bench") || need_eo(f2, "bench")) return 1;
   if (tmhip_event_record(ctx, 14)) return 1;
   for (int j = 0; j < iters; j++) {
-    if (tmhip_launch_hopping(ctx, 0, f1->d, f0->d, nullptr, EPI_STORE, 0, 0, HOP_COMM)) return 1;   // benchmark.c:295-296
+    if (tmhip_launch_hopping(ctx, 0, f1->d, f0->d, nullptr, EPI_STORE, 0, 0, HOP_COMM | HOP_FEED)) return 1;   // benchmark.c:295-296 (f1 is gathered by the next call)
     if (tmhip_launch_hopping(ctx, 1, f2->d, f1->d, nullptr, EPI_STORE, 0, 0, HOP_COMM | HOP_CHAINED)) return 1;   // f1 is the previous stencil's output
   }
   if (tmhip_event_record(ctx, 15)) return 1;

@@ -104,7 +104,7 @@ extern "C" int tmhip_multi_hopping_matrix(int n, tmhip_ctx **ctxs, int ieo, tmhi
     TMHIP_CHECK(hipSetDevice(c->device));
     hop64::HopArgs a;
     hop64::fill_args(a, c, ieo, l[r]->d, k[r]->d, nullptr, 0, 0);
-    hop64::launch_epi<true>(a, EPI_STORE, c->stream, hop64::launch_opts(c, tmhip_hop_block(c)));
+    hop64::launch_epi<1>(a, EPI_STORE, c->stream, hop64::launch_opts(c, tmhip_hop_block(c)));
     TMHIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     hop64::launch_exterior(c, a, EPI_STORE, c->stream);
     TMHIP_CHECK(hipGetLastError());

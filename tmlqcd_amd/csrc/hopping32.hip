@@ -47,6 +47,16 @@ __device__ __forceinline__ void ld6_fresh(V2T *s, const ET *f, size_t stride, in
     __builtin_memcpy(&s[2 * m], &w0, 8); __builtin_memcpy(&s[2 * m + 1], &w1, 8);
   }
 }
+// write-through (sc0 sc1) stores of the same six components, 16 bytes each: see hopping_common.h
+__device__ __forceinline__ void st6_through(ET *f, size_t stride, int j, int blk, const V2T *s) {
+  vf4 *p = reinterpret_cast<vf4 *>(f);
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    const vf4 v = vf4{s[2 * m].x, s[2 * m].y, s[2 * m + 1].x, s[2 * m + 1].y};
+    vf4 *q = p + (size_t)(3 * blk + m) * stride + j;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");   // (s_nop: the store-data hazard the compiler cannot see inside the asm)
+  }
+}
 constexpr int HOP_STAGE_BYTES = 6 * 64 * (int)sizeof(vf4);   // per wave: [6][64] float4
 __device__ __forceinline__ void stage_put(unsigned char *region, int lid, const ET *f, size_t ns, int i) {
   vf4 *st = reinterpret_cast<vf4 *>(region);

@@ -44,6 +44,18 @@ typedef int v4i __attribute__((ext_vector_type(4)));
       }                                                                                                                           \
     }                                                                                                                             \
   }                                                                                                                               \
+  /* ... and write-through stores (sc0 sc1: the bytes leave for memory, the line is dropped from this XCD's L2): data handed to      \
+     another kernel that runs beside this one; the storing wave drains them (s_waitcnt vmcnt(0)) before it signals.  One 16-byte    \
+     store per component: 8-byte sc1 stores are separate fabric writes (the stencil's boundary waves took 94 us instead of 43) */   \
+  __device__ __forceinline__ void st6_through(ET *f, size_t stride, int j, int blk, const V2T *s) {                               \
+    static_assert(sizeof(ET) == 16, "one 16-byte element per component");                                                         \
+    _Pragma("unroll") for (int c = 0; c < 6; c++) {                                                                               \
+      ET *p = f + (size_t)(6 * blk + c) * stride + j;                                                                             \
+      v4i w;                                                                                                                      \
+      __builtin_memcpy(&w, &s[c], 16);                                                                                            \
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");                                     \
+    }                                                                                                                             \
+  }                                                                                                                               \
   constexpr int HOP_STAGE_BYTES = 12 * 64 * (int)sizeof(V2T); /* per wave */                                                      \
   __device__ __forceinline__ void stage_put(unsigned char *region, int lid, const ET *f, size_t ns, int i) {                      \
     V2T *st = reinterpret_cast<V2T *>(region);                                                                                    \

@@ -107,6 +107,10 @@ struct tmhip_ctx {
   unsigned long long flag_timeout_ticks;           // bound of the device-side flag waits in ticks of the 100 MHz clock (0 = none)
   int *bmark;                                      // per 64 face sites: 1 = the stencil kernel took the hop across the cut itself ("split_early"), 0 = left to the exterior kernel
   const void *prepacked;                           // the field whose boundary-slice projections sit in the send buffers (written by the last exterior kernel), or nullptr
+  // "split_pipe": sync_flags [3] boundary slices of the running stencil kernel stored (published by the last of their waves, counted in [4]),
+  // [5] exterior kernel of stencil n done (it runs on the comm stream).  ahead_field: the field whose faces have been exchanged AHEAD of the
+  // stencil that will gather it (complete once sync_flags[1] >= ahead_seq); bcount_total: waves counted in [4] so far
+  const void *ahead_field; unsigned int ahead_seq; unsigned int bcount_total;
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
   double *deriv;
   double *momenta;     // hamiltonian_field_t::momenta, su3adj [V][4] = double [V][4][8], resident for tmhip_update_gauge (md_update.hip)
@@ -126,6 +130,7 @@ struct tmhip_ctx {
   int opt_recon;                                                        // 12 = rebuild the third row of every link in registers (opt-in)
   int opt_split_sync;                                                   // 0: the exterior kernel / the pack kernel wait for a flag of the other stream (default); 1: HIP events, no device-side wait
   int opt_split_early;                                                  // 1: boundary slices last, hop across the cut in the stencil kernel when the faces are already there
+  int opt_split_pipe;                                                   // 1: boundary slices first, exterior kernel beside the stencil kernel, faces of a chain's next stencil exchanged ahead (hopping_impl.inc, launch_pipe)
   int opt_prepack;                                                      // 1 (default): the exterior kernel projects the faces of its output for the next stencil of a chain
   int opt_comm_split;                                                   // 0: do not split off a second communicator (exercises the one-communicator fallback)
   int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot, opt_cg_self;         // cg_her
@@ -157,7 +162,9 @@ enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_T
 // `comm`: 0 no halo exchange (Hopping_Matrix_nocom), HOP_COMM exchange the faces of `in` first, HOP_COMM | HOP_CHAINED additionally
 // promises that `in` is the output of this context's previous split-phase stencil and has not been written since (a composition
 // like Qtm_pm_psi, the stencils of a fused CG iteration): its faces were projected by that stencil's exterior kernel already
-enum { HOP_COMM = 1, HOP_CHAINED = 2 };
+// HOP_FEED: the caller expects the NEXT stencil of this context to gather this one's output ("split_pipe": its faces are then
+// projected and exchanged while this stencil is still running); a wrong guess costs one unused exchange, never a result
+enum { HOP_COMM = 1, HOP_CHAINED = 2, HOP_FEED = 4 };
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
                          double cre, double cim, int comm, const v2d *cw = nullptr);
 // Small unsplit lattices (the hop-split kernel): mode 2 can compute its coefficient itself -- EVERY block adds up the `n` per-wave partial
