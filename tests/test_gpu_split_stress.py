@@ -1,0 +1,104 @@
+"""GPU: the split-phase (T-split rank) stencil under a long seeded random sequence of operations -- stencils with every twisted-mass
+epilogue, compositions (chains), linalg kernels that rewrite fields between stencils, short cg_her solves, communication-free
+stencils (whose output is stale by construction and overwritten afterwards), uploads, and a comm stream that is held back at random
+points (a neighbour arriving late) -- against the SAME sequence on the unsplit lattice.  Every form of the split path (flags, HIP
+events, split_early, split_pipe) and both self-exchanges (copies, one-rank RCCL communicator) must reproduce the unsplit fields:
+what this guards is the bookkeeping between stencils (sequence numbers, which field's faces sit in the send buffers, which faces
+were exchanged ahead), which no single-operation test exercises."""
+import numpy as np
+import pytest
+
+from tests.util import random_gauge, random_spinor
+
+pytestmark = pytest.mark.gpu
+
+T, L = 8, 16          # faces are a quarter of the local volume; face % 64 == 0 (all forms apply)
+NF = 5
+
+
+def _run(lat, seed, nops, split):
+    """The sequence on one lattice; returns the final fields and the scalars computed on the way."""
+    rng = np.random.default_rng(seed)
+    N = lat.Vh
+    f = [lat.field(random_spinor(100 + i, N)) for i in range(NF)]
+    scal = []
+    for step in range(nops):
+        op = int(rng.integers(0, 13))
+        a, b, c = (int(x) for x in rng.choice(NF, size=3, replace=False))
+        ieo = int(rng.integers(0, 2))
+        z = complex(rng.uniform(-1, 1), rng.uniform(-1, 1))
+        r = float(rng.uniform(-0.9, 0.9))
+        delay = int(rng.integers(0, 12)) if rng.random() < 0.15 else 0
+        if split and delay:
+            lat.comm_stream_delay_ms(delay)                  # the neighbour's faces arrive late
+        if op == 0:
+            lat.Hopping_Matrix(ieo, f[a], f[b])
+        elif op == 1:
+            lat.tm_times_Hopping_Matrix(ieo, f[a], f[b], z)
+        elif op == 2:
+            lat.tm_sub_Hopping_Matrix(ieo, f[a], f[c], f[b], z)
+        elif op == 3:
+            lat.Qtm_pm_psi(f[a], f[b])
+        elif op == 4:
+            lat.op("Qtm_plus_psi", f[a], f[b])
+        elif op == 5:
+            lat.op("Qtm_minus_psi", f[a], f[a])                # in place (invert_eo.c:270)
+        elif op == 6:
+            lat.assign_add_mul_r(f[a], f[b], r, N)
+        elif op == 7:
+            lat.mul_r(f[a], 0.5 + abs(r), f[b], N)
+        elif op == 8:
+            scal.append(lat.square_norm(f[a], N, 1))
+        elif op == 9:
+            f[a].zero()
+            it, _ = lat.cg_her(f[a], f[b], 6, 0.0, 1, N)       # exactly six iterations of the fused loop
+            scal.append(float(it))
+        elif op == 10:
+            if split:
+                lat.Hopping_Matrix_nocom(ieo, f[a], f[b])      # stale faces: not comparable, ...
+            lat.Hopping_Matrix(ieo, f[a], f[b])                # ... overwritten at once; what it did to the buffers must not matter
+        elif op == 11:
+            f[a].upload(random_spinor(1000 + step, N))         # the host rewrites a field that may have been a stencil output
+        else:
+            lat.bench_hopping(f[a], f[b], f[c], 2)             # the benchmark loop: every second stencil gathers the previous output
+        # keep the numbers O(1): the operators have norm < 1 but the axpys can grow
+        if step % 7 == 6:
+            for g in f:
+                n = lat.square_norm(g, N, 1)
+                if n > 0:
+                    lat.mul_r(g, 1.0 / np.sqrt(n / N), g, N)
+    lat.sync()
+    out = [g.download() for g in f]
+    for g in f:
+        g.free()
+    return out, scal
+
+
+FORMS = [("flags", {}), ("events", {"split_sync": 1}), ("no prepack", {"prepack": 0}), ("split_early", {"split_early": 1}),
+         ("split_pipe", {"split_pipe": 2})]
+
+
+@pytest.mark.parametrize("loopback", [1, 2])
+def test_random_operation_sequences_on_the_split_path(loopback):
+    from tmlqcd_amd import Lattice
+    kappa, mu, theta = 0.131, 0.017, (1.0, 0.2, 0.0, -0.3)
+    g = random_gauge(77, T * L ** 3)
+    for seed, nops in ((1, 70), (2, 70), (3, 90)):
+        ref_lat = Lattice(T, L, L, L, kappa=kappa, mu=mu, theta=theta)
+        ref_lat.set_gauge(g)
+        ref, ref_scal = _run(ref_lat, seed, nops, split=False)
+        ref_lat.close()
+        for name, opts in FORMS:
+            lat = Lattice(T, L, L, L, kappa=kappa, mu=mu, theta=theta)
+            lat.set_gauge(g)
+            for k, v in opts.items():
+                lat.set_option(k, v)
+            lat.set_loopback(loopback)
+            got, scal = _run(lat, seed, nops, split=True)
+            lat.close()
+            for i, (x, y) in enumerate(zip(got, ref)):
+                dev = np.abs(x - y).max() / max(np.abs(y).max(), 1e-300)
+                assert dev < 1e-11, (loopback, name, seed, i, dev)      # ~70 operations deep: rounding differences of the split sums accumulate
+            assert len(scal) == len(ref_scal)
+            for s1, s2 in zip(scal, ref_scal):
+                assert abs(s1 - s2) <= 1e-11 * max(abs(s2), 1.0), (loopback, name, seed)

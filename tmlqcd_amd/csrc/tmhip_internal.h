@@ -111,6 +111,7 @@ struct tmhip_ctx {
   // [5] exterior kernel of stencil n done (it runs on the comm stream).  ahead_field: the field whose faces have been exchanged AHEAD of the
   // stencil that will gather it (complete once sync_flags[1] >= ahead_seq); bcount_total: waves counted in [4] so far
   const void *ahead_field; unsigned int ahead_seq; unsigned int bcount_total;
+  int last_ext_partials;                           // partial sums the last split-phase stencil's exterior kernel wrote in front of the stencil kernel's (0: it had none)
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
   double *deriv;
   double *momenta;     // hamiltonian_field_t::momenta, su3adj [V][4] = double [V][4][8], resident for tmhip_update_gauge (md_update.hip)
