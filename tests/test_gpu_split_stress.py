@@ -102,3 +102,75 @@ def test_random_operation_sequences_on_the_split_path(loopback):
             assert len(scal) == len(ref_scal)
             for s1, s2 in zip(scal, ref_scal):
                 assert abs(s1 - s2) <= 1e-11 * max(abs(s2), 1.0), (loopback, name, seed)
+
+
+@pytest.mark.parametrize("loopback", [1, 2])
+def test_fp32_clover_and_solvers_on_every_form_of_the_split_path(loopback):
+    """The other precisions and epilogues a T-split rank runs -- the fp32 stencil and Qtm_pm_psi_32, the clover operators in both
+    precisions, cg_her / mixed_cg_her on Qtm_pm_psi and Qsw_pm_psi (fused CG iterations: reductions spread over stencil and exterior
+    kernel, faces of fp32 fields) -- on every form of the split path against the unsplit lattice."""
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    kappa, mu = 0.13, 0.02
+    g = random_gauge(78, T * L ** 3)
+    sw, swi = syn.clover_blocks(79, T, L, L, L, mu)
+    N = T * L ** 3 // 2
+    src, b = random_spinor(81, N), random_spinor(82, N)
+
+    def run(lat):
+        res = {}
+        k, q, l, x = lat.field(src), lat.field(b), lat.field(), lat.field()
+        k32, l32 = lat.field32(src.astype(np.float32)), lat.field32()
+        for ieo in (0, 1):
+            lat.Hopping_Matrix_32(ieo, l32, k32); res["hop32_%d" % ieo] = l32.download().astype(np.float64)
+        lat.Qtm_pm_psi_32(l32, k32); res["qtm32"] = l32.download().astype(np.float64)
+        lat.Qsw_pm_psi_32(l32, k32); res["qsw32"] = l32.download().astype(np.float64)
+        lat.op("Qsw_pm_psi", l, k); res["qsw"] = l.download()
+        lat.op("Qsw_minus_psi", l, k); res["qsw_minus"] = l.download()
+        for name in ("Qtm_pm_psi", "Qsw_pm_psi"):
+            x.zero(); it, _ = lat.cg_her(x, q, 2000, 1e-18, 1, N, op=name)
+            res["cg_" + name] = (it, x.download())
+            x.zero(); it, outer = lat.mixed_cg_her(x, q, 2000, 1e-18, 1, N, op=name)
+            res["mixed_" + name] = (it, x.download())
+        lat.sync()
+        for fld in (k, q, l, x, k32, l32):
+            fld.free()
+        return res
+
+    def make():
+        lat = Lattice(T, L, L, L, kappa=kappa, mu=mu)
+        lat.set_gauge(g)
+        lat.set_clover(sw, swi)
+        return lat
+
+    ref_lat = make()
+    ref = run(ref_lat)
+
+    def true_residual(name, sol):
+        """|A x - b|^2 / |b|^2 with A applied on the UNSPLIT lattice"""
+        x, y = ref_lat.field(sol), ref_lat.field()
+        ref_lat.op(name, y, x)
+        r = y.download() - b
+        x.free(); y.free()
+        return float((r * r).sum() / (b * b).sum())
+
+    def rel(x, y):
+        return float(np.abs(x - y).max() / np.abs(y).max())
+    for name, opts in FORMS:
+        lat = make()
+        for kk, v in opts.items():
+            lat.set_option(kk, v)
+        lat.set_loopback(loopback)
+        got = run(lat)
+        lat.close()
+        for key, val in got.items():
+            if isinstance(val, tuple):
+                (it, sol), (it0, _) = val, ref[key]
+                # the same solve, rounded differently (split sums; fp32 restarts): about as many iterations, and a solution of the system
+                assert it > 0 and abs(it - it0) <= 2 + 0.03 * it0, (loopback, name, key, it, it0)
+                rr = true_residual(key.split("_", 1)[1], sol)
+                assert rr <= 4e-18, (loopback, name, key, rr)
+            else:
+                tol = 5e-6 if key.endswith("32") or "32_" in key else 1e-13
+                assert rel(val, ref[key]) < tol, (loopback, name, key, rel(val, ref[key]))
+    ref_lat.close()
