@@ -146,3 +146,40 @@ void *stub_calloc(size_t bytes) {
   return m == MAP_FAILED ? NULL : m + 16;
 }
 void stub_free(void *p, size_t bytes) { munmap((char *)p - 16, bytes + 4096); }
+
+/* A host program that has its OWN SIGSEGV handler before the library installs the lazy mode's (a debugger hook, a guard-page
+ * allocator): faults that are not the library's must still reach it.  The probe handler owns one inaccessible guard page, counts the
+ * faults on it and leaves them with siglongjmp; anything else it declines (default action). */
+#include <setjmp.h>
+#include <signal.h>
+#include <string.h>
+static sigjmp_buf stub_probe_jb;
+static volatile int stub_probe_faults = 0;
+static char *stub_probe_guard = NULL;
+static void stub_probe_segv(int sig, siginfo_t *si, void *uctx) {
+  (void)uctx;
+  if (stub_probe_guard && (char *)si->si_addr >= stub_probe_guard && (char *)si->si_addr < stub_probe_guard + 4096) {
+    stub_probe_faults++;
+    siglongjmp(stub_probe_jb, 1);
+  }
+  signal(sig, SIG_DFL);   /* not ours either: die the ordinary way when the instruction runs again */
+}
+int stub_install_segv_probe(void) {
+  stub_probe_guard = mmap(NULL, 4096, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (stub_probe_guard == MAP_FAILED) return -1;
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_sigaction = stub_probe_segv;
+  sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+  sigemptyset(&sa.sa_mask);
+  return sigaction(SIGSEGV, &sa, NULL);
+}
+/* load from the guard page: returns the number of faults the probe handler has seen so far (-1: the load did not fault) */
+int stub_touch_guard(void) {
+  if (!sigsetjmp(stub_probe_jb, 1)) {
+    volatile char c = *(volatile char *)stub_probe_guard;
+    (void)c;
+    return -1;
+  }
+  return stub_probe_faults;
+}

@@ -313,3 +313,15 @@ def test_threads_fault_while_the_master_thread_changes_the_registry(prog):
         assert abs(got - want[rnd & 1]) < 1e-9 * max(1.0, abs(want[rnd & 1])), rnd
     d.Hopping_Matrix(0, _p(outs[0]), _p(f[0]))
     assert rel_err(outs[0], r[0][:N]) < TOL
+
+
+def test_faults_of_the_host_program_reach_its_own_handler():
+    """VERDICT r2 item 7 (chain test): a host program with a SIGSEGV handler of its own, installed BEFORE the lazy mode's -- its faults
+    (a guard page) must still reach it while fields are stale and watched, and the library's own faults must be served as before.
+    A process of its own: in this one the library's handler is long installed (tests/lazy_chain_child.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "lazy_chain_child.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().startswith("OK"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
