@@ -680,6 +680,32 @@ def rank_main(args, world, rank, local_rank):
                     "note": "opt-in tmhip_set_option(gauge_recon, 12); COMPRESSION_12 of misc_types.h:29-33"}
         recon = leg("gauge_recon 12", recon_leg)
 
+    # --- what this box's memory system delivers to plain streaming kernels ("measure a device-to-device copy / triad
+    # on the box and quote the fraction of THAT too"): copy R = S and triad P += c Q over several pairs of fields in turn, so that the
+    # working set (8 x 101 MB at 32^4) is beyond the 256 MB Infinity Cache
+    stream = None
+    if world == 1 and not args.loopback:
+        def stream_leg(ph):
+            def fn():
+                Vh = V // 2
+                fs = [lat.field() for _ in range(8)]           # four pairs of one-parity fields, taken in turn
+                res = {}
+                for name, call, nbytes in (("copy", lambda i: lat.assign(fs[2 * (i & 3)], fs[2 * (i & 3) + 1], Vh), 2 * 192.0 * Vh),
+                                           ("triad", lambda i: lat.assign_add_mul_r(fs[2 * (i & 3)], fs[2 * (i & 3) + 1], 0.5, Vh), 3 * 192.0 * Vh)):
+                    for i in range(4):
+                        call(i)
+                    lat.event_record(12)
+                    for i in range(40):
+                        call(i)
+                    lat.event_record(13)
+                    res[name + "_GBps"] = nbytes * 40 / (lat.event_elapsed_ms(12, 13) * 1e-3) / 1e9
+                for x in fs:
+                    x.free()
+                res["note"] = "assign / assign_add_mul_r over four pairs of one-parity fp64 fields in turn (8 x %.0f MB: beyond the Infinity Cache), HIP events over 40 calls" % (192.0 * Vh / 1e6)
+                return res
+            return ph.step("stream kernels", fn)
+        stream = leg("stream", stream_leg)
+
     # --- BASELINE configs[1] (16^4, one GPU): the launch-bound end of the path
     cg16 = None
     if world == 1 and not args.loopback and (T, L) == (32, 32):
@@ -767,6 +793,9 @@ def rank_main(args, world, rank, local_rank):
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "hop_kernel (Hopping_Matrix, one parity)",
                          "us_per_launch": 1e6 * t_launch, "achieved_2880B_model": achieved * 2880.0 / 1536.0},
         }
+        if isinstance(stream, dict) and stream.get("triad_GBps"):
+            # the vendor-nominal 8 TB/s stays `peak`; next to it what streaming kernels reach on this box, and the stencil against that
+            out["roofline"]["measured_stream"] = dict(stream, frac_of_triad=achieved / stream["triad_GBps"], frac_of_copy=achieved / stream["copy_GBps"])
         out.update(extra)
         if gpu_out is not None:
             try:
