@@ -228,6 +228,13 @@ class Ranks:
         self.on = world > 1 or force
         self.torch = self.dist = None
         self.dev = "cpu"
+        self.device = local_rank          # GPU of this rank
+        # TMLQCD_BENCH_TRANSPORT=shm: the ranks exchange through the library's host-staged shared-memory transport instead of RCCL
+        # and may SHARE GPUs (rank r on GPU r mod #GPUs): the whole multi-rank run as real processes on a one-GPU box
+        self.shm = os.environ.get("TMLQCD_BENCH_TRANSPORT") == "shm"
+        self.transport = "the host-staged shared-memory transport (ranks may share a GPU: a rehearsal of the multi-rank run, not a scaling measurement)" if self.shm else "RCCL"
+        if self.shm and backend == "nccl":
+            backend = "gloo"
         if self.on:
             # torch first: its bundled HIP/RCCL runtime must be the one every later library binds to
             import torch
@@ -244,6 +251,8 @@ class Ranks:
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             else:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
+                if self.shm:
+                    self.device = local_rank % max(torch.cuda.device_count(), 1)
 
     def barrier(self, lat=None):
         if lat is not None:
@@ -342,17 +351,27 @@ def make_lattice(ph, R, T, L, args, nproc_t):
     box = {}
 
     def create():
-        lat = Lattice(T, L, L, L, kappa=0.125, mu=0.01, nproc_t=nproc_t, proc_t=R.rank if nproc_t > 1 else 0, device=R.local_rank)
+        lat = Lattice(T, L, L, L, kappa=0.125, mu=0.01, nproc_t=nproc_t, proc_t=R.rank if nproc_t > 1 else 0, device=R.device)
         for kv in args.opt:
             k, v = kv.split("=")
             lat.set_option(k, int(v))
         box["lat"] = lat
-        box["uid"] = lat.comm_unique_id() if (R.on and nproc_t > 1 and R.rank == 0) else b"\0" * 128
+        if R.on and nproc_t > 1 and R.rank == 0:
+            if R.shm:
+                make_lattice.jobs = getattr(make_lattice, "jobs", 0) + 1
+                box["uid"] = ("bench_%d_%d_%x" % (os.getpid(), make_lattice.jobs, int.from_bytes(os.urandom(4), "little"))).encode().ljust(128, b"\0")
+            else:
+                box["uid"] = lat.comm_unique_id()
+        else:
+            box["uid"] = b"\0" * 128
     ph.step("create lattice", create)
     lat = box["lat"]
     if R.on and nproc_t > 1:
         uid = ph.collective(lambda: R.bcast_uid(box["uid"]))
-        ph.step("comm_init", lambda: lat.comm_init(uid))
+        if R.shm:
+            ph.step("comm_init", lambda: lat.comm_init_shm(uid.rstrip(b"\0").decode()))
+        else:
+            ph.step("comm_init", lambda: lat.comm_init(uid))
     if args.loopback and R.world == 1:
         lat.set_loopback(args.loopback)
     return lat
@@ -452,7 +471,7 @@ def split_leg(R, args, L, Tg, what, steps):
         def reference():
             if r != 0:
                 return
-            G = Lattice(Tg, L, L, L, kappa=0.125, mu=0.01, device=R.local_rank)
+            G = Lattice(Tg, L, L, L, kappa=0.125, mu=0.01, device=R.device)
             G.set_gauge(syn.gauge_field(7, Tg, L, L, L))
             gk = G.field(syn.spinor_field_eo(8, 0, Tg, L, L, L))
             gl, gq, gP = G.field(), G.field(), G.field()
@@ -502,7 +521,7 @@ def split_leg(R, args, L, Tg, what, steps):
         dtn = time_nocom(ph, R, S, f0, f1, f2, steps)
         cgs = time_cg(ph, R, S, S.field(), box["q9"], min(args.cg_iters, 100))
         Vs = Ts * L ** 3
-        tim = {"config": "global %dx%d^3 split in T over %d GPUs (T_local %d), half-spinor faces over RCCL" % (Tg, L, w, Ts),
+        tim = {"config": "global %dx%d^3 split in T over %d ranks (T_local %d), half-spinor faces over %s" % (Tg, L, w, Ts, R.transport),
                "value": w * 1608.0 / (1e6 * dts / (steps * Vs)), "unit": "Mflop/s", "ms_per_step": 1e3 * dts / steps,
                "us_per_launch": 1e3 * evs / (2 * steps), "steps": steps, "cg_iters_per_s": cgs["iters_per_s"],
                "nocom": {"value": w * 1608.0 / (1e6 * dtn / (steps * Vs)), "ms_per_step": 1e3 * dtn / steps,
@@ -710,7 +729,7 @@ def rank_main(args, world, rank, local_rank):
     cg16 = None
     if world == 1 and not args.loopback and (T, L) == (32, 32):
         def cg16_leg(ph):
-            l16 = Lattice(16, 16, 16, 16, kappa=0.125, mu=0.01, device=local_rank)
+            l16 = Lattice(16, 16, 16, 16, kappa=0.125, mu=0.01, device=R.device)
             l16.set_gauge(syn.gauge_field(7, 16, 16, 16, 16))
             P16, Q16 = l16.field(), l16.field(syn.spinor_field_eo(9, 1, 16, 16, 16, 16))
             c = time_cg(ph, R, l16, P16, Q16, 200)
@@ -783,7 +802,7 @@ def rank_main(args, world, rank, local_rank):
                                    "global %dx%d^3, fp64, kappa=0.125, periodic, random SU(3) gauge + Gaussian spinor"
                                    % (T, L, T * world, L),
                        "local_lattice": [T, L, L, L], "global_lattice": [T * world, L, L, L],
-                       "parallelism": ("T-split ring of %d, half-spinor faces over RCCL" % world if world > 1 else
+                       "parallelism": ("T-split ring of %d, half-spinor faces over %s" % (world, R.transport) if world > 1 else
                                        ("single GPU, split-phase path rehearsed with self-exchange (loopback %d)" % args.loopback
                                         if args.loopback else "single GPU"))},
             "lattice_updates_per_s": args.steps / dt, "us_per_site": sdt,

@@ -273,6 +273,13 @@ int tmhip_write_gauge_field(tmhip_ctx *ctx, const char *filename, int prec, cons
 #define TMHIP_UNIQUE_ID_BYTES 128
 int tmhip_comm_get_unique_id(char id[TMHIP_UNIQUE_ID_BYTES]);             /* rank 0, then broadcast by the host program */
 int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]); /* ring of nproc_t ranks along T over RCCL */
+/* The same ring WITHOUT RCCL: the ranks of a node meet in a POSIX shared-memory segment named after `job` (1 .. 64 characters, the same
+ * string on every rank of the job, different between jobs -- e.g. the launcher's job id), and faces, halo slices and scalar sums travel
+ * device -> page-locked host memory -> that segment -> device, stream-ordered on the compute stream with no overlap: the reference's own
+ * MPI exchange on host memory (xchange/xchange_field.c:98-250, linalg/square_norm.c:299-316).  Not the fast path; it needs nothing but
+ * the node's memory and lets several ranks share one GPU (how the multi-rank code is tested as real processes on a one-GPU box).
+ * Collective over the ranks; replaces tmhip_comm_init for this context.  Sums are added in rank order: the same bits on every rank. */
+int tmhip_comm_init_shm(tmhip_ctx *ctx, const char *job);
 /* tmhip_comm_init builds TWO communicators over the same ranks: one for the half-spinor faces (second HIP stream), one
  * (ncclCommSplit of the first) for the scalar all-reduces of the linalg (MPI_Allreduce in linalg/square_norm.c:314) and the
  * force halos on the main stream.  Ranks in each as RCCL reports them (ncclCommCount); 0, 0 before tmhip_comm_init. */

@@ -941,12 +941,15 @@ int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_
   if (np > 1) {
     const size_t n = (size_t)2 * 30 * ctx->g.LX * ctx->g.LY * ctx->g.LZ;   // doubles per slice of insertion matrices
     double *snd = (double *)ctx->swpm_halo_send, *rcv = (double *)ctx->swpm_halo_recv;
+    if (ctx->shm) { if (tmhip_shm_ring(ctx, ctx->stream, snd, snd + n, rcv, rcv + n, n * sizeof(double))) return 1; }
+    else {
     TMHIP_NCCL_CHECK(ncclGroupStart());
     TMHIP_NCCL_CHECK(ncclSend(snd, n, ncclDouble, dn, ctx->comm_red, ctx->stream));            // our t = 0 slice is the down neighbour's t = T
     TMHIP_NCCL_CHECK(ncclSend(snd + n, n, ncclDouble, up, ctx->comm_red, ctx->stream));        // our t = T-1 slice is the up neighbour's t = -1
     TMHIP_NCCL_CHECK(ncclRecv(rcv, n, ncclDouble, up, ctx->comm_red, ctx->stream));            // slab 0 = t = T
     TMHIP_NCCL_CHECK(ncclRecv(rcv + n, n, ncclDouble, dn, ctx->comm_red, ctx->stream));        // slab 1 = t = -1
     TMHIP_NCCL_CHECK(ncclGroupEnd());
+    }
   }
   return sw_all_launch(ctx, kappa, c_sw);
 }

@@ -75,6 +75,7 @@ int tmhip_check_async_error(tmhip_ctx *ctx) {
                  (double)ctx->flag_timeout_ticks * 1.0e-8);
     }
   }
+  if (ctx->shm) return tmhip_shm_failed(ctx);
   if (!ctx->comm_ready) return 0;
   ncclResult_t st = ncclSuccess;
   TMHIP_NCCL_CHECK(ncclCommGetAsyncError(ctx->comm, &st));
@@ -236,7 +237,8 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->io_sums) (void)hipFree(ctx->io_sums);
   if (ctx->swpm_halo_send) (void)hipFree(ctx->swpm_halo_send);
   if (ctx->swpm_halo_recv) (void)hipFree(ctx->swpm_halo_recv);
-  if (ctx->comm_ready) { if (ctx->comm_red != ctx->comm) ncclCommDestroy(ctx->comm_red); ncclCommDestroy(ctx->comm); }
+  if (ctx->shm) tmhip_shm_destroy(ctx);
+  else if (ctx->comm_ready) { if (ctx->comm_red != ctx->comm) ncclCommDestroy(ctx->comm_red); ncclCommDestroy(ctx->comm); }
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
   (void)hipFree(ctx->sync_flags);
@@ -649,6 +651,7 @@ int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]) {
 
 int tmhip_comm_count(tmhip_ctx *ctx, int *nranks_faces, int *nranks_reduce) {
   if (!ctx->comm_ready) { *nranks_faces = *nranks_reduce = 0; return 0; }
+  if (ctx->shm) { *nranks_faces = *nranks_reduce = ctx->g.nproc_t; return 0; }
   TMHIP_NCCL_CHECK(ncclCommCount(ctx->comm, nranks_faces));
   TMHIP_NCCL_CHECK(ncclCommCount(ctx->comm_red, nranks_reduce));
   return 0;
@@ -695,6 +698,7 @@ int tmhip_halo_exchange(tmhip_ctx *ctx) {
     return 0;
   }
   if (!ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
+  if (ctx->shm) TMHIP_FAIL("tmhip_halo_exchange: the shared-memory transport exchanges on the compute stream (launch_split)");
   const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
   TMHIP_NCCL_CHECK(ncclGroupStart());
   TMHIP_NCCL_CHECK(ncclSend(ctx->send_dn, n, ncclDouble, dn, ctx->comm, ctx->comm_stream));

@@ -311,11 +311,12 @@ int sums_fetch(tmhip_ctx *ctx, unsigned out[2]) {
 }
 // XOR of the checksum words over the ranks (io/dml.c:63-66): RCCL has no bit-wise XOR reduction, so the words are gathered
 int sums_combine(tmhip_ctx *ctx, unsigned sums[2]) {
-  int n = 0;
-  TMHIP_NCCL_CHECK(ncclCommCount(ctx->comm_red, &n));
+  int n = ctx->g.nproc_t;
+  if (!ctx->shm) TMHIP_NCCL_CHECK(ncclCommCount(ctx->comm_red, &n));
   if (n < 1 || n > ILDG_SLOTS) TMHIP_FAIL("sums_combine: %d ranks", n);
   TMHIP_CHECK(hipMemcpyAsync(ctx->io_sums, sums, 2 * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-  TMHIP_NCCL_CHECK(ncclAllGather(ctx->io_sums, ctx->io_sums + 2, 2, ncclUint32, ctx->comm_red, ctx->stream));   // (io_sums holds 2 * ILDG_SLOTS words)
+  if (ctx->shm) { if (tmhip_shm_allgather(ctx, ctx->stream, ctx->io_sums, ctx->io_sums + 2, 2 * sizeof(unsigned))) return 1; }
+  else TMHIP_NCCL_CHECK(ncclAllGather(ctx->io_sums, ctx->io_sums + 2, 2, ncclUint32, ctx->comm_red, ctx->stream));   // (io_sums holds 2 * ILDG_SLOTS words)
   std::vector<unsigned> h(2 * (size_t)n);
   TMHIP_CHECK(hipMemcpyAsync(h.data(), ctx->io_sums + 2, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -102,6 +102,7 @@ struct tmhip_ctx {
   // comm_split false: ncclCommSplit is unavailable (or switched off, "comm_split" 0) and comm_red == comm; still correct, because
   // a face exchange is never in flight together with a main-stream collective (launch_split, hopping_impl.inc).
   ncclComm_t comm, comm_red; bool comm_ready; bool comm_split; bool loopback; bool loopback_rccl;
+  struct TmhipShm *shm;   // != nullptr: the ranks talk through the host-staged shared-memory transport (xfer_shm.hip) instead of RCCL; everything on `stream`
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
   unsigned int *sync_flags; unsigned int hop_seq;  // [0] main stream reached stencil n, [1] faces of stencil n received, [2] a bounded wait gave up
   unsigned long long flag_timeout_ticks;           // bound of the device-side flag waits in ticks of the 100 MHz clock (0 = none)
@@ -155,6 +156,13 @@ static inline int tmhip_hop_block(const tmhip_ctx *ctx) { return ctx->opt_block 
 // Reductions go through RCCL on T-split ranks -- and in the one-rank RCCL loopback (tmhip_comm_set_loopback(ctx, 2)), so that the
 // multi-rank code path (partial sums, ncclAllReduce, scalar update as separate steps) runs in the single-GPU tests too.
 static inline bool tmhip_reduce_over_ranks(const tmhip_ctx *ctx) { return ctx->comm_ready && (ctx->g.nproc_t > 1 || ctx->loopback_rccl); }
+
+// ---- host-staged shared-memory transport (xfer_shm.hip): stream-ordered ring exchange / sum / gather over the ranks of the node ----
+void tmhip_shm_destroy(tmhip_ctx *ctx);
+int tmhip_shm_failed(tmhip_ctx *ctx);
+int tmhip_shm_ring(tmhip_ctx *ctx, hipStream_t st, const void *to_dn, const void *to_up, void *from_up, void *from_dn, size_t bytes);
+int tmhip_shm_allreduce(tmhip_ctx *ctx, hipStream_t st, double *x, int n);
+int tmhip_shm_allgather(tmhip_ctx *ctx, hipStream_t st, const void *mine, void *all, size_t bytes);
 
 // ---- launch helpers implemented across the .hip files ----
 enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4, EPI_CLOVER_INV = 5, EPI_CLOVER_G5 = 6, EPI_CLOVER = 7,

@@ -136,6 +136,7 @@ def load_library():
         "tmhip_rg_mixed_cg_her": [vp, vp, vp, i, d, i, i, i, d, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)],
         "tmhip_comm_get_unique_id": [C.c_char_p],
         "tmhip_comm_init": [vp, C.c_char_p],
+        "tmhip_comm_init_shm": [vp, C.c_char_p],
         "tmhip_comm_set_loopback": [vp, i],
         "tmhip_comm_count": [vp, C.POINTER(i), C.POINTER(i)],
         "tmhip_comm_is_split": [vp],
@@ -609,6 +610,10 @@ class Lattice:
 
     def comm_init(self, uid):
         _ck(self.lib.tmhip_comm_init(self.h, uid), "tmhip_comm_init")
+
+    def comm_init_shm(self, job):
+        """the ring over the host-staged shared-memory transport (ranks of one node, no RCCL; `job`: the same string on every rank)"""
+        _ck(self.lib.tmhip_comm_init_shm(self.h, job.encode()), "tmhip_comm_init_shm")
 
     def comm_count(self):
         """(ranks of the face communicator, ranks of the reduction communicator) as RCCL reports them; (0, 0) without one."""
