@@ -43,3 +43,43 @@ def test_bench_runs_as_n_processes_and_agrees_with_the_unsplit_lattice(nranks):
         s32 = rec["strong_32"]
         assert s32["rank_check"]["ok"] is True, s32
     assert rec["cg"]["iters_per_s"] > 0 and abs(rec["hermiticity_rel_dev"]) < 1e-12
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_next_rows_as_real_processes(world, tmp_path):
+    """D_psi, the device-side clover term / inverse and Qsw_pm_psi, cg_her and mixed_cg_her on both operators, both parts of the fermion
+    force, the link update with its halo exchange and update_momenta -- every rank a process of its own (tests/mp_rank_worker.py), slab by
+    slab against the unsplit lattice."""
+    import numpy as np
+    worker = os.path.join(ROOT, "tests", "mp_rank_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60")
+    job = "mp_%d_%d" % (os.getpid(), world)
+    ref = subprocess.run([sys.executable, worker, "0", "1", job, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert ref.returncode == 0, ref.stderr[-3000:]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), job, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=400) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    one = np.load(os.path.join(str(tmp_path), "rank0_of_1.npz"))
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d_of_%d.npz" % (r, world))) for r in range(world)]
+
+    def slab(a, r):
+        n = a.shape[0] // world
+        return a[r * n:(r + 1) * n]
+    for key in ("D_psi", "Qsw_pm_psi", "Qtm_pm_psi", "derivative", "links", "hop_after_update", "momenta"):
+        sc = np.abs(one[key]).max()
+        for r in range(world):
+            dev = np.abs(parts[r][key] - slab(one[key], r)).max() / sc
+            assert dev < 1e-12, (key, r, dev)
+    for r in range(world):                                       # global sums: the same number on every rank
+        assert np.allclose(parts[r]["norm"], one["norm"], rtol=1e-13), (r, parts[r]["norm"], one["norm"])
+        assert np.array_equal(parts[r]["norm"], parts[0]["norm"])   # ... bit for bit (added in rank order on every rank)
+    for name in ("Qtm_pm_psi", "Qsw_pm_psi"):
+        it0 = int(one["cg_it_" + name][0])
+        for r in range(world):
+            assert abs(int(parts[r]["cg_it_" + name][0]) - it0) <= 1, name
+            assert abs(int(parts[r]["mixed_it_" + name][0]) - int(one["mixed_it_" + name][0])) <= 3 + 0.03 * it0, name
+            for kind in ("cg_", "mixed_"):
+                sc = np.abs(one[kind + name]).max()
+                assert np.abs(parts[r][kind + name] - slab(one[kind + name], r)).max() / sc < 1e-6, (kind, name, r)
