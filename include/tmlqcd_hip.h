@@ -261,8 +261,9 @@ typedef struct {
  * stencil gauge copy as after tmhip_set_gauge; sums[2] = SciDAC checksum A, B of this rank's sites (XOR over ranks = the file's) */
 int tmhip_gauge_unpack_ildg(tmhip_ctx *ctx, const void *file_bytes, int prec, unsigned *sums);
 int tmhip_gauge_pack_ildg(tmhip_ctx *ctx, void *file_bytes, int prec, unsigned *sums);
-/* read_gauge_field(filename, gf) / write_gauge_field(filename, prec, xlfInfo), LIME framing included (the reader also on T-split ranks:
- * every rank reads its contiguous part of the record, the checksum is combined over the ranks; the writer: one rank); the reader returns 0
+/* read_gauge_field(filename, gf) / write_gauge_field(filename, prec, xlfInfo), LIME framing included (both also on T-split ranks, collective:
+ * every rank reads / writes its contiguous part of the record at its offset, the checksum is combined over the ranks, rank 0 writes the
+ * framing records -- the file is byte for byte the one a single rank writes); the reader returns 0
  * or -1 with the reference's messages (io_checks = !g_disable_IO_checks; prec_expected = gauge_precision_read_flag);
  * host_gauge (may be NULL): the host's g_gauge_field to fill as well; xlf_info: the formatted "xlf-info" message or NULL */
 int tmhip_read_gauge_field(tmhip_ctx *ctx, const char *filename, int prec_expected, int io_checks, void *host_gauge, tmhip_gauge_info *info);

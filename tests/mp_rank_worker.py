@@ -65,6 +65,13 @@ lat.momenta_upload(mom)
 lat.update_gauge(0.05)
 res["links"] = lat.gauge_download()[:V]
 lat.Hopping_Matrix(0, l, k); res["hop_after_update"] = l.download()
+# ILDG: every rank writes its part of ONE record at its offset (checksum words gathered over the ranks), then all read the file back
+conf = os.path.join(outdir, "conf_%d.lime" % world)
+sums = lat.write_gauge_field(conf, 64, "plaquette = 0.5")
+rc, back, info = lat.read_gauge_field(conf, 64)
+res["ildg"] = np.array([rc, sums[0], sums[1], info.suma, info.sumb, info.suma_stored, info.sumb_stored], dtype=np.float64)
+res["links_read_back"] = back[:V]
+lat.Hopping_Matrix(1, l, k); res["hop_after_read"] = l.download()
 lat.update_momenta(0.1)
 res["momenta"] = lat.momenta_download()
 lat.sync()

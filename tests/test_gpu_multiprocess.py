@@ -67,7 +67,12 @@ def test_next_rows_as_real_processes(world, tmp_path):
     def slab(a, r):
         n = a.shape[0] // world
         return a[r * n:(r + 1) * n]
-    for key in ("D_psi", "Qsw_pm_psi", "Qtm_pm_psi", "derivative", "links", "hop_after_update", "momenta"):
+    # the configuration file written by `world` ranks is the file one rank writes, byte for byte (the date in the xlf record aside)
+    fa, fb = (open(os.path.join(str(tmp_path), "conf_%d.lime" % w), "rb").read() for w in (1, world))
+    assert len(fa) == len(fb) and sum(x != y for x, y in zip(fa, fb)) <= 32, "the split writers' file differs from the single writer's"
+    for r in range(world):
+        assert parts[r]["ildg"][0] == 0 and np.array_equal(parts[r]["ildg"][1:], one["ildg"][1:]), (r, parts[r]["ildg"], one["ildg"])   # read status, checksum words
+    for key in ("D_psi", "Qsw_pm_psi", "Qtm_pm_psi", "derivative", "links", "links_read_back", "hop_after_update", "hop_after_read", "momenta"):
         sc = np.abs(one[key]).max()
         for r in range(world):
             dev = np.abs(parts[r][key] - slab(one[key], r)).max() / sc

@@ -614,6 +614,7 @@ void tmlqcd_hip_forget(spinor *field) {
   g_reg.erase(it);
 }
 void tmlqcd_hip_comm_init(const char unique_id[128]) { CK(tmhip_comm_init(ctx(), unique_id)); }
+void tmlqcd_hip_comm_init_shm(const char *job) { CK(tmhip_comm_init_shm(ctx(), job)); }
 void tmlqcd_hip_finalize(void) {
   if (!g_ctx) return;
   RegLock lk;

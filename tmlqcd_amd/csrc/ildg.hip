@@ -458,33 +458,57 @@ int tmhip_read_gauge_field(tmhip_ctx *ctx, const char *filename, int prec_expect
   return 0;
 }
 
-/* io/gauge_write.c:22-59 write_gauge_field(filename, prec, xlfInfo) for a single rank: "xlf-info" (MB 1, ME 1; the message is
- * formatted by the caller, io/utils_write_xlf_xml.c:30-63, NULL or "" leaves the record out), "ildg-format" (1, 0), "ildg-binary-data"
- * (0, 0) from the links resident in HBM, "scidac-checksum" (0, 1).  sums (may be NULL) receives the checksum written. */
+/* io/gauge_write.c:22-59 write_gauge_field(filename, prec, xlfInfo): "xlf-info" (MB 1, ME 1; the message is formatted by the caller,
+ * io/utils_write_xlf_xml.c:30-63, NULL or "" leaves the record out), "ildg-format" (1, 0), "ildg-binary-data" (0, 0) from the links
+ * resident in HBM, "scidac-checksum" (0, 1).  sums (may be NULL) receives the checksum written.
+ * T-split ranks (collective, as the reference's parallel writer io/gauge_write_binary.c:38-170): the record is the global lattice in
+ * its site order t, z, y, x -- the ranks' parts follow one another -- so rank 0 writes the framing records and every rank its part
+ * at its offset; the checksum words are combined over the ranks first (which is also the barrier behind rank 0 creating the file).
+ * The file is complete when the call has returned on every rank. */
 int tmhip_write_gauge_field(tmhip_ctx *ctx, const char *filename, int prec, const char *xlf_info, unsigned *sums) {
-  if (ctx->g.nproc_t != 1) TMHIP_FAIL("tmhip_write_gauge_field: single rank only (T-split ranks take their part of the record from tmhip_gauge_pack_ildg)");
   if (prec != 32 && prec != 64) TMHIP_FAIL("tmhip_write_gauge_field: precision %d (32 or 64)", prec);
-  const unsigned long long bytes = (unsigned long long)ctx->V * 4 * 144 * prec / 64;
+  const int np = ctx->g.nproc_t, rk = ctx->g.proc_t;
+  if (np > 1 && !tmhip_reduce_over_ranks(ctx)) TMHIP_FAIL("tmhip_write_gauge_field on a T-split lattice needs the communicator (tmhip_comm_init)");
+  const unsigned long long part = (unsigned long long)ctx->V * 4 * 144 * prec / 64, bytes = part * np;
   void *buf = nullptr;
-  TMHIP_CHECK(hipHostMalloc(&buf, bytes, hipHostMallocDefault));
+  TMHIP_CHECK(hipHostMalloc(&buf, part, hipHostMallocDefault));
   unsigned cs[2] = {0, 0};
   if (tmhip_gauge_pack_ildg(ctx, buf, prec, cs)) { (void)hipHostFree(buf); return 1; }
-  FILE *fp = fopen(filename, "wb");
-  if (!fp) { (void)hipHostFree(buf); TMHIP_FAIL("write_gauge_field: cannot create %s", filename); }
   char fmt[512], chk[512];
   snprintf(fmt, sizeof(fmt), "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<ildgFormat xmlns=\"http://www.lqcd.org/ildg\"\n"
            "            xmlns:xsi=\"http://www.w3.org/2001/XMLSchema-instance\"\n            xsi:schemaLocation=\"http://www.lqcd.org/ildg/filefmt.xsd\">\n"
            "  <version>1.0</version>\n  <field>su3gauge</field>\n  <precision>%d</precision>\n  <lx>%d</lx>\n  <ly>%d</ly>\n  <lz>%d</lz>\n  <lt>%d</lt>\n</ildgFormat>",
-           prec, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.T);                                  // io/utils_write_ildg_format.c:30-43
-  snprintf(chk, sizeof(chk), "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<scidacChecksum>\n  <version>1.0</version>\n  <suma>%08x</suma>\n  <sumb>%08x</sumb>\n</scidacChecksum>",
-           cs[0], cs[1]);                                                                       // io/utils_write_checksum.c:30-35
+           prec, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->g.T * np);                             // io/utils_write_ildg_format.c:30-43
+  const bool have_xlf = xlf_info && xlf_info[0];
+  auto padded = [](unsigned long long n) { return (n + 7) / 8 * 8; };
+  const unsigned long long data_pos = (have_xlf ? 144 + padded(strlen(xlf_info)) : 0) + 144 + padded(strlen(fmt)) + 144;   // where the binary record's data begins
+  FILE *fp = nullptr;
   int bad = 0;
-  if (xlf_info && xlf_info[0]) bad = bad || lime_write_message(fp, 1, 1, "xlf-info", xlf_info);
-  bad = bad || lime_write_message(fp, 1, 0, "ildg-format", fmt);
-  bad = bad || lime_write_header(fp, 0, 0, "ildg-binary-data", bytes) || lime_write_data(fp, buf, bytes);
-  bad = bad || lime_write_message(fp, 0, 1, "scidac-checksum", chk);
+  if (rk == 0) {
+    fp = fopen(filename, "wb");
+    if (!fp) { (void)hipHostFree(buf); TMHIP_FAIL("write_gauge_field: cannot create %s", filename); }
+    if (have_xlf) bad = bad || lime_write_message(fp, 1, 1, "xlf-info", xlf_info);
+    bad = bad || lime_write_message(fp, 1, 0, "ildg-format", fmt);
+    bad = bad || lime_write_header(fp, 0, 0, "ildg-binary-data", bytes);
+    bad = bad || ftell(fp) != (long)data_pos || fflush(fp);
+  }
+  if (np > 1 && sums_combine(ctx, cs)) { if (fp) fclose(fp); (void)hipHostFree(buf); return 1; }   // XOR over the ranks; nobody gets here before rank 0 has created the file
+  if (rk != 0) {
+    fp = fopen(filename, "r+b");
+    if (!fp) { (void)hipHostFree(buf); TMHIP_FAIL("write_gauge_field: rank %d cannot open %s", rk, filename); }
+  }
+  bad = bad || fseek(fp, (long)(data_pos + (unsigned long long)rk * part), SEEK_SET) || (fwrite(buf, 1, part, fp) != part);
+  if (rk == 0) {
+    snprintf(chk, sizeof(chk), "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<scidacChecksum>\n  <version>1.0</version>\n  <suma>%08x</suma>\n  <sumb>%08x</sumb>\n</scidacChecksum>",
+             cs[0], cs[1]);                                                                     // io/utils_write_checksum.c:30-35
+    static const unsigned char zero[8] = {0};
+    bad = bad || fseek(fp, (long)(data_pos + bytes), SEEK_SET);
+    if (!bad && bytes % 8) bad = fwrite(zero, 1, 8 - bytes % 8, fp) != 8 - bytes % 8;
+    bad = bad || lime_write_message(fp, 0, 1, "scidac-checksum", chk);
+  }
   bad = fclose(fp) || bad;
   (void)hipHostFree(buf);
+  if (np > 1) { unsigned done[2] = {bad ? 1u << (rk & 31) : 0u, 0}; if (sums_combine(ctx, done)) return 1; bad = bad || done[0]; }   // every part is in the file (and any rank's error is everybody's)
   if (bad) TMHIP_FAIL("write_gauge_field: error while writing %s", filename);
   if (sums) { sums[0] = cs[0]; sums[1] = cs[1]; }
   return 0;
