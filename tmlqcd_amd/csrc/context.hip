@@ -698,7 +698,7 @@ int tmhip_halo_exchange(tmhip_ctx *ctx) {
     return 0;
   }
   if (!ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
-  if (ctx->shm) TMHIP_FAIL("tmhip_halo_exchange: the shared-memory transport exchanges on the compute stream (launch_split)");
+  if (ctx->shm) return tmhip_shm_ring(ctx, ctx->comm_stream, ctx->send_dn, ctx->send_up, ctx->recv_up, ctx->recv_dn, n * sizeof(double));   // host-staged: copy out, one host function, copy in -- on the comm stream like the RCCL calls below
   const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
   TMHIP_NCCL_CHECK(ncclGroupStart());
   TMHIP_NCCL_CHECK(ncclSend(ctx->send_dn, n, ncclDouble, dn, ctx->comm, ctx->comm_stream));

@@ -1,13 +1,15 @@
 // Host-staged transport of a T-split job whose ranks share a node but not an RCCL communicator: faces, halo slices and scalars
 // travel device -> page-locked host buffer -> a POSIX shared-memory segment -> the neighbour's page-locked buffer -> device.  It is what
 // the reference does with MPI on host memory (xchange/xchange_field.c:98-250: MPI_Isend / MPI_Irecv / MPI_Waitall, linalg/square_norm.c:
-// 299-316: MPI_Allreduce), stream-ordered: every operation is copy-out, ONE host function on the stream, copy-in.  No overlap with the
-// stencil, PCIe both ways: this is not the fast path (RCCL over xGMI is) -- it is the path that needs nothing but the node's memory,
-// and the one that lets several ranks of a job share ONE GPU, i.e. run the multi-rank code as real processes on a one-GPU box
-// (tests/test_gpu_multiprocess.py, bench.py with TMLQCD_BENCH_TRANSPORT=shm).
+// 299-316: MPI_Allreduce), stream-ordered: every operation is copy-out, ONE host function on the stream, copy-in -- a drop-in for the
+// RCCL call at the same place (the faces on the comm stream under the stencil kernel, with the flags of launch_split; everything
+// else on the compute stream).  PCIe both ways: this is not the fast path (RCCL over xGMI is) -- it is the path that needs nothing
+// but the node's memory, and the one that lets several ranks of a job share ONE GPU, i.e. run the multi-rank code, split-phase
+// protocol included, as real processes on a one-GPU box (tests/test_gpu_multiprocess.py, bench.py with TMLQCD_BENCH_TRANSPORT=shm).
 //
-// Everything of a context goes through ONE stream (the compute stream; launch_split's serial form), and every rank issues the same
-// sequence of operations on it, so a host function may simply wait for its neighbours: they are in the same call or on their way to it.
+// Every rank issues the same sequence of operations, so a host function may simply wait for its neighbours: they are in the same call
+// or on their way to it.  The mailboxes carry ONE kind of message at a time: a face exchange runs between the start of its stencil kernel
+// and the exterior kernel, and no ring operation of the compute stream lies in between; the sums use slots of their own.
 // Bounded like every wait of this library (flag_timeout_ms): a dead neighbour becomes an error of the next synchronising call.
 #include "tmhip_internal.h"
 
@@ -49,8 +51,8 @@ struct TmhipShm {
   Header *hdr;
   int nranks, rank;
   size_t mailbox_bytes;
-  unsigned long long sent[2], received[2];   // [0]: to / from the down neighbour, [1]: up
-  unsigned long long red_seq;
+  std::atomic<unsigned long long> sent[2], received[2];   // [0]: to / from the down neighbour, [1]: up (atomics: the host functions of the two streams may run on different threads)
+  std::atomic<unsigned long long> red_seq;
   char *stage_send[2], *stage_recv[2];       // page-locked, mailbox_bytes each
   char *stage_small;                          // page-locked, reductions
   double timeout_s;
@@ -90,22 +92,22 @@ void ring_cb(void *p) {
   for (int dir = 0; dir < 2; dir++) {
     if (!(dir == 0 ? a->to_dn : a->to_up)) continue;
     Mailbox *m = mailbox(s, dir == 0 ? dn : up, dir == 0 ? 1 : 0);
-    const unsigned long long n = s->sent[dir];
+    const unsigned long long n = s->sent[dir].load();
     if (!wait_for(s, [&] { return m->consumed.load(std::memory_order_acquire) == n; })) break;   // the previous message has been taken out
     memcpy((char *)(m + 1), s->stage_send[dir], a->bytes);
     m->bytes = a->bytes;
     m->written.store(n + 1, std::memory_order_release);
-    s->sent[dir] = n + 1;
+    s->sent[dir].store(n + 1);
   }
   for (int dir = 0; dir < 2; dir++) {                  // dir 0: from the up neighbour (our mailbox 1) -> stage_recv[0]; dir 1: from down
     if (!(dir == 0 ? a->from_up : a->from_dn)) continue;
     Mailbox *m = mailbox(s, s->rank, dir == 0 ? 1 : 0);
-    const unsigned long long n = s->received[dir];
+    const unsigned long long n = s->received[dir].load();
     if (!wait_for(s, [&] { return m->written.load(std::memory_order_acquire) == n + 1; })) break;
     if (m->bytes != a->bytes) s->failed.store(2);      // the ranks are not in the same operation
     memcpy(s->stage_recv[dir], (const char *)(m + 1), a->bytes);
     m->consumed.store(n + 1, std::memory_order_release);
-    s->received[dir] = n + 1;
+    s->received[dir].store(n + 1);
   }
   delete a;
 }
@@ -114,7 +116,7 @@ struct GatherArgs { TmhipShm *s; size_t bytes; int reduce_doubles; };   // reduc
 void gather_cb(void *p) {
   GatherArgs *a = (GatherArgs *)p;
   TmhipShm *s = a->s;
-  const unsigned long long seq = ++s->red_seq;
+  const unsigned long long seq = s->red_seq.fetch_add(1) + 1;
   const int par = (int)(seq & 1);
   Slot *mine = slot(s, s->rank, par);
   memcpy(mine->payload, s->stage_small, a->bytes);
