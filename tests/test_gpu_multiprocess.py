@@ -88,3 +88,33 @@ def test_next_rows_as_real_processes(world, tmp_path):
             for kind in ("cg_", "mixed_"):
                 sc = np.abs(one[kind + name]).max()
                 assert np.abs(parts[r][kind + name] - slab(one[kind + name], r)).max() / sc < 1e-6, (kind, name, r)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_random_sequences_between_real_processes(world, tmp_path):
+    """The seeded random operation sequence of test_gpu_split_stress.py (stencils with every epilogue, chains, linalg between them,
+    short cg_her solves, uploads, the benchmark loop) on a 16 x 16^3 lattice cut into `world` slabs, every rank a process that falls
+    behind at random points -- for every form of the split path, slab by slab against the unsplit lattice."""
+    import numpy as np
+    from tests.test_gpu_split_stress import FORMS
+    worker = os.path.join(ROOT, "tests", "mp_stress_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60")
+    seed, nops = 5, 60
+    ref = subprocess.run([sys.executable, worker, "0", "1", "none", str(tmp_path), str(seed), str(nops), "flags"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert ref.returncode == 0, ref.stderr[-3000:]
+    one = np.load(os.path.join(str(tmp_path), "stress_flags_0_of_1.npz"))
+    for form, _ in FORMS:
+        job = "st_%d_%d_%s" % (os.getpid(), world, form.replace(" ", ""))
+        procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), job, str(tmp_path), str(seed), str(nops), form], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+        outs = [p.communicate(timeout=400) for p in procs]
+        for p, (so, se) in zip(procs, outs):
+            assert p.returncode == 0, (form, se[-3000:])
+        for r in range(world):
+            part = np.load(os.path.join(str(tmp_path), "stress_%s_%d_of_%d.npz" % (form.replace(" ", "_"), r, world)))
+            assert len(part["scal"]) == len(one["scal"]) and np.allclose(part["scal"], one["scal"], rtol=1e-11, atol=1e-11), (form, r)
+            for i in range(5):
+                full = one["f%d" % i]
+                n = full.shape[0] // world
+                dev = np.abs(part["f%d" % i] - full[r * n:(r + 1) * n]).max() / np.abs(full).max()
+                assert dev < 1e-11, (form, r, i, dev)

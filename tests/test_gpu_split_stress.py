@@ -16,13 +16,19 @@ T, L = 8, 16          # faces are a quarter of the local volume; face % 64 == 0 
 NF = 5
 
 
-def _run(lat, seed, nops, split):
-    """The sequence on one lattice; returns the final fields and the scalars computed on the way."""
+def _run(lat, seed, nops, split, gen=None, skew=None):
+    """The sequence on one lattice; returns the final fields and the scalars computed on the way.  gen(tag): this rank's slab of the
+    global random field `tag` (several ranks: tests/mp_stress_worker.py); skew(step): called before every operation."""
     rng = np.random.default_rng(seed)
     N = lat.Vh
-    f = [lat.field(random_spinor(100 + i, N)) for i in range(NF)]
+    if gen is None:
+        def gen(tag):
+            return random_spinor(tag, N)
+    f = [lat.field(gen(100 + i)) for i in range(NF)]
     scal = []
     for step in range(nops):
+        if skew:
+            skew(step)
         op = int(rng.integers(0, 13))
         a, b, c = (int(x) for x in rng.choice(NF, size=3, replace=False))
         ieo = int(rng.integers(0, 2))
@@ -58,15 +64,15 @@ def _run(lat, seed, nops, split):
                 lat.Hopping_Matrix_nocom(ieo, f[a], f[b])      # stale faces: not comparable, ...
             lat.Hopping_Matrix(ieo, f[a], f[b])                # ... overwritten at once; what it did to the buffers must not matter
         elif op == 11:
-            f[a].upload(random_spinor(1000 + step, N))         # the host rewrites a field that may have been a stencil output
+            f[a].upload(gen(1000 + step))                      # the host rewrites a field that may have been a stencil output
         else:
             lat.bench_hopping(f[a], f[b], f[c], 2)             # the benchmark loop: every second stencil gathers the previous output
         # keep the numbers O(1): the operators have norm < 1 but the axpys can grow
         if step % 7 == 6:
             for g in f:
-                n = lat.square_norm(g, N, 1)
+                n = lat.square_norm(g, N, 1)               # (global sum: the same number on every rank)
                 if n > 0:
-                    lat.mul_r(g, 1.0 / np.sqrt(n / N), g, N)
+                    lat.mul_r(g, 1.0 / np.sqrt(n / (N * lat.nproc_t)), g, N)
     lat.sync()
     out = [g.download() for g in f]
     for g in f:
