@@ -29,10 +29,25 @@ su3 *stub_init(int T_, int LX_, int LY_, int LZ_) {
   g_update_gauge_copy = 1;
   return gauge_block;
 }
+/* one rank of a T-split job (PARALLELT: mpi_init.c:240-242,330-332): RAND = the two halo time-slices, t = T first, then t = -1
+ * (geometry_eo.c:292-299); the caller fills them like xchange_gauge would */
+su3 *stub_init_rank(int T_, int LX_, int LY_, int LZ_, int nproc_t, int proc_t) {
+  su3 *p;
+  g_nproc_t = nproc_t; g_proc_coords[0] = proc_t;
+  T = T_; LX = LX_; LY = LY_; LZ = LZ_;
+  VOLUME = T * LX * LY * LZ; RAND = nproc_t > 1 ? 2 * LX * LY * LZ : 0; VOLUMEPLUSRAND = VOLUME + RAND;
+  free(gauge_block); free(g_gauge_field);
+  gauge_block = (su3 *)calloc(4 * (size_t)VOLUMEPLUSRAND + 1, sizeof(su3));
+  g_gauge_field = (su3 **)calloc(VOLUMEPLUSRAND, sizeof(su3 *));
+  for (int i = 0; i < VOLUMEPLUSRAND; i++) g_gauge_field[i] = gauge_block + 4 * (size_t)i;
+  g_update_gauge_copy = 1;
+  p = gauge_block;
+  return p;
+}
 void stub_boundary(double kappa, double x0, double x1, double x2, double x3) {
   const double PI_ = 3.14159265358979;
   g_kappa = kappa;
-  ka0 = kappa * cexp(x0 * PI_ / T * I); ka1 = kappa * cexp(x1 * PI_ / LX * I);
+  ka0 = kappa * cexp(x0 * PI_ / (T * g_nproc_t) * I); ka1 = kappa * cexp(x1 * PI_ / LX * I);
   ka2 = kappa * cexp(x2 * PI_ / LY * I); ka3 = kappa * cexp(x3 * PI_ / LZ * I);
 }
 void stub_set_mu(double mu) { g_mu = mu; }

@@ -118,3 +118,37 @@ def test_random_sequences_between_real_processes(world, tmp_path):
                 n = full.shape[0] // world
                 dev = np.abs(part["f%d" % i] - full[r * n:(r + 1) * n]).max() / np.abs(full).max()
                 assert dev < 1e-11, (form, r, i, dev)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_drop_in_symbols_on_t_split_ranks(world, tmp_path):
+    """The reference-named symbols on a T-split lattice, every rank a host process with tmLQCD's own globals (g_nproc_t,
+    g_proc_coords, RAND halo slices of g_gauge_field): Hopping_Matrix, Qtm_pm_psi, square_norm / scalar_prod_r with parallel = 1
+    (and 0: the local sum), cg_her -- in coherent and in lazy residency -- slab by slab against the unsplit host program."""
+    import numpy as np
+    worker = os.path.join(ROOT, "tests", "mp_dropin_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60")
+    ref = subprocess.run([sys.executable, worker, "0", "1", "none", str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert ref.returncode == 0, ref.stderr[-3000:]
+    job = "di_%d_%d" % (os.getpid(), world)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), job, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=400) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    one = np.load(os.path.join(str(tmp_path), "dropin_0_of_1.npz"))
+    parts = [np.load(os.path.join(str(tmp_path), "dropin_%d_of_%d.npz" % (r, world))) for r in range(world)]
+    for tag in ("coherent", "lazy"):
+        for key in ("_hop", "_qtm", "_cg"):
+            full = one[tag + key]
+            n = full.shape[0] // world
+            for r in range(world):
+                tol = 1e-8 if key == "_cg" else 1e-13
+                assert np.abs(parts[r][tag + key] - full[r * n:(r + 1) * n]).max() / np.abs(full).max() < tol, (tag, key, r)
+        local = 0.0
+        for r in range(world):
+            assert np.allclose(parts[r][tag + "_sums"][:2], one[tag + "_sums"][:2], rtol=1e-13), (tag, r)      # global sums on every rank
+            assert abs(int(parts[r][tag + "_it"][0]) - int(one[tag + "_it"][0])) <= 1
+            local += parts[r][tag + "_sums"][2]
+        assert abs(local - one[tag + "_sums"][2]) <= 1e-13 * one[tag + "_sums"][2]                             # parallel = 0: each rank its own part
+        assert np.array_equal(parts[0]["lazy_hop"], parts[0]["coherent_hop"])

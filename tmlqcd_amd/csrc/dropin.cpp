@@ -69,6 +69,7 @@ struct Mirror {
   int prot = 0;             // P_RW: untouched; P_RO: both copies current, a host store must be noticed; P_NONE: the host copy is stale
   std::vector<unsigned char> page_ok;   // P_NONE: pages of the span already brought up to date one by one
   int faults = 0;           // page-wise read synchronisations since the device last wrote the field
+  bool nowatch = false;     // lazy mode: this array lies inside the malloc heap -- never protected, handled like the coherent mode handles it
 };
 enum { P_RW = 0, P_RO = 1, P_NONE = 2 };
 unsigned long long g_tick = 0;
@@ -427,6 +428,34 @@ bool mapping_replaced(const void *host, const Mirror &m) {
   return false;
 }
 
+// Lazy mode cannot watch an array that lives INSIDE the malloc heap: its pages also hold the allocator's own bookkeeping (the headers of
+// the neighbouring chunks) and whatever else the program keeps there, and the fault handler itself allocates -- a protected heap page
+// ends in a fault inside the handler.  glibc serves a request from the heap whenever a free chunk fits, whatever M_MMAP_THRESHOLD says
+// (a 200 KB numpy array in a process that has freed a few MB), so the threshold alone is no guarantee.  Such arrays are simply not
+// watched: they are copied on every call, as in the coherent mode.  The heap is the "[heap]" mapping of /proc/self/maps (the main
+// arena; tmLQCD's fields -- one calloc of hundreds of MB -- are mappings of their own and never fall in it).
+bool in_malloc_heap(const void *host, size_t bytes) {
+  static uintptr_t lo = 0, hi = 0;
+  const uintptr_t a = (uintptr_t)host, b = a + bytes;
+  const uintptr_t brk_now = (uintptr_t)sbrk(0);
+  if (hi != brk_now || !lo) {          // (first call, or the heap has grown / shrunk)
+    lo = hi = 0;
+    if (FILE *fp = fopen("/proc/self/maps", "r")) {
+      char line[512];
+      while (fgets(line, sizeof(line), fp)) {
+        if (!strstr(line, "[heap]")) continue;
+        unsigned long x = 0, y = 0;
+        if (sscanf(line, "%lx-%lx", &x, &y) == 2) { lo = x; hi = y; }
+        break;
+      }
+      fclose(fp);
+    }
+    if (!lo) { lo = 1; hi = 0; }        // no heap mapping at all
+    if (hi < brk_now && lo > 1) hi = brk_now;
+  }
+  return lo > 1 && a < hi && b > lo;
+}
+
 Mirror &mirror(tmhip_ctx *c, const void *host, int kind, int n = 0) {
   RegLock lk;
   const size_t bytes = (size_t)(kind == KIND_LIN ? n : nsites(kind)) * sizeof(spinor);
@@ -460,6 +489,7 @@ Mirror &mirror(tmhip_ctx *c, const void *host, int kind, int n = 0) {
     CK(tmhip_field_alloc(c, kind == KIND_LIN ? TMHIP_FIELD_FULL : kind, &m.f));
     m.kind = kind; m.n = n; m.dev_valid = false; m.host_valid = true; m.bytes = bytes; m.prot = P_RW;
   }
+  if (g_mode == TMLQCD_HIP_LAZY && m.prot == P_RW) m.nowatch = in_malloc_heap(host, bytes);   // (decided while the array is unwatched; the heap may have grown over a recycled address)
   m.last_use = ++g_tick;   // after the reset above: a mirror in use by the current call must never be the eviction victim of its sibling
   return m;
 }
@@ -467,12 +497,13 @@ Mirror &mirror(tmhip_ctx *c, const void *host, int kind, int n = 0) {
 tmhip_field *in(tmhip_ctx *c, const void *host, int kind, int n = 0) {
   RegLock lk;   // a mirror's state changes under the lock too: the fault handler reads it on other threads
   Mirror &m = mirror(c, host, kind, n);
-  if (g_mode == TMLQCD_HIP_COHERENT || !m.dev_valid) {
+  const bool copy_always = g_mode == TMLQCD_HIP_COHERENT || (g_mode == TMLQCD_HIP_LAZY && m.nowatch);
+  if (copy_always || !m.dev_valid) {
     if (!(m.dev_valid && !m.host_valid))   // never overwrite newer device data with a stale host copy
       upload(c, host, m);
     m.dev_valid = true;
   }
-  if (g_mode == TMLQCD_HIP_LAZY && m.host_valid && m.prot == P_RW) set_prot(host, m, P_RO, g_reg);   // the mirror stays good until the host stores to the array
+  if (g_mode == TMLQCD_HIP_LAZY && !m.nowatch && m.host_valid && m.prot == P_RW) set_prot(host, m, P_RO, g_reg);   // the mirror stays good until the host stores to the array
   return m.f;
 }
 
@@ -482,7 +513,7 @@ void done(tmhip_ctx *c, const void *host) {
   RegLock lk;
   Mirror &m = g_reg[host];
   m.dev_valid = true; m.host_valid = false;
-  if (g_mode == TMLQCD_HIP_COHERENT) {
+  if (g_mode == TMLQCD_HIP_COHERENT || (g_mode == TMLQCD_HIP_LAZY && m.nowatch)) {
     download(c, host, m);
     m.dev_valid = false;   // coherent mode: the host copy is the truth (it may be rewritten or its address recycled)
   } else if (g_mode == TMLQCD_HIP_LAZY) {
@@ -498,6 +529,8 @@ void lazy_fault(int sig, siginfo_t *si, void *uctx) {
   // that changes the registry: one at a time in here, under the registry's lock.  A fault of the thread that already is in the
   // handler would be a bug of this handler: let it crash instead of recursing.
   const bool nested = in_handler_here();
+  static const bool trace = getenv("TMLQCD_HIP_LAZY_DEBUG") != nullptr && atoi(getenv("TMLQCD_HIP_LAZY_DEBUG")) > 1;
+  if (trace) { char m[128]; const int n = snprintf(m, sizeof(m), "[lazy] fault %p %s enter\n", si->si_addr, (((ucontext_t *)uctx)->uc_mcontext.gregs[REG_ERR] & 2) ? "store" : "load"); (void)!write(2, m, (size_t)n); }
   if (g_ctx && si->si_code == SEGV_ACCERR && !nested) {
     RegLock lk;
     g_handler_thread.store((uintptr_t)pthread_self(), std::memory_order_relaxed);
@@ -538,7 +571,18 @@ void lazy_fault(int sig, siginfo_t *si, void *uctx) {
     if (ours) { g_lazy_stats[0]++; mprotect((void *)page, g_page, prot_flags(page_need(page, g_reg))); }
     g_handler_thread.store(0, std::memory_order_relaxed);
   }
+  if (trace) { char m[64]; const int n = snprintf(m, sizeof(m), "[lazy] fault %p leave ours=%d\n", si->si_addr, (int)ours); (void)!write(2, m, (size_t)n); }
   if (ours) return;                                  // the faulting instruction runs again
+  {
+    // TMLQCD_HIP_LAZY_DEBUG=1: say what is being passed on (the program's own crash, or a bug of this handler) before the next handler sees it
+    static const bool dbg = getenv("TMLQCD_HIP_LAZY_DEBUG") != nullptr;
+    if (dbg) {
+      char msg[256];
+      const int n = snprintf(msg, sizeof(msg), "[tmlqcd_dropin] SIGSEGV at %p (si_code %d, %s) is not on a watched page of %zu mirrors%s: passed on\n", si->si_addr,
+                             si->si_code, (((ucontext_t *)uctx)->uc_mcontext.gregs[REG_ERR] & 2) ? "store" : "load", g_reg.size(), nested ? ", raised inside this handler" : "");
+      if (n > 0) (void)!write(2, msg, (size_t)n);
+    }
+  }
   if (g_old_segv.sa_flags & SA_SIGINFO) { if (g_old_segv.sa_sigaction) { g_old_segv.sa_sigaction(sig, si, uctx); return; } }
   else if (g_old_segv.sa_handler != SIG_DFL && g_old_segv.sa_handler != SIG_IGN) { g_old_segv.sa_handler(sig); return; }
   signal(SIGSEGV, SIG_DFL);                          // not ours, nobody else's: die the ordinary way when the instruction faults again
@@ -552,6 +596,7 @@ void install_lazy_handler() {
   // them back by munmap, but RAISES the threshold to the size of every mmap'ed block it frees (up to 32 MB): a second work field
   // of the same size would then come from the heap.  Setting the threshold explicitly switches that adjustment off, so every
   // field-sized block stays an mmap of its own (and a freed one is recognised by mapping_replaced / host_unmapped).
+  // (Not a guarantee -- a request is still served from the heap when a free chunk fits: in_malloc_heap() keeps such arrays unwatched.)
   mallopt(M_MMAP_THRESHOLD, 128 * 1024);
   struct sigaction sa;
   memset(&sa, 0, sizeof(sa));
@@ -1413,7 +1458,12 @@ double tmlqcd_hip_benchmark_loop(spinor *f0, spinor *f1, spinor *f2, int iters) 
   g_reg[f2].dev_valid = true; g_reg[f2].host_valid = false;
   g_mode = saved;
   if (g_mode == TMLQCD_HIP_COHERENT) { tmlqcd_hip_sync_to_host(f1); tmlqcd_hip_sync_to_host(f2); }
-  if (g_mode == TMLQCD_HIP_LAZY) { set_prot(f1, g_reg[f1], P_NONE, g_reg); set_prot(f2, g_reg[f2], P_NONE, g_reg); }
+  if (g_mode == TMLQCD_HIP_LAZY)
+    for (spinor *f : {f1, f2}) {
+      Mirror &m = g_reg[f];
+      if (m.nowatch) { download(c, f, m); m.dev_valid = false; }   // (an array inside the malloc heap: copied, never watched)
+      else set_prot(f, m, P_NONE, g_reg);
+    }
   return ms * 1e-3;
 }
 
