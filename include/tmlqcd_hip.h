@@ -324,11 +324,13 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "split_early" 0 (default) | 1: T-split ranks -- the boundary time-slices are dispatched last and take the hop across the cut inside the stencil kernel
  *                when the faces have already arrived (one look at the flag, never a wait); what came too early is left to the exterior kernel.
  *                +3-4 % with a copy-engine-like exchange, neutral to -1 % behind RCCL's kernels, which start late (profiles/r03_split_early_ab.log)
- *   "split_pipe" 0 (default) | 1 | 2: T-split ranks -- the boundary time-slices are dispatched FIRST; a stencil whose faces are not there yet has its
+ *   "split_pipe" -1 (default: automatic) | 0 | 1 | 2: T-split ranks -- the boundary time-slices are dispatched FIRST; a stencil whose faces are not there yet has its
  *                exterior kernel run on the comm stream beside the remaining slices, and the faces of the NEXT stencil of a chain (Qtm_pm_psi, a CG
  *                iteration, the benchmark loop) are exchanged while the current one is still running, so that one takes all eight hops inline with
  *                no exterior kernel.  Behind RCCL 32 x 32^3: 90-92 -> 95-97 % of the unsplit rate, 16 x 32^3 85 -> 88 %; loses on grids the chip holds
- *                at once (1 applies it from 262144 sites per parity up, 2 always) and with plain device-to-device copies (profiles/r03_split_forms.md)
+ *                at once and with plain device-to-device copies (profiles/r03_split_forms.md).  -1: on where it wins -- faces carried by RCCL, local
+ *                lattice of 262144 sites per parity or more; 1: that size rule whatever carries the faces; 2: always; 0: never.  An exchange ahead is
+ *                never in flight together with a collective of the compute stream (the compute stream waits for it first)
  *   "prepack" 1 (default) | 0: T-split ranks -- the exterior kernel also projects the completed boundary slices of its output into the send buffers, so
  *                the next stencil of a chain (Qtm_pm_psi, a fused CG iteration) starts its exchange without a pack kernel
  *   "flag_timeout_ms" bound of those device-side waits (default 120 s, or TMLQCD_HIP_FLAG_TIMEOUT_S in the environment; 0 = none): a late

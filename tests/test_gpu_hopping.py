@@ -140,7 +140,7 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, early):
         lat.set_option("split_sync", 0)
         lat.set_option("prepack", 1)
         lat.set_option("split_early", 0)
-        lat.set_option("split_pipe", 0)
+        lat.set_option("split_pipe", -1)
     dk.free(); dl.free()
 
 

@@ -941,6 +941,7 @@ int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_
   if (np > 1) {
     const size_t n = (size_t)2 * 30 * ctx->g.LX * ctx->g.LY * ctx->g.LZ;   // doubles per slice of insertion matrices
     double *snd = (double *)ctx->swpm_halo_send, *rcv = (double *)ctx->swpm_halo_recv;
+    if (tmhip_comm_quiesce(ctx)) return 1;
     if (ctx->shm) { if (tmhip_shm_ring(ctx, ctx->stream, snd, snd + n, rcv, rcv + n, n * sizeof(double))) return 1; }
     else {
     TMHIP_NCCL_CHECK(ncclGroupStart());

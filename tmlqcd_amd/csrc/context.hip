@@ -146,7 +146,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
-  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_split_early = 0;
+  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_split_early = 0; ctx->opt_split_pipe = -1;
   {
     // bound of the device-side waits for the neighbours' faces: TMLQCD_HIP_FLAG_TIMEOUT_S in the environment (0 = none), default 120 s
     double sec = 120.0;
@@ -302,7 +302,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "flag_timeout_ms")) { if (value < 0) TMHIP_FAIL("flag_timeout_ms must be >= 0 (0 = wait without bound)"); ctx->flag_timeout_ticks = (unsigned long long)value * 100000ull; }
   else if (!strcmp(name, "split_early")) { ctx->opt_split_early = value != 0; ctx->prepacked = nullptr; }
   else if (!strcmp(name, "prepack")) { ctx->opt_prepack = value != 0; ctx->prepacked = nullptr; }
-  else if (!strcmp(name, "split_pipe")) { if (value < 0 || value > 2) TMHIP_FAIL("split_pipe must be 0 (off), 1 (local lattices of >= 262144 sites per parity) or 2 (every size)"); ctx->opt_split_pipe = value; ctx->prepacked = nullptr; ctx->ahead_field = nullptr; }
+  else if (!strcmp(name, "split_pipe")) { if (value < -1 || value > 2) TMHIP_FAIL("split_pipe must be -1 (automatic), 0 (off), 1 (local lattices of >= 262144 sites per parity) or 2 (every size)"); ctx->opt_split_pipe = value; ctx->prepacked = nullptr; ctx->ahead_field = nullptr; }
   else if (!strcmp(name, "comm_split")) { if (ctx->comm_ready) TMHIP_FAIL("comm_split must be set before the communicator is created"); ctx->opt_comm_split = value != 0; }
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
   else if (!strcmp(name, "gauge_cache")) { if (value < -1 || value > 1) TMHIP_FAIL("gauge_cache must be -1 (automatic), 0 or 1"); ctx->opt_gauge_cache = value; }

@@ -112,6 +112,7 @@ struct tmhip_ctx {
   // [5] exterior kernel of stencil n done (it runs on the comm stream).  ahead_field: the field whose faces have been exchanged AHEAD of the
   // stencil that will gather it (complete once sync_flags[1] >= ahead_seq); bcount_total: waves counted in [4] so far
   const void *ahead_field; unsigned int ahead_seq; unsigned int bcount_total;
+  unsigned int quiesced_seq;                       // the exchange ahead with this sequence number has been waited for on the compute stream (tmhip_comm_quiesce)
   int last_ext_partials;                           // partial sums the last split-phase stencil's exterior kernel wrote in front of the stencil kernel's (0: it had none)
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
   double *deriv;
@@ -156,6 +157,12 @@ static inline int tmhip_hop_block(const tmhip_ctx *ctx) { return ctx->opt_block 
 // Reductions go through RCCL on T-split ranks -- and in the one-rank RCCL loopback (tmhip_comm_set_loopback(ctx, 2)), so that the
 // multi-rank code path (partial sums, ncclAllReduce, scalar update as separate steps) runs in the single-GPU tests too.
 static inline bool tmhip_reduce_over_ranks(const tmhip_ctx *ctx) { return ctx->comm_ready && (ctx->g.nproc_t > 1 || ctx->loopback_rccl); }
+
+// "split_pipe": an exchange of faces AHEAD (comm stream) may still be in flight when the compute stream reaches an RCCL collective -- two
+// communicators at work at once, which RCCL allows only while every rank submits in the same order and the kernels can co-reside.  Called in
+// front of every compute-stream RCCL call: the compute stream first waits for the exchange ahead (a one-wave kernel, only when one is
+// outstanding), so that also with this option a face exchange is never in flight together with a collective of the compute stream.
+int tmhip_comm_quiesce(tmhip_ctx *ctx);
 
 // ---- host-staged shared-memory transport (xfer_shm.hip): stream-ordered ring exchange / sum / gather over the ranks of the node ----
 void tmhip_shm_destroy(tmhip_ctx *ctx);
