@@ -152,3 +152,33 @@ def test_drop_in_symbols_on_t_split_ranks(world, tmp_path):
             local += parts[r][tag + "_sums"][2]
         assert abs(local - one[tag + "_sums"][2]) <= 1e-13 * one[tag + "_sums"][2]                             # parallel = 0: each rank its own part
         assert np.array_equal(parts[0]["lazy_hop"], parts[0]["coherent_hop"])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_md_trajectory_between_real_processes(world, tmp_path):
+    """A leapfrog trajectory of the clover determinant with the lattice cut into `world` processes (tests/mp_md_worker.py): after four
+    steps the links and momenta of every rank are the unsplit trajectory's slab, the action agrees, and the trajectory is reversible
+    -- the link halo, the stencil copy and the clover term are refreshed from the neighbours after every update_gauge."""
+    import numpy as np
+    worker = os.path.join(ROOT, "tests", "mp_md_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60")
+    ref = subprocess.run([sys.executable, worker, "0", "1", "none", str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+    assert ref.returncode == 0, ref.stderr[-3000:]
+    job = "md_%d_%d" % (os.getpid(), world)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), job, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=500) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    one = np.load(os.path.join(str(tmp_path), "md_0_of_1.npz"))
+    for r in range(world):
+        part = np.load(os.path.join(str(tmp_path), "md_%d_of_%d.npz" % (r, world)))
+        for key in ("links", "momenta"):
+            full = one[key]
+            n = full.shape[0] // world
+            dev = np.abs(part[key] - full[r * n:(r + 1) * n]).max() / np.abs(full).max()
+            assert dev < 1e-10, (key, r, dev)
+        assert abs(part["action"][0] - one["action"][0]) <= 1e-10 * abs(one["action"][0])
+        assert abs(int(part["iters"][0]) - int(one["iters"][0])) <= 12          # (a dozen solves, +-1 iteration each)
+        assert np.abs(part["back"]).max() < 1e-9
+    assert np.abs(one["back"]).max() < 1e-9
