@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 faulthandler.enable()
-faulthandler.dump_traceback_later(int(os.environ.get("MP_WORKER_TIMEOUT", "200")), exit=True)
+faulthandler.dump_traceback_later(int(os.environ.get("MP_WORKER_TIMEOUT", "240")), exit=True)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests.test_gpu_md_trajectory import EO, CloverDetTrajectory  # noqa: E402

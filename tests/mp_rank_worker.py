@@ -11,7 +11,7 @@ import faulthandler
 import numpy as np
 
 faulthandler.enable()
-faulthandler.dump_traceback_later(int(os.environ.get("MP_WORKER_TIMEOUT", "150")), exit=True)     # a hung rank says where, and ends
+faulthandler.dump_traceback_later(int(os.environ.get("MP_WORKER_TIMEOUT", "240")), exit=True)     # a hung rank says where, and ends
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
