@@ -281,6 +281,17 @@ int tmhip_comm_init(tmhip_ctx *ctx, const char id[TMHIP_UNIQUE_ID_BYTES]); /* ri
  * the node's memory and lets several ranks share one GPU (how the multi-rank code is tested as real processes on a one-GPU box).
  * Collective over the ranks; replaces tmhip_comm_init for this context.  Sums are added in rank order: the same bits on every rank. */
 int tmhip_comm_init_shm(tmhip_ctx *ctx, const char *job);
+/* The direct face carrier, on top of either ring (collective, after tmhip_comm_init / tmhip_comm_init_shm): every rank maps its two
+ * neighbours' receive buffers (hipIpcGetMemHandle / hipIpcOpenMemHandle; the handles travel over the communicator the context has) and
+ * the kernels that produce the projected half-spinor faces store them straight into the neighbour's memory -- over xGMI between GPUs,
+ * through the mapping between processes that share a GPU.  It replaces the MPI_Isend / MPI_Irecv / MPI_Waitall of
+ * xchange/xchange_halffield.c:176-263 (operator/halfspinor_body.c:281-317) for the faces; sums and the other halos stay on the
+ * communicator.  No copy, no kernel of a communication library, nothing on the receiver's compute units; on lattices whose boundary
+ * waves fit the wait budget a stencil of a T-split rank is ONE kernel ("direct_form").  Non-zero (and the faces stay on the communicator,
+ * on EVERY rank) when some rank cannot map a neighbour. */
+int tmhip_comm_init_ipc(tmhip_ctx *ctx);
+/* 1 when the faces travel as direct stores (0: over the communicator); *sharers (may be NULL): ranks of the job on this rank's GPU */
+int tmhip_comm_faces_direct(tmhip_ctx *ctx, int *sharers);
 /* tmhip_comm_init builds TWO communicators over the same ranks: one for the half-spinor faces (second HIP stream), one
  * (ncclCommSplit of the first) for the scalar all-reduces of the linalg (MPI_Allreduce in linalg/square_norm.c:314) and the
  * force halos on the main stream.  Ranks in each as RCCL reports them (ncclCommCount); 0, 0 before tmhip_comm_init. */
@@ -290,7 +301,8 @@ int tmhip_comm_count(tmhip_ctx *ctx, int *nranks_faces, int *nranks_reduce);
 int tmhip_comm_is_split(tmhip_ctx *ctx);
 /* Single-GPU self-test of the split-phase path: faces are packed, "exchanged"
  * with this rank itself and consumed by the exterior kernel.  on = 1: device-to-device
- * copies; on = 2: through a one-rank RCCL communicator (ncclSend/ncclRecv to self). */
+ * copies; on = 2: through a one-rank RCCL communicator (ncclSend/ncclRecv to self); on = 3: the direct carrier onto
+ * oneself (the neighbours' receive buffers are this rank's own). */
 int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on);
 /* Test hook: holds the comm stream back for `ms` milliseconds (<= 20000) in front of the next thing enqueued on it, i.e. the next halo
  * exchange -- what a late neighbour looks like from this rank (xchange_field's MPI_Waitall simply waits, xchange/xchange_field.c:98-250;
@@ -321,16 +333,19 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "split_sync" 0 (default) | 1: T-split ranks -- 0: the exterior kernel (main stream) and the pack kernel (comm stream) wait on the device for a
  *                flag of the other stream; 1: the two streams are ordered by HIP events, no wait on the device at all (slower: two events on the
  *                main stream per stencil)
- *   "split_early" 0 (default) | 1: T-split ranks -- the boundary time-slices are dispatched last and take the hop across the cut inside the stencil kernel
- *                when the faces have already arrived (one look at the flag, never a wait); what came too early is left to the exterior kernel.
- *                +3-4 % with a copy-engine-like exchange, neutral to -1 % behind RCCL's kernels, which start late (profiles/r03_split_early_ab.log)
- *   "split_pipe" -1 (default: automatic) | 0 | 1 | 2: T-split ranks -- the boundary time-slices are dispatched FIRST; a stencil whose faces are not there yet has its
+ *   "split_pipe" 0 (default) | 1 | 2: T-split ranks -- the boundary time-slices are dispatched FIRST; a stencil whose faces are not there yet has its
  *                exterior kernel run on the comm stream beside the remaining slices, and the faces of the NEXT stencil of a chain (Qtm_pm_psi, a CG
  *                iteration, the benchmark loop) are exchanged while the current one is still running, so that one takes all eight hops inline with
- *                no exterior kernel.  Behind RCCL 32 x 32^3: 90-92 -> 95-97 % of the unsplit rate, 16 x 32^3 85 -> 88 %; loses on grids the chip holds
- *                at once and with plain device-to-device copies (profiles/r03_split_forms.md).  -1: on where it wins -- faces carried by RCCL, local
- *                lattice of 262144 sites per parity or more; 1: that size rule whatever carries the faces; 2: always; 0: never.  An exchange ahead is
- *                never in flight together with a collective of the compute stream (the compute stream waits for it first)
+ *                no exterior kernel.  Behind a ONE-rank RCCL communicator 32 x 32^3: 90-92 -> 95-97 % of the unsplit rate, 16 x 32^3 85 -> 88 %; loses
+ *                on grids the chip holds at once and with plain device-to-device copies (profiles/r03_split_forms.md).  1: local lattices of 262144
+ *                sites per parity or more; 2: always.  Off by default until it has run between two RCCL ranks.  An exchange ahead is never in flight
+ *                together with a collective of the compute stream (the compute stream waits for it first)
+ *   "direct_form" -1 (default) | 0 | 1: the direct carrier (tmhip_comm_init_ipc) -- 1: one kernel per stencil (the boundary waves wait for their
+ *                neighbour's word after their seven local hops, add the hop across the cut, project their output and store the projection into the
+ *                neighbour's buffer); 0: stencil kernel + exterior kernel (which waits and pushes); -1: one kernel while the boundary waves of a
+ *                launch are at most 1024 / (ranks sharing this GPU)
+ *   "direct_order" bit 0 / bit 1: one-kernel form -- boundary time-slices dispatched first (else last) in a stencil whose faces are packed now /
+ *                were pushed ahead by the stencil before (default 2)
  *   "prepack" 1 (default) | 0: T-split ranks -- the exterior kernel also projects the completed boundary slices of its output into the send buffers, so
  *                the next stencil of a chain (Qtm_pm_psi, a fused CG iteration) starts its exchange without a pack kernel
  *   "flag_timeout_ms" bound of those device-side waits (default 120 s, or TMLQCD_HIP_FLAG_TIMEOUT_S in the environment; 0 = none): a late

@@ -74,12 +74,15 @@ def test_fused_epilogues(setup16, ieo):
         f.free()
 
 
-@pytest.mark.parametrize("mode,split_sync,prepack,early", [(1, 0, 1, 0), (2, 0, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (1, 0, 0, 0), (2, 1, 0, 0), (1, 0, 1, 1), (2, 0, 1, 1), (1, 0, 1, 2), (2, 0, 1, 2)])
-def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, early):
+@pytest.mark.parametrize("mode,split_sync,prepack,form", [(1, 0, 1, 0), (2, 0, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (1, 0, 0, 0), (2, 1, 0, 0), (1, 0, 1, 2), (2, 0, 1, 2),
+                                                          (3, 0, 1, "one/0"), (3, 0, 1, "one/1"), (3, 0, 1, "one/2"), (3, 0, 1, "one/3"), (3, 0, 1, "two/0")])
+def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, form):
     """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self, the stencil over all sites with the hop
-    across the cut taken from the received faces -- inside the stencil kernel behind a flag (split_sync 0, default) or by the
-    exterior kernel behind a HIP event (1) -- must equal the plain periodic stencil.  prepack 1 (default): the stencils of a chain
-    (Qtm_pm_psi below) take their faces from the previous stencil's exterior kernel instead of a pack kernel."""
+    across the cut added by the exterior kernel -- behind a flag (split_sync 0, default) or behind a HIP event (1) -- must equal the
+    plain periodic stencil.  prepack 1 (default): the stencils of a chain (Qtm_pm_psi below) take their faces from the previous
+    stencil's exterior kernel instead of a pack kernel.  form 2: "split_pipe".  mode 3: the direct carrier onto oneself (the
+    producing waves store the faces into the receiver's buffers): "one/<order>" = one kernel per stencil, boundary waves wait for
+    their neighbour's word, with every dispatch order of the boundary slices; "two/0" = stencil + exterior kernel."""
     orc, lat = setup16
     N = orc.Vh
     k = random_spinor(31, N)
@@ -87,9 +90,11 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, early):
     dk, dl = lat.field(k), lat.field()
     lat.set_option("split_sync", split_sync)
     lat.set_option("prepack", prepack)
-    lat.set_option("split_early", 1 if early == 1 else 0)   # boundary slices last; they take the hop across the cut themselves if the faces are already there
-    lat.set_option("split_pipe", 2 if early == 2 else 0)    # boundary slices first, exterior kernel beside the stencil kernel, faces of a chain exchanged ahead
-    lat.set_loopback(mode)  # 1: D2D copies, 2: one-rank RCCL communicator (ncclSend/Recv to self)
+    lat.set_option("split_pipe", 2 if form == 2 else 0)    # boundary slices first, exterior kernel beside the stencil kernel, faces of a chain exchanged ahead
+    if mode == 3:
+        lat.set_option("direct_form", 1 if form.startswith("one") else 0)
+        lat.set_option("direct_order", int(form.split("/")[1]))
+    lat.set_loopback(mode)  # 1: D2D copies, 2: one-rank RCCL communicator (ncclSend/Recv to self), 3: direct stores into "the neighbour's" buffers
     try:
         for rep in range(3):       # repeated calls re-use the face buffers: a stale-cache bug would show here
             for ieo in (0, 1):
@@ -139,8 +144,8 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, early):
         lat.set_loopback(0)
         lat.set_option("split_sync", 0)
         lat.set_option("prepack", 1)
-        lat.set_option("split_early", 0)
-        lat.set_option("split_pipe", -1)
+        lat.set_option("split_pipe", 0)
+        lat.set_option("direct_form", -1); lat.set_option("direct_order", 2)
     dk.free(); dl.free()
 
 

@@ -161,7 +161,7 @@ def test_fused_cg_on_a_t8_rank_of_32_cubed():
     it0, h0 = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
     ref = dp.download()
     assert it0 > 0
-    for loop in (1, 2):
+    for loop in (1, 2, 3):
         lat.set_loopback(loop)
         dp.zero()
         it, h = lat.cg_her(dp, dq, 500, 1e-20, 1, N)

@@ -2,7 +2,7 @@
 epilogue, compositions (chains), linalg kernels that rewrite fields between stencils, short cg_her solves, communication-free
 stencils (whose output is stale by construction and overwritten afterwards), uploads, and a comm stream that is held back at random
 points (a neighbour arriving late) -- against the SAME sequence on the unsplit lattice.  Every form of the split path (flags, HIP
-events, split_early, split_pipe) and both self-exchanges (copies, one-rank RCCL communicator) must reproduce the unsplit fields:
+events, split_pipe; the direct carrier's one- and two-kernel forms) and all three self-exchanges (copies, one-rank RCCL communicator, direct stores) must reproduce the unsplit fields:
 what this guards is the bookkeeping between stencils (sequence numbers, which field's faces sit in the send buffers, which faces
 were exchanged ahead), which no single-operation test exercises."""
 import numpy as np
@@ -80,11 +80,15 @@ def _run(lat, seed, nops, split, gen=None, skew=None):
     return out, scal
 
 
-FORMS = [("flags", {}), ("events", {"split_sync": 1}), ("no prepack", {"prepack": 0}), ("split_early", {"split_early": 1}),
-         ("split_pipe", {"split_pipe": 2})]
+FORMS = [("flags", {}), ("events", {"split_sync": 1}), ("no prepack", {"prepack": 0}), ("split_pipe", {"split_pipe": 2})]
+# loopback 3 = the direct carrier (faces stored by the producing waves into "the neighbour's" buffers): its own two forms
+DIRECT_FORMS = [("one kernel, boundary last / first", {"direct_form": 1, "direct_order": 2}), ("one kernel, boundary first / last", {"direct_form": 1, "direct_order": 1}),
+                ("stencil + exterior kernel", {"direct_form": 0})]
+def forms_of(loopback):
+    return DIRECT_FORMS if loopback == 3 else FORMS
 
 
-@pytest.mark.parametrize("loopback", [1, 2])
+@pytest.mark.parametrize("loopback", [1, 2, 3])
 def test_random_operation_sequences_on_the_split_path(loopback):
     from tmlqcd_amd import Lattice
     kappa, mu, theta = 0.131, 0.017, (1.0, 0.2, 0.0, -0.3)
@@ -94,7 +98,7 @@ def test_random_operation_sequences_on_the_split_path(loopback):
         ref_lat.set_gauge(g)
         ref, ref_scal = _run(ref_lat, seed, nops, split=False)
         ref_lat.close()
-        for name, opts in FORMS:
+        for name, opts in forms_of(loopback):
             lat = Lattice(T, L, L, L, kappa=kappa, mu=mu, theta=theta)
             lat.set_gauge(g)
             for k, v in opts.items():
@@ -110,7 +114,7 @@ def test_random_operation_sequences_on_the_split_path(loopback):
                 assert abs(s1 - s2) <= 1e-11 * max(abs(s2), 1.0), (loopback, name, seed)
 
 
-@pytest.mark.parametrize("loopback", [1, 2])
+@pytest.mark.parametrize("loopback", [1, 2, 3])
 def test_fp32_clover_and_solvers_on_every_form_of_the_split_path(loopback):
     """The other precisions and epilogues a T-split rank runs -- the fp32 stencil and Qtm_pm_psi_32, the clover operators in both
     precisions, cg_her / mixed_cg_her on Qtm_pm_psi and Qsw_pm_psi (fused CG iterations: reductions spread over stencil and exterior
@@ -162,7 +166,7 @@ def test_fp32_clover_and_solvers_on_every_form_of_the_split_path(loopback):
 
     def rel(x, y):
         return float(np.abs(x - y).max() / np.abs(y).max())
-    for name, opts in FORMS:
+    for name, opts in forms_of(loopback):
         lat = make()
         for kk, v in opts.items():
             lat.set_option(kk, v)

@@ -146,7 +146,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
-  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_split_early = 0; ctx->opt_split_pipe = -1;
+  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_split_pipe = 0; ctx->opt_direct_form = -1; ctx->opt_direct_order = 2;
   {
     // bound of the device-side waits for the neighbours' faces: TMLQCD_HIP_FLAG_TIMEOUT_S in the environment (0 = none), default 120 s
     double sec = 120.0;
@@ -183,8 +183,6 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   TMHIP_CHECK(hipMalloc((void **)&ctx->recv_up, 2 * fb));
   ctx->send_up = ctx->send_dn + (size_t)6 * ctx->face;
   ctx->recv_dn = ctx->recv_up + (size_t)6 * ctx->face;
-  TMHIP_CHECK(hipMalloc((void **)&ctx->bmark, (size_t)(2 * (ctx->face / 64) + 2) * sizeof(int)));
-  TMHIP_CHECK(hipMemsetAsync(ctx->bmark, 0, (size_t)(2 * (ctx->face / 64) + 2) * sizeof(int), ctx->stream));
   TMHIP_CHECK(hipMalloc((void **)&ctx->sync_flags, 64));
   TMHIP_CHECK(hipMemsetAsync(ctx->sync_flags, 0, 64, ctx->stream));
   TMHIP_CHECK(hipMemsetAsync(ctx->recv_up, 0, 2 * fb, ctx->stream));
@@ -237,12 +235,12 @@ void tmhip_destroy(tmhip_ctx *ctx) {
   if (ctx->io_sums) (void)hipFree(ctx->io_sums);
   if (ctx->swpm_halo_send) (void)hipFree(ctx->swpm_halo_send);
   if (ctx->swpm_halo_recv) (void)hipFree(ctx->swpm_halo_recv);
+  tmhip_direct_destroy(ctx);
   if (ctx->shm) tmhip_shm_destroy(ctx);
   else if (ctx->comm_ready) { if (ctx->comm_red != ctx->comm) ncclCommDestroy(ctx->comm_red); ncclCommDestroy(ctx->comm); }
   (void)hipFree(ctx->gauge); (void)hipFree(ctx->partials); (void)hipFree(ctx->result_dev);
   (void)hipHostFree(ctx->result_host);
   (void)hipFree(ctx->sync_flags);
-  if (ctx->bmark) (void)hipFree(ctx->bmark);
   (void)hipFree(ctx->send_dn); (void)hipFree(ctx->recv_up);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->cg_state) (void)hipFree(ctx->cg_state);
@@ -298,11 +296,12 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "occ")) { if (value < 0 || value > 8) TMHIP_FAIL("occ must be in [0, 8] waves per SIMD (0 = no cap)"); ctx->opt_occ = value; }
   else if (!strcmp(name, "xcd")) { if (value < 0 || value > 4) TMHIP_FAIL("xcd must be 0 (none), 1 (chunk), 2 (automatic), 3 (slab) or 4 (tile)"); ctx->opt_xcd = value; }
   else if (!strcmp(name, "tgrp")) { if (value < 0 || value > ctx->g.T) TMHIP_FAIL("tgrp must be in [0, T]"); ctx->opt_tgrp = value; }
-  else if (!strcmp(name, "split_sync")) { if (value < 0 || value > 1) TMHIP_FAIL("split_sync must be 0 (boundary hop in the stencil kernel, behind a flag) or 1 (HIP events + exterior kernel)"); ctx->opt_split_sync = value; }
+  else if (!strcmp(name, "split_sync")) { if (value < 0 || value > 1) TMHIP_FAIL("split_sync must be 0 (the exterior kernel and the pack kernel wait for a word of the other stream) or 1 (the streams are ordered by HIP events: no wait on the device)"); ctx->opt_split_sync = value; }
   else if (!strcmp(name, "flag_timeout_ms")) { if (value < 0) TMHIP_FAIL("flag_timeout_ms must be >= 0 (0 = wait without bound)"); ctx->flag_timeout_ticks = (unsigned long long)value * 100000ull; }
-  else if (!strcmp(name, "split_early")) { ctx->opt_split_early = value != 0; ctx->prepacked = nullptr; }
+  else if (!strcmp(name, "direct_form")) { if (value < -1 || value > 1) TMHIP_FAIL("direct_form must be -1 (automatic), 0 (stencil + exterior kernel) or 1 (one kernel per stencil whenever the shape allows)"); ctx->opt_direct_form = value; }
+  else if (!strcmp(name, "direct_order")) { if (value < 0 || value > 3) TMHIP_FAIL("direct_order: bit 0 / bit 1 = boundary time-slices first for a stencil whose faces are packed now / were pushed ahead"); ctx->opt_direct_order = value; }
   else if (!strcmp(name, "prepack")) { ctx->opt_prepack = value != 0; ctx->prepacked = nullptr; }
-  else if (!strcmp(name, "split_pipe")) { if (value < -1 || value > 2) TMHIP_FAIL("split_pipe must be -1 (automatic), 0 (off), 1 (local lattices of >= 262144 sites per parity) or 2 (every size)"); ctx->opt_split_pipe = value; ctx->prepacked = nullptr; ctx->ahead_field = nullptr; }
+  else if (!strcmp(name, "split_pipe")) { if (value < 0 || value > 2) TMHIP_FAIL("split_pipe must be 0 (off, default), 1 (local lattices of >= 262144 sites per parity) or 2 (every size)"); ctx->opt_split_pipe = value; ctx->prepacked = nullptr; ctx->ahead_field = nullptr; }
   else if (!strcmp(name, "comm_split")) { if (ctx->comm_ready) TMHIP_FAIL("comm_split must be set before the communicator is created"); ctx->opt_comm_split = value != 0; }
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
   else if (!strcmp(name, "gauge_cache")) { if (value < -1 || value > 1) TMHIP_FAIL("gauge_cache must be -1 (automatic), 0 or 1"); ctx->opt_gauge_cache = value; }
@@ -672,10 +671,15 @@ int tmhip_comm_stream_delay_ms(tmhip_ctx *ctx, int ms) {
 
 int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
   if (ctx->g.nproc_t > 1) TMHIP_FAIL("loopback is a single-rank self-test");
+  if (on < 0 || on > 3) TMHIP_FAIL("loopback: 0 off, 1 device-to-device copies, 2 one-rank RCCL communicator, 3 direct carrier onto oneself");
   ctx->loopback = on != 0;
   ctx->loopback_rccl = on == 2;
-  ctx->prepacked = nullptr; ctx->ahead_field = nullptr;
-  if (on < 0 || on > 2) TMHIP_FAIL("loopback: 0 off, 1 device-to-device copies, 2 one-rank RCCL communicator");
+  ctx->prepacked = nullptr; ctx->ahead_field = nullptr; ctx->direct.ahead_field = nullptr;
+  if (on == 3) { if (tmhip_direct_init_self(ctx)) return 1; }
+  else if (ctx->direct.on) {   // back to a carrier on the comm stream: everything pushed so far has been consumed or is abandoned
+    TMHIP_CHECK(hipStreamSynchronize(ctx->stream)); TMHIP_CHECK(hipStreamSynchronize(ctx->comm_stream));
+    ctx->direct.on = false;
+  }
   if (on == 2 && !ctx->comm_ready) {  // one-rank RCCL communicator: faces travel through ncclSend/ncclRecv to self
     TMHIP_CHECK(hipSetDevice(ctx->device));
     ncclUniqueId u;

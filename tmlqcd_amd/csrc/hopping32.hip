@@ -36,14 +36,14 @@ template <bool NT> __device__ __forceinline__ void st6(ET *f, size_t stride, int
     else *q = v;
   }
 }
-// agent-scope (sc1) loads of the six components 6 blk .. 6 blk + 5: see hopping_common.h
+// system-scope (sc0 sc1) loads of the six components 6 blk .. 6 blk + 5: see hopping_common.h
 __device__ __forceinline__ void ld6_fresh(V2T *s, const ET *f, size_t stride, int j, int blk) {
   const vf4 *p = reinterpret_cast<const vf4 *>(f);
 #pragma unroll
   for (int m = 0; m < 3; m++) {
     const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p + (size_t)(3 * blk + m) * stride + j);
-    const unsigned long long w0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __builtin_memcpy(&s[2 * m], &w0, 8); __builtin_memcpy(&s[2 * m + 1], &w1, 8);
   }
 }

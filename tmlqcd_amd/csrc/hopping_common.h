@@ -29,17 +29,18 @@ typedef int v4i __attribute__((ext_vector_type(4)));
   template <bool NT> __device__ __forceinline__ void st6(ET *f, size_t stride, int j, int blk, const V2T *s) {                    \
     _Pragma("unroll") for (int c = 0; c < 6; c++) stc<NT>(f + (size_t)(6 * blk + c) * stride + j, s[c]);                          \
   }                                                                                                                               \
-  /* the same six components with agent-scope loads (sc1: served by L2, never by this CU's L1): data another kernel has just      \
-     written while this one was already running (the exchanged faces) without paying an L1 invalidate for the whole CU */          \
+  /* the same six components with system-scope loads (sc0 sc1: never served by this CU's L1): data another kernel -- of this GPU,  \
+     or a neighbour's through an IPC mapping -- has just written while this one was already running (the exchanged faces), without  \
+     paying an L1 invalidate for the whole CU */                                                                                   \
   __device__ __forceinline__ void ld6_fresh(V2T *s, const ET *f, size_t stride, int j, int blk) {                                 \
     _Pragma("unroll") for (int c = 0; c < 6; c++) {                                                                               \
       const ET *p = f + (size_t)(6 * blk + c) * stride + j;                                                                       \
       if constexpr (sizeof(ET) == 16) {                                                                                           \
         const double *q = reinterpret_cast<const double *>(p);                                                                    \
-        s[c].x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                                \
-        s[c].y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                            \
+        s[c].x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                                                \
+        s[c].y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                                            \
       } else {                                                                                                                    \
-        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
         __builtin_memcpy(&s[c], &w, 8);                                                                                           \
       }                                                                                                                           \
     }                                                                                                                             \

@@ -56,6 +56,24 @@ struct tmhip_field {
   tmhip_field *half[2];  // FULL only: views
 };
 
+// The direct face carrier (tmhip_comm_init_ipc; loopback 3 = onto oneself): the ring neighbours' receive buffers and arrival words are
+// mapped into this process (hipIpcOpenMemHandle) and whoever produces the projected faces -- the pack kernel, the exterior kernel, the
+// boundary waves of a stencil kernel -- stores them there itself (write-through, system scope); the last wave to finish writes the push
+// number into the neighbours' words.  No copy, no kernel of a communication library, nothing on the receiving GPU's compute units.
+// Double-buffered by push parity; protocol and flow control: launch_direct (hopping_impl.inc), DESIGN.md section 7.
+struct TmhipDirect {
+  bool on;
+  void *mine;                   // ONE uncached device allocation: [2 push parities][from up | from dn] faces, then the arrival words
+  v2d *rbuf[2][2];              // [parity][0: written by the up neighbour (halo_up), 1: by the down neighbour (halo_dn)]
+  unsigned int *arr[2];         // arrival words, 128 bytes apart: [0] written by the up neighbour, [1] by the down neighbour
+  void *peer_map[2];            // mappings to close at the end ([1] null when both neighbours are one rank, both null for the self-push)
+  v2d *peer_buf[2][2];          // [parity][0: the up neighbour's "from dn" buffer (our t = T-1 projections go there), 1: the down neighbour's "from up" buffer (our t = 0)]
+  unsigned int *peer_arr[2];    // [0] the up neighbour's arr[1], [1] the down neighbour's arr[0]
+  unsigned int push_seq;        // pushes issued so far (the same number on every rank: all ranks run the same sequence of stencils)
+  const void *ahead_field; unsigned int ahead_push;   // the field whose faces were pushed AHEAD by the stencil that wrote it, and under which number
+  int sharers;                  // ranks of this job that sit on this physical GPU (1 in production; the one-GPU rehearsals have more)
+};
+
 struct tmhip_ctx {
   tmhip_geom g;
   int device;
@@ -104,9 +122,9 @@ struct tmhip_ctx {
   ncclComm_t comm, comm_red; bool comm_ready; bool comm_split; bool loopback; bool loopback_rccl;
   struct TmhipShm *shm;   // != nullptr: the ranks talk through the host-staged shared-memory transport (xfer_shm.hip) instead of RCCL; everything on `stream`
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
-  unsigned int *sync_flags; unsigned int hop_seq;  // [0] main stream reached stencil n, [1] faces of stencil n received, [2] a bounded wait gave up
+  unsigned int *sync_flags; unsigned int hop_seq;  // [0] main stream reached stencil n, [1] faces of stencil n received, [2] a bounded wait gave up (table of all words: DESIGN.md section 7)
   unsigned long long flag_timeout_ticks;           // bound of the device-side flag waits in ticks of the 100 MHz clock (0 = none)
-  int *bmark;                                      // per 64 face sites: 1 = the stencil kernel took the hop across the cut itself ("split_early"), 0 = left to the exterior kernel
+  TmhipDirect direct;                              // the direct face carrier (off unless tmhip_comm_init_ipc / loopback 3)
   const void *prepacked;                           // the field whose boundary-slice projections sit in the send buffers (written by the last exterior kernel), or nullptr
   // "split_pipe": sync_flags [3] boundary slices of the running stencil kernel stored (published by the last of their waves, counted in [4]),
   // [5] exterior kernel of stencil n done (it runs on the comm stream).  ahead_field: the field whose faces have been exchanged AHEAD of the
@@ -132,7 +150,8 @@ struct tmhip_ctx {
   int opt_stg;                                                          // 1 = LDS-staged stencil (own-block input spinors staged once, y/z neighbours read from LDS)
   int opt_recon;                                                        // 12 = rebuild the third row of every link in registers (opt-in)
   int opt_split_sync;                                                   // 0: the exterior kernel / the pack kernel wait for a flag of the other stream (default); 1: HIP events, no device-side wait
-  int opt_split_early;                                                  // 1: boundary slices last, hop across the cut in the stencil kernel when the faces are already there
+  int opt_direct_form;                                                  // direct carrier: -1 automatic (one kernel per stencil while the boundary waves fit the wait budget), 0 stencil + exterior kernel, 1 one kernel whenever the shape allows
+  int opt_direct_order;                                                 // direct carrier, one-kernel form: bit 0 / bit 1 = boundary time-slices FIRST for a stencil whose faces are packed now / were pushed ahead (else last)
   int opt_split_pipe;                                                   // 1: boundary slices first, exterior kernel beside the stencil kernel, faces of a chain's next stencil exchanged ahead (hopping_impl.inc, launch_pipe)
   int opt_prepack;                                                      // 1 (default): the exterior kernel projects the faces of its output for the next stencil of a chain
   int opt_comm_split;                                                   // 0: do not split off a second communicator (exercises the one-communicator fallback)
@@ -170,6 +189,10 @@ int tmhip_shm_failed(tmhip_ctx *ctx);
 int tmhip_shm_ring(tmhip_ctx *ctx, hipStream_t st, const void *to_dn, const void *to_up, void *from_up, void *from_dn, size_t bytes);
 int tmhip_shm_allreduce(tmhip_ctx *ctx, hipStream_t st, double *x, int n);
 int tmhip_shm_allgather(tmhip_ctx *ctx, hipStream_t st, const void *mine, void *all, size_t bytes);
+
+// ---- direct face carrier (xfer_ipc.hip) ----
+int tmhip_direct_init_self(tmhip_ctx *ctx);   // loopback 3
+void tmhip_direct_destroy(tmhip_ctx *ctx);
 
 // ---- launch helpers implemented across the .hip files ----
 enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4, EPI_CLOVER_INV = 5, EPI_CLOVER_G5 = 6, EPI_CLOVER = 7,

@@ -137,6 +137,8 @@ def load_library():
         "tmhip_comm_get_unique_id": [C.c_char_p],
         "tmhip_comm_init": [vp, C.c_char_p],
         "tmhip_comm_init_shm": [vp, C.c_char_p],
+        "tmhip_comm_init_ipc": [vp],
+        "tmhip_comm_faces_direct": [vp, C.POINTER(i)],
         "tmhip_comm_set_loopback": [vp, i],
         "tmhip_comm_count": [vp, C.POINTER(i), C.POINTER(i)],
         "tmhip_comm_is_split": [vp],
@@ -614,6 +616,17 @@ class Lattice:
     def comm_init_shm(self, job):
         """the ring over the host-staged shared-memory transport (ranks of one node, no RCCL; `job`: the same string on every rank)"""
         _ck(self.lib.tmhip_comm_init_shm(self.h, job.encode()), "tmhip_comm_init_shm")
+
+    def comm_init_ipc(self):
+        """the direct face carrier on top of the ring (collective, after comm_init / comm_init_shm): faces are stored by the producing
+        waves straight into the ring neighbours' IPC-mapped receive buffers"""
+        _ck(self.lib.tmhip_comm_init_ipc(self.h), "tmhip_comm_init_ipc")
+
+    def comm_faces_direct(self):
+        """(True when the faces travel as direct stores, ranks of the job on this rank's GPU)"""
+        n = C.c_int()
+        v = self.lib.tmhip_comm_faces_direct(self.h, C.byref(n))
+        return bool(v), n.value
 
     def comm_count(self):
         """(ranks of the face communicator, ranks of the reduction communicator) as RCCL reports them; (0, 0) without one."""
