@@ -96,6 +96,9 @@ void gamma5(spinor *const l, spinor *const k, const int V);                   /*
 
 void tmlqcd_hip_comm_init(const char unique_id[128]); /* ranks along T: id from tmhip_comm_get_unique_id, broadcast (MPI_Bcast) by the host */
 void tmlqcd_hip_comm_init_shm(const char *job);         /* the same ring without RCCL: host-staged through a shared-memory segment of the node (tmhip_comm_init_shm) */
+int tmlqcd_hip_comm_init_ipc(void);                      /* after either: the half-spinor faces travel as direct stores into the ring neighbours' IPC-mapped receive buffers
+                                                          * (tmhip_comm_init_ipc; replaces the MPI_Isend/Irecv/Waitall of xchange/xchange_halffield.c:176-263).  Collective.
+                                                          * Non-zero when some rank cannot map a neighbour: every rank then keeps the communicator's exchange */
 double square_norm(const spinor *const P, const int N, const int parallel);
 double scalar_prod_r(const spinor *const S, const spinor *const R, const int N, const int parallel);
 void assign_add_mul_r(spinor *const P, spinor *const Q, const double c, const int N);

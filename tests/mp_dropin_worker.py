@@ -49,6 +49,8 @@ stub.stub_boundary(0.13, 1.0, 0.0, 0.0, 0.0)
 stub.stub_set_mu(0.02)
 if world > 1:
     d.tmlqcd_hip_comm_init_shm(job.encode())
+    if os.environ.get("MP_FACES") == "direct":
+        assert d.tmlqcd_hip_comm_init_ipc() == 0
 
 
 def p(a):

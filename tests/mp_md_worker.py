@@ -28,6 +28,8 @@ class SplitTrajectory(CloverDetTrajectory):
         self.lat = lat = Lattice(T, L, L, L, kappa=kappa, mu=mu, nproc_t=world, proc_t=rank, device=0)
         if world > 1:
             lat.comm_init_shm(job)
+            if os.environ.get("MP_FACES") == "direct":
+                lat.comm_init_ipc()
         self.g0 = syn.gauge_field(seed, T, L, L, L, world, rank)
         XYZ = L ** 3
         self.p0 = np.concatenate([np.random.default_rng([seed + 1, rank * T + t]).standard_normal((XYZ, 4, 8)) for t in range(T)])

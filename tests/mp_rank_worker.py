@@ -25,6 +25,9 @@ kappa, mu, csw, theta = 0.13, 0.02, 1.2, (1.0, 0.3, 0.0, -0.2)
 lat = Lattice(T, L, L, L, kappa=kappa, mu=mu, theta=theta, nproc_t=world, proc_t=rank, device=0)
 if world > 1:
     lat.comm_init_shm(job)
+    if os.environ.get("MP_FACES") == "direct":          # faces as direct stores into the neighbours' IPC-mapped buffers; sums and the other halos stay on the ring
+        lat.comm_init_ipc()
+        assert lat.comm_faces_direct() == (True, world)  # (all ranks of the test share the one GPU)
 g = syn.gauge_field(21, T, L, L, L, world, rank)
 lat.set_gauge(g)
 N, V = lat.Vh, lat.V

@@ -78,3 +78,31 @@ def test_rank_0_reference_raises_before_any_split_operation():
     rc = rec["rank_check"]
     assert rc["ok"] is False and rc["step"] == "reference" and rc["failed_ranks"] == [0]
     assert rec["traces"][0] == "setup|headline" and rec["traces"][1] == "setup|headline"     # no rank started the split operators
+
+
+def test_a_rank_that_dies_still_yields_one_line():
+    """the child tree dies (rank 1 exits before the rendezvous) -> the parent prints ONE well-formed line with
+    value null and the reason, instead of nothing; the surviving rank's rendezvous is bounded (TMLQCD_BENCH_PG_TIMEOUT_S)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=_env(TMLQCD_BENCH_RENDEZVOUS_ONLY="1", TMLQCD_BENCH_TEST_FAULT="die", TMLQCD_BENCH_PG_TIMEOUT_S="20"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and rec["n_ranks"] == 2 and "no result line" in rec["error"] and rec["metric"].startswith("Hopping_Matrix")
+    assert rec["steps"] == 3 and rec["warmup"] == 1 and rec["wall_s"]["total"] < 200
+
+
+def test_a_run_that_hangs_is_ended_and_reported():
+    """... and a child tree that hangs is ended after TMLQCD_BENCH_TIMEOUT_S (whole process group) and reported the same way."""
+    import time
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"],
+                       env=_env(TMLQCD_BENCH_RENDEZVOUS_ONLY="1", TMLQCD_BENCH_TEST_FAULT="hang", TMLQCD_BENCH_TIMEOUT_S="25"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and time.perf_counter() - t0 < 120
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and "did not finish within 25 s" in rec["error"]

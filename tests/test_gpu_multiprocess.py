@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(nranks, extra=()):
+def _bench(nranks, extra=(), **more_env):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(TMLQCD_BENCH_TRANSPORT="shm", HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60")
+    env.update(more_env)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--L", "16", "--steps", "20", "--warmup", "2", "--cg-iters", "20",
            "--no-cpu", "--no-rows"] + list(extra)
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
@@ -35,8 +36,16 @@ def test_bench_runs_as_n_processes_and_agrees_with_the_unsplit_lattice(nranks):
     assert chk["ok"] is True, chk
     assert chk["hopping_matrix_max_rel_dev"] <= 1e-13 and chk["qtm_pm_psi_max_rel_dev"] <= 1e-13 and chk["global_norm_rel_dev"] <= 1e-13
     assert abs(chk["cg_iters_split"] - chk["cg_iters_unsplit"]) <= 1 and chk["cg_solution_max_rel_dev"] <= 1e-8
-    assert rec["n_gpus"] == nranks and rec["value"] and rec["value"] > 0
-    assert rec["rccl_nranks"] == [nranks, nranks] and rec["comm_split"] is False      # (the transport reports its ring; no second communicator)
+    # an honest line: the ranks share ONE GPU -- n_gpus counts devices, n_ranks processes, and the line is marked as a rehearsal
+    assert rec["n_ranks"] == nranks and rec["n_gpus"] == 1 and rec["rehearsal"] is True and rec["value"] and rec["value"] > 0
+    assert rec["transport"] == "shm" and rec["ring_nranks"] == [nranks, nranks] and rec["rccl_nranks"] is None      # RCCL built nothing here
+    assert set(rec["wall_s"]) >= {"configs[3]", "headline", "total"} and rec["wall_s"]["total"] < 600
+    # default TMLQCD_BENCH_FACES=auto: after the communicator's legs the direct carrier (IPC-mapped neighbour buffers, faces stored by
+    # the producing waves) runs configs[3] against the unsplit lattice and the headline loop against the communicator's output
+    fd = rec["faces_direct"]
+    assert fd["ok"] is True, fd
+    assert fd["strong"]["rank_check"]["ok"] is True and fd["strong"]["faces"] == "direct" and fd["strong"]["ranks_sharing_a_gpu"] == nranks
+    assert fd["headline"]["max_rel_dev_vs_communicator"] <= 1e-13 and fd["headline"]["faces"] == "direct"
     st = rec["strong"]
     assert st.get("ok", True) and st["value"] > 0 and st["cg_iters_per_s"] > 0 and st["nocom"]["value"] > 0
     if 16 % nranks == 0 and (16 // nranks) % 2 == 0:
@@ -45,15 +54,25 @@ def test_bench_runs_as_n_processes_and_agrees_with_the_unsplit_lattice(nranks):
     assert rec["cg"]["iters_per_s"] > 0 and abs(rec["hermiticity_rel_dev"]) < 1e-12
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_next_rows_as_real_processes(world, tmp_path):
+def test_bench_with_the_direct_carrier_from_the_start():
+    """TMLQCD_BENCH_TRANSPORT=ipc: every leg -- rank checks against the unsplit lattice, configs[3], 16^4 / N, the headline with its
+    reductions and solves -- with the faces stored straight into the neighbours' IPC-mapped buffers, three processes on one GPU."""
+    rec, err = _bench(3, TMLQCD_BENCH_TRANSPORT="ipc")
+    assert rec["rank_check"]["ok"] is True and rec["rank_check"]["faces"] == "direct", rec["rank_check"]
+    assert rec["faces"] == "direct" and rec["transport"] == "shm" and rec["ranks_sharing_a_gpu"] == 3 and "faces_direct" not in rec
+    assert rec["strong"]["value"] > 0 and rec["cg"]["iters_per_s"] > 0 and abs(rec["hermiticity_rel_dev"]) < 1e-12
+    assert "gave up" not in err
+
+
+@pytest.mark.parametrize("world,faces", [(2, "ring"), (3, "ring"), (3, "direct")])
+def test_next_rows_as_real_processes(world, faces, tmp_path):
     """D_psi, the device-side clover term / inverse and Qsw_pm_psi, cg_her and mixed_cg_her on both operators, both parts of the fermion
     force, the link update with its halo exchange and update_momenta -- every rank a process of its own (tests/mp_rank_worker.py), slab by
     slab against the unsplit lattice."""
     import numpy as np
     worker = os.path.join(ROOT, "tests", "mp_rank_worker.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60")
-    job = "mp_%d_%d" % (os.getpid(), world)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60", MP_FACES=faces)
+    job = "mp_%d_%d_%s" % (os.getpid(), world, faces)
     ref = subprocess.run([sys.executable, worker, "0", "1", job, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert ref.returncode == 0, ref.stderr[-3000:]
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), job, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -90,28 +109,35 @@ def test_next_rows_as_real_processes(world, tmp_path):
                 assert np.abs(parts[r][kind + name] - slab(one[kind + name], r)).max() / sc < 1e-6, (kind, name, r)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_random_sequences_between_real_processes(world, tmp_path):
+@pytest.mark.parametrize("world,Tg", [(2, 16), (4, 16), (6, 24)])
+def test_random_sequences_between_real_processes(world, Tg, tmp_path):
     """The seeded random operation sequence of test_gpu_split_stress.py (stencils with every epilogue, chains, linalg between them,
-    short cg_her solves, uploads, the benchmark loop) on a 16 x 16^3 lattice cut into `world` slabs, every rank a process that falls
-    behind at random points -- for every form of the split path, slab by slab against the unsplit lattice."""
+    short cg_her solves, uploads, the benchmark loop) on a Tg x 16^3 lattice cut into `world` slabs, every rank a process that falls
+    behind at random points -- for every form of the split path, slab by slab against the unsplit lattice.  "direct: ...": the faces
+    are stored by the producing waves into the NEIGHBOUR PROCESS's receive buffers (hipIpc mappings; the processes share the GPU), in
+    the one-kernel form with the boundary waves waiting for the neighbour's word, and in the two-kernel form.  Six processes (the most
+    the test box admits on its GPU; T_local 4): the direct forms only."""
+    import re
     import numpy as np
-    from tests.test_gpu_split_stress import FORMS
+    from tests.test_gpu_split_stress import DIRECT_FORMS, FORMS
     worker = os.path.join(ROOT, "tests", "mp_stress_worker.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60", MP_TG=str(Tg))
     seed, nops = 5, 60
     ref = subprocess.run([sys.executable, worker, "0", "1", "none", str(tmp_path), str(seed), str(nops), "flags"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert ref.returncode == 0, ref.stderr[-3000:]
     one = np.load(os.path.join(str(tmp_path), "stress_flags_0_of_1.npz"))
-    for form, _ in FORMS:
-        job = "st_%d_%d_%s" % (os.getpid(), world, form.replace(" ", ""))
+    forms = ([f for f, _ in FORMS] if world < 6 else []) + ["direct: " + f for f, _ in DIRECT_FORMS]
+    for form in forms:
+        tag = re.sub(r"[^A-Za-z0-9]+", "_", form)
+        job = "st_%d_%d_%s" % (os.getpid(), world, tag)
         procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), job, str(tmp_path), str(seed), str(nops), form], env=env,
                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
         outs = [p.communicate(timeout=400) for p in procs]
         for p, (so, se) in zip(procs, outs):
             assert p.returncode == 0, (form, se[-3000:])
+            assert "gave up" not in se, (form, se[-2000:])             # no bounded wait ran into its deadline
         for r in range(world):
-            part = np.load(os.path.join(str(tmp_path), "stress_%s_%d_of_%d.npz" % (form.replace(" ", "_"), r, world)))
+            part = np.load(os.path.join(str(tmp_path), "stress_%s_%d_of_%d.npz" % (tag, r, world)))
             assert len(part["scal"]) == len(one["scal"]) and np.allclose(part["scal"], one["scal"], rtol=1e-11, atol=1e-11), (form, r)
             for i in range(5):
                 full = one["f%d" % i]
@@ -120,14 +146,14 @@ def test_random_sequences_between_real_processes(world, tmp_path):
                 assert dev < 1e-11, (form, r, i, dev)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_drop_in_symbols_on_t_split_ranks(world, tmp_path):
+@pytest.mark.parametrize("world,faces", [(2, "ring"), (4, "ring"), (4, "direct")])
+def test_drop_in_symbols_on_t_split_ranks(world, faces, tmp_path):
     """The reference-named symbols on a T-split lattice, every rank a host process with tmLQCD's own globals (g_nproc_t,
     g_proc_coords, RAND halo slices of g_gauge_field): Hopping_Matrix, Qtm_pm_psi, square_norm / scalar_prod_r with parallel = 1
     (and 0: the local sum), cg_her -- in coherent and in lazy residency -- slab by slab against the unsplit host program."""
     import numpy as np
     worker = os.path.join(ROOT, "tests", "mp_dropin_worker.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60", MP_FACES=faces)
     ref = subprocess.run([sys.executable, worker, "0", "1", "none", str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert ref.returncode == 0, ref.stderr[-3000:]
     job = "di_%d_%d" % (os.getpid(), world)
@@ -154,14 +180,14 @@ def test_drop_in_symbols_on_t_split_ranks(world, tmp_path):
         assert np.array_equal(parts[0]["lazy_hop"], parts[0]["coherent_hop"])
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_md_trajectory_between_real_processes(world, tmp_path):
+@pytest.mark.parametrize("world,faces", [(2, "ring"), (4, "ring"), (4, "direct")])
+def test_md_trajectory_between_real_processes(world, faces, tmp_path):
     """A leapfrog trajectory of the clover determinant with the lattice cut into `world` processes (tests/mp_md_worker.py): after four
     steps the links and momenta of every rank are the unsplit trajectory's slab, the action agrees, and the trajectory is reversible
     -- the link halo, the stencil copy and the clover term are refreshed from the neighbours after every update_gauge."""
     import numpy as np
     worker = os.path.join(ROOT, "tests", "mp_md_worker.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60", MP_FACES=faces)
     ref = subprocess.run([sys.executable, worker, "0", "1", "none", str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
     assert ref.returncode == 0, ref.stderr[-3000:]
     job = "md_%d_%d" % (os.getpid(), world)

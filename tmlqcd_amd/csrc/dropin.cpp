@@ -660,6 +660,7 @@ void tmlqcd_hip_forget(spinor *field) {
 }
 void tmlqcd_hip_comm_init(const char unique_id[128]) { CK(tmhip_comm_init(ctx(), unique_id)); }
 void tmlqcd_hip_comm_init_shm(const char *job) { CK(tmhip_comm_init_shm(ctx(), job)); }
+int tmlqcd_hip_comm_init_ipc(void) { return tmhip_comm_init_ipc(ctx()); }   // (non-zero: the faces stay on the communicator, on every rank -- not fatal)
 void tmlqcd_hip_finalize(void) {
   if (!g_ctx) return;
   RegLock lk;

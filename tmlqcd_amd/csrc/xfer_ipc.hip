@@ -31,8 +31,14 @@ size_t face_bytes(const tmhip_ctx *ctx) { return (size_t)6 * ctx->face * sizeof(
 int alloc_mine(tmhip_ctx *ctx) {
   TmhipDirect &d = ctx->direct;
   const size_t fb = face_bytes(ctx), total = 4 * fb + 4096;
-  TMHIP_CHECK(hipExtMallocWithFlags(&d.mine, total, hipDeviceMallocUncached));
+  // TMLQCD_HIP_DIRECT_ALLOC = plain | finegrained | uncached (A/B): what the receive buffers are made of
+  int kind = 3;
+  if (const char *e = getenv("TMLQCD_HIP_DIRECT_ALLOC")) kind = !strcmp(e, "plain") ? 0 : (!strcmp(e, "finegrained") ? 1 : 3);
+  if (kind == 0) TMHIP_CHECK(hipMalloc(&d.mine, total));
+  else TMHIP_CHECK(hipExtMallocWithFlags(&d.mine, total, kind == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
   TMHIP_CHECK(hipMemsetAsync(d.mine, 0, total, ctx->stream));
+  TMHIP_CHECK(hipMalloc((void **)&d.count, 33 * 128));
+  TMHIP_CHECK(hipMemsetAsync(d.count, 0, 33 * 128, ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   char *b = (char *)d.mine;
   for (int p = 0; p < 2; p++) for (int w = 0; w < 2; w++) d.rbuf[p][w] = (v2d *)(b + (size_t)(2 * p + w) * fb);
@@ -78,6 +84,7 @@ void tmhip_direct_destroy(tmhip_ctx *ctx) {
   if (!d.mine) return;
   for (int k = 0; k < 2; k++) if (d.peer_map[k]) (void)hipIpcCloseMemHandle(d.peer_map[k]);
   (void)hipFree(d.mine);
+  if (d.count) (void)hipFree(d.count);
   memset(&d, 0, sizeof(d));
 }
 

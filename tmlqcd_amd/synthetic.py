@@ -15,6 +15,9 @@ import numpy as np
 def _threads():
     """Worker threads for the per-time-slice generators (numpy releases the GIL inside its kernels): the CPUs this process may use,
     at most 16 -- a 64 x 32^3 gauge field took 47 s on one thread, most of a multi-rank bench run."""
+    e = os.environ.get("TMLQCD_SYNTH_THREADS")      # the ranks of a multi-rank bench run share the node's CPUs: bench.py sets CPUs / ranks
+    if e and e.isdigit() and int(e) > 0:
+        return min(16, int(e))
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:

@@ -27,7 +27,7 @@ RULES = [
     # fp64, large lattices: the LDS-staged kernel, __launch_bounds__(256, 3) for the twisted-mass epilogues, (256, 1) for the clover ones
     (r"^void hop64::hop_kernel<(\d+), ([013]), true, 256, (3|1), -1, 64>", "fp64 staged"),
     # fp64, small lattices and ragged shapes: the gather kernel
-    (r"^void hop64::hop_kernel<(\d+), ([0123]), true, (64|256), 1, (-1|-2), 0>", "fp64 gather"),
+    (r"^void hop64::hop_kernel<(\d+), ([0123]), true, (64|256), (1|3), (-1|-2), 0>", "fp64 gather"),
     (r"^void hop64::hop_split4_kernel<(\d+), true>", "fp64 hop-split"),
     (r"^void hop64::hop_exterior_kernel<(\d+), true>", "fp64 exterior"),
     (r"^void hop64::pack_faces_kernel", "fp64 pack"),

@@ -14,6 +14,8 @@ TMHIP_SPINOR_IO_PLANES
 template __global__ void hop_kernel<PROBE_EPI, 0, true, 256, 3, -1, 64>(const HopArgs);
 template __global__ void hop_kernel<PROBE_EPI, 1, true, 256, 3, -1, 64>(const HopArgs);
 template __global__ void hop_kernel<PROBE_EPI, 3, true, 256, 3, -1, 64>(const HopArgs);
-template __global__ void hop_kernel<PROBE_EPI, 1, true, 256, 1, -1, 0>(const HopArgs);
-template __global__ void hop_kernel<PROBE_EPI, 3, true, 256, 1, -1, 0>(const HopArgs);
+template __global__ void hop_kernel<PROBE_EPI, 1, true, 256, 3, -1, 0>(const HopArgs);
+template __global__ void hop_kernel<PROBE_EPI, 3, true, 256, 3, -1, 0>(const HopArgs);
+template __global__ void hop_kernel<PROBE_EPI, 1, true, 64, 3, -1, 0>(const HopArgs);
+template __global__ void hop_kernel<PROBE_EPI, 3, true, 64, 3, -1, 0>(const HopArgs);
 }  // namespace hop64
