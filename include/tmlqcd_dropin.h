@@ -84,6 +84,18 @@ void Q_minus_psi(spinor *const l, spinor *const k);
 void M_minus_psi(spinor *const l, spinor *const k);
 void D_dagg_psi(spinor *const l, spinor *const k);
 typedef struct { float c[24]; } spinor32;   /* su3.h:83: spinor32 = 4 x su3_vector32 = 12 complex float */
+/* fp32 twins on HOST spinor32 arrays by their reference names (row f1).  Operands are copied in and results out on every call (the
+ * coherent semantics; the fp32 solvers iterate device-resident through mixed_cg_her / rg_mixed_cg_her below).  N <= VOLUME/2. */
+void Hopping_Matrix_32(const int ieo, spinor32 *const l, spinor32 *const k);              /* operator/Hopping_Matrix_32.h:31 */
+void Hopping_Matrix_32_orphaned(const int ieo, spinor32 *const l, spinor32 *const k);     /* :30 -- called by EVERY thread of an enclosing OpenMP team: one issues the device call, all meet before and after */
+void Qtm_pm_psi_32(spinor32 *const l, spinor32 *const k);                                 /* operator/tm_operators_32.c:94 */
+float square_norm_32(const spinor32 *const P, const int N, const int parallel);           /* linalg/square_norm_32.c:95 */
+float scalar_prod_r_32(const spinor32 *const S, const spinor32 *const R, const int N, const int parallel);   /* linalg/scalar_prod_r_32.c:109 */
+void assign_add_mul_r_32(spinor32 *const R, spinor32 *const S, const float c, const int N);                  /* linalg/assign_add_mul_r_32.c:104 */
+void assign_mul_add_r_32(spinor32 *const R, const float c, const spinor32 *const S, const int N);            /* linalg/assign_mul_add_r_32.c:81 */
+void diff_32(spinor32 *const Q, const spinor32 *const R, const spinor32 *const S, const int N);              /* linalg/diff_32.c:39 */
+void assign_to_32(spinor32 *const R, spinor *const S, const int N);                       /* linalg/assign_to_32.c:37 */
+void assign_to_64(spinor *const R, spinor32 *const S, const int N);                       /* linalg/assign_to_32.c:84 (N = VOLUME/2) */
 void mul_one_pm_imu_inv_32(spinor32 *const l, const double _sign, const int N);                                        /* tm_operators.c:74 */
 void assign_mul_one_pm_imu_inv_32(spinor32 *const l, spinor32 *const k, const double _sign, const int N);              /* tm_operators.h */
 void mul_one_pm_imu_sub_mul_32(spinor32 *const l, spinor32 *const k, spinor32 *const j, const double _sign, const int N); /* tm_operators.c:103 */

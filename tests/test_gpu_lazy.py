@@ -325,3 +325,23 @@ def test_faults_of_the_host_program_reach_its_own_handler():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "lazy_chain_child.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().startswith("OK"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("where,why", [("heap", "inside the malloc heap"), ("arena", "inside a thread's malloc arena"), ("shared", "a shared mapping")])
+def test_arrays_that_cannot_be_watched(where, why):
+    """the hang of round 3 was a fault taken INSIDE malloc, on a watched page of the malloc heap.  Arrays in a
+    malloc arena (main or per-thread) or in a shared mapping are recognised from /proc/self/maps and never watched: copied per call,
+    results the coherent mode's, no fault served.  And with the test hook that watches them anyway, the first fault ends the process
+    with a message within seconds -- it fails loudly, it does not hang (tests/lazy_unwatchable_child.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = [sys.executable, os.path.join(root, "tests", "lazy_unwatchable_child.py"), where]
+    env = dict(os.environ, TMLQCD_HIP_LAZY_DEBUG="1")
+    env.pop("TMLQCD_HIP_LAZY_FORCE_WATCH", None)
+    r = subprocess.run(child, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().startswith("OK") and r.stdout.strip().endswith("faults served 0"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert "not watched, copied per call: " + why in r.stderr, r.stderr[-1500:]
+    r = subprocess.run(child, env=dict(env, TMLQCD_HIP_LAZY_FORCE_WATCH="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 1 and "must not be watched" in r.stderr and "OK" not in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])

@@ -16,7 +16,6 @@
 #include <atomic>
 #include <cerrno>
 #include <fcntl.h>
-#include <malloc.h>
 #include <pthread.h>
 #include <signal.h>
 #include <stdint.h>
@@ -67,9 +66,12 @@ struct Mirror {
   // lazy mode (TMLQCD_HIP_LAZY): the host array's pages are protected so that the host's own loads and stores say when a copy is needed
   size_t bytes = 0;         // extent of the host array this mirror stands for
   int prot = 0;             // P_RW: untouched; P_RO: both copies current, a host store must be noticed; P_NONE: the host copy is stale
-  std::vector<unsigned char> page_ok;   // P_NONE: pages of the span already brought up to date one by one
+  std::vector<unsigned char> page_ok;   // P_NONE: pages of the span already brought up to date one by one.  Sized ONCE, when the mirror is made
+                                        // (lazy mode): the SIGSEGV handler and everything it calls only ever overwrite it
   int faults = 0;           // page-wise read synchronisations since the device last wrote the field
-  bool nowatch = false;     // lazy mode: this array lies inside the malloc heap -- never protected, handled like the coherent mode handles it
+  bool nowatch = false;     // lazy mode: this array cannot be watched (malloc heap / arena, shared or file-backed mapping) -- never protected, copied per call like the coherent mode
+  bool classified = false;  // lazy mode: nowatch / unsafe were decided
+  bool unsafe = false;      // test hook TMLQCD_HIP_LAZY_FORCE_WATCH: watched although unwatchable -- a fault on it ends the program with a message (never a hang)
 };
 enum { P_RW = 0, P_RO = 1, P_NONE = 2 };
 unsigned long long g_tick = 0;
@@ -81,11 +83,18 @@ int g_device = -1;
 int g_mode = TMLQCD_HIP_COHERENT;
 int g_dims[6] = {0, 0, 0, 0, 0, 0};
 std::unordered_map<const void *, Mirror> g_reg;
+// What the SIGSEGV handler of the lazy mode walks instead of the map: a fixed array of (host array, its mirror) kept in step with g_reg
+// under the lock (mirrors live in map nodes: their addresses are stable).  Reading it allocates nothing and follows no bucket chain.
+struct Watch { const void *host; Mirror *m; };
+constexpr int WATCH_CAP = 4096;
+Watch g_watch[WATCH_CAP];
+int g_nwatch = 0;
 bool g_gauge_uploaded = false;   // the current context holds a gauge copy
 bool g_dev_links_newer = false;   // resident mode: the device links are ahead of g_gauge_field until tmlqcd_hip_sync_gauge_to_host
 bool g_momenta_resident = false;  // the momenta live on the device (tmlqcd_hip_update_momenta), not re-uploaded by tmlqcd_hip_update_gauge
 bool g_clover_uploaded = false;
 tmhip_field *g_full_tmp = nullptr; // FULL-lattice scratch of Q_pm_psi / D_dagg_psi (tm_operators.c:380-397)
+tmhip_field *g_f32[3] = {nullptr, nullptr, nullptr};   // device fields of the fp32 host-pointer symbols (Hopping_Matrix_32 ...)
 
 // ONE lock for the registry: taken around every change of g_reg or of a mirror's state by the entry points and for the whole body of
 // the SIGSEGV handler of the lazy mode, which walks the map -- a host thread faulting on a stale field while the master thread is
@@ -187,16 +196,25 @@ inline int page_want(const void *host, const Mirror &m, uintptr_t page) {
   return idx < m.page_ok.size() && m.page_ok[idx] ? P_RO : P_NONE;
 }
 // the strictest protection any mirror asks for this page (pages at the edge of a field are shared with its neighbours)
-int page_need(uintptr_t page, const std::unordered_map<const void *, Mirror> &reg) {
+int page_need(uintptr_t page, const std::unordered_map<const void *, Mirror> & /* the watch table mirrors it */) {
   int need = P_RW;
-  for (auto &kv : reg) {
-    const Mirror &m = kv.second;
+  for (int k = 0; k < g_nwatch; k++) {
+    const Mirror &m = *g_watch[k].m;
+    const void *host = g_watch[k].host;
     if (m.prot == P_RW || !m.bytes) continue;
-    if (page < span_lo(kv.first) || page >= span_hi(kv.first, m.bytes)) continue;
-    const int w = page_want(kv.first, m, page);
+    if (page < span_lo(host) || page >= span_hi(host, m.bytes)) continue;
+    const int w = page_want(host, m, page);
     if (w > need) need = w;
   }
   return need;
+}
+// g_reg changed (insert / erase): bring the handler's table in step.  Entry-point context, under the lock.
+void rebuild_watch() {
+  g_nwatch = 0;
+  for (auto &kv : g_reg) {
+    if (g_nwatch == WATCH_CAP) { fprintf(stderr, "[tmlqcd_dropin] fatal: more than %d mirrored host arrays\n", WATCH_CAP); exit(1); }
+    g_watch[g_nwatch++] = Watch{kv.first, &kv.second};
+  }
 }
 // (re)apply the protection of one mirror's span; interior pages belong to it alone, the two edge pages are negotiated
 void apply_prot(const void *host, Mirror &m, const std::unordered_map<const void *, Mirror> &reg) {
@@ -226,8 +244,10 @@ void set_prot(const void *host, Mirror &m, int prot, const std::unordered_map<co
     return;
   }
   m.prot = prot;
-  if (prot == P_NONE) { m.page_ok.assign((span_hi(host, m.bytes) - span_lo(host)) / g_page, 0); m.faults = 0; }
-  else m.page_ok.clear();
+  const size_t npages = (span_hi(host, m.bytes) - span_lo(host)) / g_page;
+  if (prot == P_NONE && m.page_ok.size() != npages) m.page_ok.assign(npages, 0);   // (entry points only: the handler never closes a span)
+  else std::fill(m.page_ok.begin(), m.page_ok.end(), 0);
+  if (prot == P_NONE) m.faults = 0;
   apply_prot(host, m, reg);
 }
 
@@ -259,8 +279,14 @@ int nsites(int kind) { return kind == TMHIP_FIELD_FULL ? VOLUME : VOLUME / 2; }
 // whole-field download of that neighbour must not land in -- or re-allocate -- the buffer the interrupted copy is filling.
 void *g_bounce[2] = {nullptr, nullptr};
 size_t g_bounce_bytes[2] = {0, 0};
+void *g_page_tmp = nullptr;     // page-locked: the handler's page-wise fetches (64 spinors)
+[[noreturn]] void handler_die(const char *msg) {   // async-signal-safe exit with a message
+  (void)!write(2, msg, strlen(msg));
+  _exit(1);
+}
 void *bounce(size_t bytes) {
   const int k = in_handler_here() ? 1 : 0;
+  if (k == 1 && g_bounce_bytes[1] < bytes) handler_die("[tmlqcd_dropin] fatal: lazy mode: the fault handler's staging buffer is smaller than the field it has to fetch\n");
   if (g_bounce_bytes[k] < bytes) {
     if (g_bounce[k]) tmhip_pinned_free(g_bounce[k]);
     g_bounce[k] = nullptr; g_bounce_bytes[k] = 0;
@@ -268,6 +294,18 @@ void *bounce(size_t bytes) {
     g_bounce_bytes[k] = bytes;
   }
   return g_bounce[k];
+}
+
+// Called by mirror() in lazy mode (entry-point context): whatever the fault handler will need for an array of this size exists before
+// the array is ever watched -- its page-locked staging buffer, the page buffer.  The handler allocates nothing.
+void prepare_handler_buffers(size_t bytes) {
+  if (g_bounce_bytes[1] < bytes) {
+    if (g_bounce[1]) tmhip_pinned_free(g_bounce[1]);
+    g_bounce[1] = nullptr; g_bounce_bytes[1] = 0;
+    CK(tmhip_pinned_alloc(bytes, &g_bounce[1]));
+    g_bounce_bytes[1] = bytes;
+  }
+  if (!g_page_tmp) CK(tmhip_pinned_alloc(64 * sizeof(spinor), &g_page_tmp));
 }
 
 // host <-> device for a mirror of any shape (KIND_LIN: the two halves are plain prefixes, no site permutation)
@@ -350,7 +388,7 @@ void download(tmhip_ctx *c, const void *host_user, Mirror &m) {
   m.host_valid = true;
   if (!watched) { if (staged) memcpy(const_cast<void *>(host_user), host, m.bytes); return; }
   m.prot = g_mode == TMLQCD_HIP_LAZY ? P_RO : P_RW;                     // both copies current: watch for host stores
-  m.page_ok.clear(); m.faults = 0;
+  std::fill(m.page_ok.begin(), m.page_ok.end(), 0); m.faults = 0;
   const uintptr_t lo = span_lo(host_user), hi = span_hi(host_user, m.bytes);
   if (install_pages((uintptr_t)host_user, m.bytes, lo, hi, (const char *)host)) return;
   mprotect((void *)lo, hi - lo, PROT_READ | PROT_WRITE);                // (memory that cannot be moved: open, copy, close)
@@ -370,7 +408,7 @@ void release_host(tmhip_ctx *c, const void *host, Mirror &m) {
   // freed by the program (and possibly mapped again for something else, which a download would overwrite): there is no host copy
   // to bring up to date
   if (g_mode == TMLQCD_HIP_LAZY && m.prot != P_RW && (host_unmapped(host, m) || mapping_replaced(host, m))) {
-    m.prot = P_RW; m.page_ok.clear(); m.dev_valid = false; m.host_valid = true;
+    m.prot = P_RW; std::fill(m.page_ok.begin(), m.page_ok.end(), 0); m.dev_valid = false; m.host_valid = true;
     return;
   }
   if (m.f && m.dev_valid && !m.host_valid) download(c, host, m);
@@ -391,6 +429,7 @@ void evict_if_crowded(tmhip_ctx *c, const void *keep) {
     release_host(c, victim, g_reg[victim]);
     if (g_reg[victim].f) tmhip_field_free(c, g_reg[victim].f);
     g_reg.erase(victim);
+    rebuild_watch();
   }
 }
 
@@ -428,38 +467,60 @@ bool mapping_replaced(const void *host, const Mirror &m) {
   return false;
 }
 
-// Lazy mode cannot watch an array that lives INSIDE the malloc heap: its pages also hold the allocator's own bookkeeping (the headers of
-// the neighbouring chunks) and whatever else the program keeps there, and the fault handler itself allocates -- a protected heap page
-// ends in a fault inside the handler.  glibc serves a request from the heap whenever a free chunk fits, whatever M_MMAP_THRESHOLD says
-// (a 200 KB numpy array in a process that has freed a few MB), so the threshold alone is no guarantee.  Such arrays are simply not
-// watched: they are copied on every call, as in the coherent mode.  The heap is the "[heap]" mapping of /proc/self/maps (the main
-// arena; tmLQCD's fields -- one calloc of hundreds of MB -- are mappings of their own and never fall in it).
-bool in_malloc_heap(const void *host, size_t bytes) {
-  static uintptr_t lo = 0, hi = 0;
+// Lazy mode watches an array by taking its pages away.  That is only sound for memory the program addresses and nobody else does:
+//  * NOT inside a malloc arena -- the main one ("[heap]") or a thread's (a 64 MB-aligned mapping of at most 64 MB, read-write at the
+//    bottom, PROT_NONE above: glibc's HEAP_MAX_SIZE): such pages also hold the allocator's chunk headers, free() / malloc() touch them
+//    while they hold the arena's lock, and a fault taken there cannot be served (the handler's own callees allocate).  glibc serves a
+//    request from an arena whenever a free chunk fits, whatever M_MMAP_THRESHOLD says (a 200 KB numpy array in a process that has
+//    freed a few MB) -- which is why this library does NOT touch the program's malloc settings any more (it pinned the mmap threshold
+//    until round 3; blocks above glibc's 32 MB ceiling of that threshold -- tmLQCD's fields at production sizes -- are mappings of
+//    their own in any case);
+//  * private and anonymous ("rw-p", no file): the handler swaps pages in with mremap(MREMAP_FIXED), which would silently turn a
+//    MAP_SHARED / file-backed / hugetlb / SysV segment into private memory.
+// Anything else is simply not watched: it is copied on every call, as in the coherent mode.  /proc/self/maps is read when a mirror is
+// made (or its array was re-mapped), in entry-point context.
+uintptr_t g_heap_lo = 0;   // start of the "[heap]" mapping (the initial program break: it never moves), 1 = there is none
+bool below_program_break(const void *host) { return g_heap_lo > 1 && (uintptr_t)host >= g_heap_lo && (uintptr_t)host < (uintptr_t)sbrk(0); }
+const char *unwatchable(const void *host, size_t bytes) {
   const uintptr_t a = (uintptr_t)host, b = a + bytes;
-  const uintptr_t brk_now = (uintptr_t)sbrk(0);
-  if (hi != brk_now || !lo) {          // (first call, or the heap has grown / shrunk)
-    lo = hi = 0;
-    if (FILE *fp = fopen("/proc/self/maps", "r")) {
-      char line[512];
-      while (fgets(line, sizeof(line), fp)) {
-        if (!strstr(line, "[heap]")) continue;
-        unsigned long x = 0, y = 0;
-        if (sscanf(line, "%lx-%lx", &x, &y) == 2) { lo = x; hi = y; }
-        break;
-      }
-      fclose(fp);
+  FILE *fp = fopen("/proc/self/maps", "r");
+  if (!fp) return "cannot read /proc/self/maps";
+  const char *why = "not mapped";
+  char line[512];
+  bool found = false, arena_candidate = false;
+  unsigned long flo = 0, fhi = 0;
+  while (fgets(line, sizeof(line), fp)) {
+    unsigned long lo = 0, hi = 0, off = 0, ino = 0; char perm[8] = "", dev[16] = ""; int consumed = 0;
+    if (sscanf(line, "%lx-%lx %7s %lx %15s %lu %n", &lo, &hi, perm, &off, dev, &ino, &consumed) < 6) continue;
+    const char *name = line + consumed;
+    if (found) {   // the line after the array's mapping: a thread arena is read-write memory followed by its PROT_NONE reserve up to the 64 MB boundary
+      if (arena_candidate && lo == fhi && !strncmp(perm, "---p", 4) && hi == flo + ((unsigned long)64 << 20)) why = "inside a thread's malloc arena";
+      break;
     }
-    if (!lo) { lo = 1; hi = 0; }        // no heap mapping at all
-    if (hi < brk_now && lo > 1) hi = brk_now;
+    if (!g_heap_lo && strstr(name, "[heap]")) g_heap_lo = lo;
+    if (a >= lo && a < hi) {
+      found = true; flo = lo; fhi = hi;
+      if (b > hi) { why = "spans several mappings"; break; }
+      if (strstr(name, "[heap]")) { why = "inside the malloc heap"; break; }
+      if (perm[3] != 'p') { why = "a shared mapping"; break; }
+      if (ino != 0 || (name[0] && name[0] != '\n')) { why = "a file-backed or named mapping"; break; }
+      if (perm[0] != 'r' || perm[1] != 'w') { why = "not read-write memory"; break; }
+      why = nullptr;
+      arena_candidate = (lo % ((unsigned long)64 << 20)) == 0 && hi - lo <= ((unsigned long)64 << 20);
+      if (arena_candidate && hi - lo == ((unsigned long)64 << 20)) { why = "inside a thread's malloc arena"; break; }   // (a full arena has no reserve behind it)
+      if (!arena_candidate) break;
+    }
   }
-  return lo > 1 && a < hi && b > lo;
+  fclose(fp);
+  if (!g_heap_lo) g_heap_lo = 1;   // (the heap line comes before any mmap region: if it was not seen up to the array's line, take the break as it is)
+  return why;
 }
 
 Mirror &mirror(tmhip_ctx *c, const void *host, int kind, int n = 0) {
   RegLock lk;
   const size_t bytes = (size_t)(kind == KIND_LIN ? n : nsites(kind)) * sizeof(spinor);
   const bool known = g_reg.find(host) != g_reg.end();
+  bool remapped = false;
   if (!known) evict_if_crowded(c, host);
   if (g_mode == TMLQCD_HIP_LAZY) {
     // One device mirror per host byte, checked on EVERY call: an array the program now addresses from another base (the halves of
@@ -474,22 +535,42 @@ Mirror &mirror(tmhip_ctx *c, const void *host, int kind, int n = 0) {
       if (g_reg[o].f) tmhip_field_free(c, g_reg[o].f);
       g_reg.erase(o);
     }
+    if (!overlap.empty()) rebuild_watch();
     if (known && mapping_replaced(host, g_reg[host])) {   // freed and re-allocated at the same address: the host copy is the truth
+      remapped = true;
       Mirror &old = g_reg[host];
-      old.dev_valid = false; old.host_valid = true; old.prot = P_RW; old.page_ok.clear(); old.faults = 0;
+      old.dev_valid = false; old.host_valid = true; old.prot = P_RW; std::fill(old.page_ok.begin(), old.page_ok.end(), 0); old.faults = 0;
     }
   }
+  // (the main heap may have grown over a recycled address since the array was classified: one comparison with the program break, no file)
+  const bool reclassify = g_mode == TMLQCD_HIP_LAZY && known && g_reg[host].prot == P_RW && !g_reg[host].nowatch && below_program_break(host);
   Mirror &m = g_reg[host];
   if (m.f && (m.kind != kind || (kind == KIND_LIN && m.n != n))) {   // same host buffer re-used with another shape (or another prefix length)
     release_host(c, host, m);
     tmhip_field_free(c, m.f);
     m = Mirror();
   }
+  bool fresh = false;
   if (!m.f) {
     CK(tmhip_field_alloc(c, kind == KIND_LIN ? TMHIP_FIELD_FULL : kind, &m.f));
     m.kind = kind; m.n = n; m.dev_valid = false; m.host_valid = true; m.bytes = bytes; m.prot = P_RW;
+    fresh = true;
   }
-  if (g_mode == TMLQCD_HIP_LAZY && m.prot == P_RW) m.nowatch = in_malloc_heap(host, bytes);   // (decided while the array is unwatched; the heap may have grown over a recycled address)
+  if (g_mode == TMLQCD_HIP_LAZY && m.prot == P_RW && (fresh || reclassify || remapped || !m.classified)) {
+    // decided while the array is unwatched, and everything the fault handler will need for it is made NOW
+    const char *why = unwatchable(host, bytes);
+    static const bool force = getenv("TMLQCD_HIP_LAZY_FORCE_WATCH") != nullptr;     // test hook: watch it anyway, a fault on it must end loudly
+    m.nowatch = why != nullptr && !force;
+    m.unsafe = why != nullptr && force;
+    m.classified = true;
+    static const bool dbg = getenv("TMLQCD_HIP_LAZY_DEBUG") != nullptr;
+    if (why && dbg) fprintf(stderr, "[tmlqcd_dropin] lazy mode: the array at %p (%zu bytes) is %s: %s\n", host, bytes, force ? "WATCHED ALTHOUGH IT SHOULD NOT BE (test hook)" : "not watched, copied per call", why);
+    if (!m.nowatch) {
+      prepare_handler_buffers(bytes);
+      m.page_ok.assign((span_hi(host, bytes) - span_lo(host)) / g_page, 0);
+    }
+  }
+  if (!known || fresh) rebuild_watch();
   m.last_use = ++g_tick;   // after the reset above: a mirror in use by the current call must never be the eviction victim of its sibling
   return m;
 }
@@ -521,7 +602,27 @@ void done(tmhip_ctx *c, const void *host) {
   }
 }
 
-// SIGSEGV on a protected page of a mirrored host array (lazy mode); anything else goes to the handler that was there before
+// SIGSEGV on a protected page of a mirrored host array (lazy mode); anything else goes to the handler that was there before.
+//
+// What this handler may do, and why it cannot hang (round-3 review, item 5; the hang of gpurun_out/r03_mp_*.log was a fault taken
+// inside malloc, on a watched page of the malloc heap, with the handler's callees then waiting for the allocator's lock):
+//  * It allocates nothing itself: the table it walks is a fixed array (g_watch), every mirror's page map was sized when the mirror
+//    was made, its page-locked buffers (staging buffer of the largest watched array, the 64-spinor page buffer) exist before an array is
+//    first watched (prepare_handler_buffers).  A request beyond them ends the program with a message (handler_die), never a retry.
+//  * It DOES enter the HIP runtime: tmhip_field_download_range = one kernel launch that writes into page-locked memory + a stream
+//    synchronisation.  The runtime takes its own locks there and may allocate.  That is safe because the INTERRUPTED thread can hold
+//    neither a runtime lock nor an allocator lock at the moment of the fault:
+//      - the only code that ever touches a watched page is the program's own loads and stores and this library's host -> bounce
+//        memcpy of an upload (which holds only the registry lock, recursive for its owner).  The HIP runtime never sees a pointer
+//        into the program's arrays in this mode -- every transfer goes through the page-locked bounce buffers -- so no fault can be
+//        raised from inside the runtime (the "bounce-buffer argument");
+//      - no watched page holds allocator state: arrays inside a malloc arena, main or per-thread, are not watched (unwatchable());
+//        an mmap'ed block's own header lies in front of the user pointer, and free() of such a block takes no arena lock.
+//    ANOTHER thread may be inside the runtime or the allocator (the master thread in an entry point while an OpenMP worker faults):
+//    then this handler waits for an ordinary lock whose holder is running -- a delay, not a cycle; the registry lock is the only one
+//    held across, and its holder never waits for a faulting thread.
+//  * TMLQCD_HIP_LAZY_FORCE_WATCH (test hook) watches an unwatchable array anyway; a fault on one of its pages is answered with a
+//    message and _exit(1) before anything else is called (tests/test_gpu_lazy.py).
 void lazy_fault(int sig, siginfo_t *si, void *uctx) {
   const uintptr_t addr = (uintptr_t)si->si_addr, page = addr & ~(g_page - 1);
   bool ours = false;
@@ -535,12 +636,13 @@ void lazy_fault(int sig, siginfo_t *si, void *uctx) {
     RegLock lk;
     g_handler_thread.store((uintptr_t)pthread_self(), std::memory_order_relaxed);
     const bool store = (((ucontext_t *)uctx)->uc_mcontext.gregs[REG_ERR] & 2) != 0;
-    for (auto &kv : g_reg) {
-      Mirror &m = kv.second;
-      const void *host = kv.first;
+    for (int wk = 0; wk < g_nwatch; wk++) {
+      Mirror &m = *g_watch[wk].m;
+      const void *host = g_watch[wk].host;
       if (!m.bytes || page < span_lo(host) || page >= span_hi(host, m.bytes)) continue;
       ours = true;                                   // (also when another thread has opened the page in the meantime: just run again)
       if (m.prot == P_RW) continue;
+      if (m.unsafe) handler_die("[tmlqcd_dropin] fatal: lazy mode: fault on a watched page of an array that must not be watched (malloc arena / shared mapping; TMLQCD_HIP_LAZY_FORCE_WATCH): ending instead of risking a deadlock\n");
       if (store) {
         g_lazy_stats[3]++;                                   // the host is about to change the array: its copy becomes the only good one
         if (!m.host_valid) download(g_ctx, host, m);
@@ -555,9 +657,9 @@ void lazy_fault(int sig, siginfo_t *si, void *uctx) {
         } else {
           const uintptr_t base = (uintptr_t)host, lo = page > base ? page : base, hi = page + g_page < base + m.bytes ? page + g_page : base + m.bytes;
           const int s0 = (int)((lo - base) / sizeof(spinor)), s1 = (int)((hi - base + sizeof(spinor) - 1) / sizeof(spinor));
-          static void *tmp = nullptr;                 // page-locked: see bounce()
-          if (!tmp) CK(tmhip_pinned_alloc(64 * sizeof(spinor), &tmp));
-          if (tmhip_field_download_range(g_ctx, m.f, tmp, s0, s1 - s0)) die("lazy synchronisation of a page failed");
+          void *tmp = g_page_tmp;                     // page-locked, made when the first array was watched (prepare_handler_buffers)
+          if (!tmp || s1 - s0 > 64) handler_die("[tmlqcd_dropin] fatal: lazy mode: no page buffer for a page-wise fetch\n");
+          if (tmhip_field_download_range(g_ctx, m.f, tmp, s0, s1 - s0)) handler_die("[tmlqcd_dropin] fatal: lazy synchronisation of a page failed\n");
           m.page_ok[idx] = 1;
           const char *from = (const char *)tmp + (lo - (base + (size_t)s0 * sizeof(spinor)));
           if (!install_pages(lo, hi - lo, page, page + g_page, from)) {
@@ -590,14 +692,7 @@ void lazy_fault(int sig, siginfo_t *si, void *uctx) {
 void install_lazy_handler() {
   if (g_handler_installed) return;
   g_page = (uintptr_t)sysconf(_SC_PAGESIZE);
-  // Arrays the library watches must never be recycled INSIDE the malloc heap: free() of a heap chunk writes its bookkeeping into the
-  // chunk, i.e. into a protected page, and the fault would be taken while the allocator holds its lock -- the handler's own
-  // allocations (HIP runtime) then wait for that lock for ever.  glibc serves requests above M_MMAP_THRESHOLD by mmap and gives
-  // them back by munmap, but RAISES the threshold to the size of every mmap'ed block it frees (up to 32 MB): a second work field
-  // of the same size would then come from the heap.  Setting the threshold explicitly switches that adjustment off, so every
-  // field-sized block stays an mmap of its own (and a freed one is recognised by mapping_replaced / host_unmapped).
-  // (Not a guarantee -- a request is still served from the heap when a free chunk fits: in_malloc_heap() keeps such arrays unwatched.)
-  mallopt(M_MMAP_THRESHOLD, 128 * 1024);
+  // (the program's malloc settings are left alone: arrays that cannot be watched are recognised one by one, unwatchable())
   struct sigaction sa;
   memset(&sa, 0, sizeof(sa));
   sa.sa_sigaction = lazy_fault;
@@ -657,6 +752,7 @@ void tmlqcd_hip_forget(spinor *field) {
   if (it->second.prot != P_RW) { it->second.host_valid = true; set_prot(field, it->second, P_RW, g_reg); }   // (the array is being freed: nothing to fetch)
   if (it->second.f) tmhip_field_free(g_ctx, it->second.f);
   g_reg.erase(it);
+  rebuild_watch();
 }
 void tmlqcd_hip_comm_init(const char unique_id[128]) { CK(tmhip_comm_init(ctx(), unique_id)); }
 void tmlqcd_hip_comm_init_shm(const char *job) { CK(tmhip_comm_init_shm(ctx(), job)); }
@@ -667,8 +763,11 @@ void tmlqcd_hip_finalize(void) {
   tmlqcd_hip_sync_all_to_host();
   for (auto &kv : g_reg) { if (kv.second.prot != P_RW) set_prot(kv.first, kv.second, P_RW, g_reg); if (kv.second.f) tmhip_field_free(g_ctx, kv.second.f); }
   g_reg.clear();
+  g_nwatch = 0;
   if (g_full_tmp) { tmhip_field_free(g_ctx, g_full_tmp); g_full_tmp = nullptr; }
+  for (int k = 0; k < 3; k++) if (g_f32[k]) { tmhip_field_free(g_ctx, g_f32[k]); g_f32[k] = nullptr; }
   for (int k = 0; k < 2; k++) if (g_bounce[k]) { tmhip_pinned_free(g_bounce[k]); g_bounce[k] = nullptr; g_bounce_bytes[k] = 0; }
+  if (g_page_tmp) { tmhip_pinned_free(g_page_tmp); g_page_tmp = nullptr; }
   tmhip_destroy(g_ctx);
   g_ctx = nullptr;
   g_gauge_uploaded = false;
@@ -1219,6 +1318,113 @@ void assign_mul_one_pm_imu_inv_32(spinor32 *const l, spinor32 *const k, const do
 void mul_one_pm_imu_sub_mul_32(spinor32 *const l, spinor32 *const k, spinor32 *const j, const double _sign, const int N) {
   tmhip_ctx *c = refresh(false);
   CK(tmhip_diag32_host(c, l, k, j, 1., (_sign < 0. ? -1. : 1.) * g_mu, N));
+}
+
+// ------------------------------------------------------------------ fp32 twins on host spinor32 arrays
+// Hopping_Matrix_32 (operator/Hopping_Matrix_32.c:97-127), Qtm_pm_psi_32 (operator/tm_operators_32.c:94-112) and the fp32 linalg
+// (linalg/*_32.c) by their reference names.  Host spinor32 arrays are not kept in the registry (the solvers that iterate in fp32 --
+// mixed_cg_her, rg_mixed_cg_her -- run device-resident through their own entry points below): every call copies its operands in and its
+// result out through a small pool of device fields, i.e. the coherent semantics of the fp64 symbols, PCIe-bound and exact.
+// The `_orphaned` convention (SURVEY 8b "Threading"): the reference's fp32 operators are called INSIDE an enclosing OpenMP parallel
+// region by all its threads (Qtm_pm_psi_32 opens the region, operator/tm_operators_32.c:96-110).  Here ONE thread issues the device
+// call and all threads of the team meet before and after it -- orphaned `omp barrier` / `omp master`, which bind to whatever
+// region encloses the call and are no-ops outside of one (this file is compiled with -fopenmp).
+extern "C++" {
+namespace {
+tmhip_field *f32(tmhip_ctx *c, int k) {
+  if (!g_f32[k]) CK(tmhip_field_alloc32(c, &g_f32[k]));
+  return g_f32[k];
+}
+tmhip_field *in32(tmhip_ctx *c, int k, const spinor32 *host, int N) {
+  tmhip_field *f = f32(c, k);
+  CK(tmhip_field_upload32(c, f, host, N));
+  return f;
+}
+void need_N32(int N, const char *who) {
+  if (N < 0 || N > VOLUME / 2) { fprintf(stderr, "[tmlqcd_dropin] %s: N = %d outside [0, VOLUME/2] (fp32 fields are one-parity fields)\n", who, N); exit(1); }
+}
+template <class F> inline void team_once(F body) {
+#pragma omp barrier
+#pragma omp master
+  body();
+#pragma omp barrier
+}
+}  // namespace
+}  // extern "C++"
+
+void Hopping_Matrix_32(const int ieo, spinor32 *const l, spinor32 *const k) {   /* called from the master thread outside any parallel region */
+  tmhip_ctx *c = refresh(true);
+  if ((void *)l == (void *)k) die("Hopping_Matrix_32: l and k must differ");
+  tmhip_field *fk = in32(c, 0, k, VOLUME / 2), *fl = f32(c, 1);
+  CK(tmhip_hopping_matrix_32(c, ieo, fl, fk));
+  CK(tmhip_field_download32(c, fl, l, VOLUME / 2));
+}
+void Hopping_Matrix_32_orphaned(const int ieo, spinor32 *const l, spinor32 *const k) {   /* by every thread of the enclosing team */
+  team_once([&] { Hopping_Matrix_32(ieo, l, k); });
+}
+void Qtm_pm_psi_32(spinor32 *const l, spinor32 *const k) {
+  tmhip_ctx *c = refresh(true);
+  tmhip_field *fk = in32(c, 0, k, VOLUME / 2), *fl = f32(c, 1);
+  CK(tmhip_Qtm_pm_psi_32(c, fl, fk));
+  CK(tmhip_field_download32(c, fl, l, VOLUME / 2));
+}
+float square_norm_32(const spinor32 *const P, const int N, const int parallel) {   /* linalg/square_norm_32.c:95 */
+  tmhip_ctx *c = refresh(false);
+  need_N32(N, "square_norm_32");
+  if (N == 0) return 0.f;
+  double r = 0;
+  CK(tmhip_square_norm_32(c, in32(c, 0, P, N), N, parallel, &r));
+  return (float)r;
+}
+float scalar_prod_r_32(const spinor32 *const S, const spinor32 *const R, const int N, const int parallel) {   /* linalg/scalar_prod_r_32.c:109 */
+  tmhip_ctx *c = refresh(false);
+  need_N32(N, "scalar_prod_r_32");
+  if (N == 0) return 0.f;
+  double r = 0;
+  tmhip_field *fs = in32(c, 0, S, N), *fr = (const void *)S == (const void *)R ? fs : in32(c, 1, R, N);
+  CK(tmhip_scalar_prod_r_32(c, fs, fr, N, parallel, &r));
+  return (float)r;
+}
+void assign_add_mul_r_32(spinor32 *const R, spinor32 *const S, const float cc, const int N) {   /* linalg/assign_add_mul_r_32.c:104: R += c S */
+  tmhip_ctx *c = refresh(false);
+  need_N32(N, "assign_add_mul_r_32");
+  if (N == 0) return;
+  tmhip_field *fr = in32(c, 0, R, N), *fs = (void *)S == (void *)R ? fr : in32(c, 1, S, N);
+  CK(tmhip_assign_add_mul_r_32(c, fr, fs, cc, N));
+  CK(tmhip_field_download32(c, fr, R, N));
+}
+void assign_mul_add_r_32(spinor32 *const R, const float cc, const spinor32 *const S, const int N) {   /* linalg/assign_mul_add_r_32.c:81: R = c R + S */
+  tmhip_ctx *c = refresh(false);
+  need_N32(N, "assign_mul_add_r_32");
+  if (N == 0) return;
+  tmhip_field *fr = in32(c, 0, R, N), *fs = (const void *)S == (const void *)R ? fr : in32(c, 1, S, N);
+  CK(tmhip_assign_mul_add_r_32(c, fr, cc, fs, N));
+  CK(tmhip_field_download32(c, fr, R, N));
+}
+void diff_32(spinor32 *const Q, const spinor32 *const R, const spinor32 *const S, const int N) {   /* linalg/diff_32.c:39: Q = R - S */
+  tmhip_ctx *c = refresh(false);
+  need_N32(N, "diff_32");
+  if (N == 0) return;
+  tmhip_field *fq = in32(c, 0, S, N), *fr = in32(c, 1, R, N);     // Q = -1 * S + R
+  CK(tmhip_assign_mul_add_r_32(c, fq, -1.f, fr, N));
+  CK(tmhip_field_download32(c, fq, Q, N));
+}
+void assign_to_32(spinor32 *const R, spinor *const S, const int N) {   /* linalg/assign_to_32.c:37: the fp64 operand goes through the registry like any other input */
+  tmhip_ctx *c = refresh(false);
+  need_N32(N, "assign_to_32");
+  if (N == 0) return;
+  tmhip_field *fs = in(c, S, TMHIP_FIELD_EO), *fr = f32(c, 0);
+  CK(tmhip_assign_to_32(c, fr, fs, N));
+  CK(tmhip_field_download32(c, fr, R, N));
+}
+void assign_to_64(spinor *const R, spinor32 *const S, const int N) {   /* linalg/assign_to_32.c:84 */
+  tmhip_ctx *c = refresh(false);
+  need_N32(N, "assign_to_64");
+  if (N == 0) return;
+  if (N != VOLUME / 2) die("assign_to_64: N must be VOLUME/2 (the fp64 result is a registered one-parity field)");
+  tmhip_field *fs = in32(c, 0, S, N), *fr = out(c, R, TMHIP_FIELD_EO);
+  CK(tmhip_assign_to_64(c, fr, fs, N));
+  done(c, R);
 }
 
 // ------------------------------------------------------------------ solver

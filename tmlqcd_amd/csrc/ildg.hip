@@ -310,7 +310,8 @@ int sums_fetch(tmhip_ctx *ctx, unsigned out[2]) {
   return 0;
 }
 // XOR of the checksum words over the ranks (io/dml.c:63-66): RCCL has no bit-wise XOR reduction, so the words are gathered
-int sums_combine(tmhip_ctx *ctx, unsigned sums[2]) {
+// any_nonzero: the words are error flags, not checksums -- combined as "did ANY rank report one" (an XOR lets two ranks' flags cancel)
+int sums_combine(tmhip_ctx *ctx, unsigned sums[2], bool any_nonzero = false) {
   int n = ctx->g.nproc_t;
   if (!ctx->shm) TMHIP_NCCL_CHECK(ncclCommCount(ctx->comm_red, &n));
   if (n < 1 || n > ILDG_SLOTS) TMHIP_FAIL("sums_combine: %d ranks", n);
@@ -322,7 +323,10 @@ int sums_combine(tmhip_ctx *ctx, unsigned sums[2]) {
   TMHIP_CHECK(hipMemcpyAsync(h.data(), ctx->io_sums + 2, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   sums[0] = sums[1] = 0;
-  for (int k = 0; k < n; k++) { sums[0] ^= h[2 * k]; sums[1] ^= h[2 * k + 1]; }
+  for (int k = 0; k < n; k++) {
+    if (any_nonzero) { sums[0] |= h[2 * k]; sums[1] |= h[2 * k + 1]; }
+    else { sums[0] ^= h[2 * k]; sums[1] ^= h[2 * k + 1]; }
+  }
   return 0;
 }
 IldgGeom io_geom(const tmhip_ctx *ctx) {
@@ -485,21 +489,25 @@ int tmhip_write_gauge_field(tmhip_ctx *ctx, const char *filename, int prec, cons
   const unsigned long long data_pos = (have_xlf ? 144 + padded(strlen(xlf_info)) : 0) + 144 + padded(strlen(fmt)) + 144;   // where the binary record's data begins
   FILE *fp = nullptr;
   int bad = 0;
+  // A rank that cannot open the file does NOT leave: both collectives below are reached by every rank, whatever happened to it (a rank
+  // that returned early left the others waiting in the gather without a bound), and its error reaches everybody through the second one.
   if (rk == 0) {
     fp = fopen(filename, "wb");
-    if (!fp) { (void)hipHostFree(buf); TMHIP_FAIL("write_gauge_field: cannot create %s", filename); }
-    if (have_xlf) bad = bad || lime_write_message(fp, 1, 1, "xlf-info", xlf_info);
-    bad = bad || lime_write_message(fp, 1, 0, "ildg-format", fmt);
-    bad = bad || lime_write_header(fp, 0, 0, "ildg-binary-data", bytes);
-    bad = bad || ftell(fp) != (long)data_pos || fflush(fp);
+    if (!fp) { fprintf(stderr, "[tmlqcd_hip] write_gauge_field: cannot create %s\n", filename); bad = 1; }
+    else {
+      if (have_xlf) bad = bad || lime_write_message(fp, 1, 1, "xlf-info", xlf_info);
+      bad = bad || lime_write_message(fp, 1, 0, "ildg-format", fmt);
+      bad = bad || lime_write_header(fp, 0, 0, "ildg-binary-data", bytes);
+      bad = bad || ftell(fp) != (long)data_pos || fflush(fp);
+    }
   }
   if (np > 1 && sums_combine(ctx, cs)) { if (fp) fclose(fp); (void)hipHostFree(buf); return 1; }   // XOR over the ranks; nobody gets here before rank 0 has created the file
   if (rk != 0) {
     fp = fopen(filename, "r+b");
-    if (!fp) { (void)hipHostFree(buf); TMHIP_FAIL("write_gauge_field: rank %d cannot open %s", rk, filename); }
+    if (!fp) { fprintf(stderr, "[tmlqcd_hip] write_gauge_field: rank %d cannot open %s\n", rk, filename); bad = 1; }
   }
-  bad = bad || fseek(fp, (long)(data_pos + (unsigned long long)rk * part), SEEK_SET) || (fwrite(buf, 1, part, fp) != part);
-  if (rk == 0) {
+  if (fp) bad = bad || fseek(fp, (long)(data_pos + (unsigned long long)rk * part), SEEK_SET) || (fwrite(buf, 1, part, fp) != part);
+  if (rk == 0 && fp) {
     snprintf(chk, sizeof(chk), "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n<scidacChecksum>\n  <version>1.0</version>\n  <suma>%08x</suma>\n  <sumb>%08x</sumb>\n</scidacChecksum>",
              cs[0], cs[1]);                                                                     // io/utils_write_checksum.c:30-35
     static const unsigned char zero[8] = {0};
@@ -507,9 +515,9 @@ int tmhip_write_gauge_field(tmhip_ctx *ctx, const char *filename, int prec, cons
     if (!bad && bytes % 8) bad = fwrite(zero, 1, 8 - bytes % 8, fp) != 8 - bytes % 8;
     bad = bad || lime_write_message(fp, 0, 1, "scidac-checksum", chk);
   }
-  bad = fclose(fp) || bad;
+  if (fp) bad = fclose(fp) || bad;
   (void)hipHostFree(buf);
-  if (np > 1) { unsigned done[2] = {bad ? 1u << (rk & 31) : 0u, 0}; if (sums_combine(ctx, done)) return 1; bad = bad || done[0]; }   // every part is in the file (and any rank's error is everybody's)
+  if (np > 1) { unsigned done[2] = {bad ? 1u : 0u, 0}; if (sums_combine(ctx, done, true)) return 1; bad = bad || done[0]; }   // every part is in the file (and any rank's error is everybody's: OR, not XOR)
   if (bad) TMHIP_FAIL("write_gauge_field: error while writing %s", filename);
   if (sums) { sums[0] = cs[0]; sums[1] = cs[1]; }
   return 0;

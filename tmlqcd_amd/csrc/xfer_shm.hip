@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cerrno>
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
@@ -38,7 +39,10 @@ struct Header {
   std::atomic<int> arrived, left;
   int nranks;
   unsigned long long mailbox_bytes;
-  char pad[32];
+  int creator_pid;                     // rank 0 of the run that made this segment: a joiner that finds it dead has opened a leftover
+  int pad0;
+  unsigned long long nonce;            // its start time: told apart from an earlier run that recycled the pid
+  char pad[16];
 };
 static_assert(sizeof(Mailbox) == 64 && sizeof(Slot) == 128 && sizeof(Header) == 64, "layout shared between processes");
 const unsigned long long MAGIC = 0x746d6869705f7368ull;
@@ -148,34 +152,99 @@ extern "C" int tmhip_comm_init_shm(tmhip_ctx *ctx, const char *job) {
   s->timeout_s = ctx->flag_timeout_ticks ? (double)ctx->flag_timeout_ticks * 1.0e-8 : 0.0;
   const size_t per_rank = 2 * (sizeof(Mailbox) + s->mailbox_bytes) + 2 * sizeof(Slot);
   s->total = sizeof(Header) + (size_t)s->nranks * per_rank;
+  // Meeting in the segment is bounded by INIT_WAIT_S whatever the flag timeout says (0 = none must not mean "wait for a rank that died
+  // before it got here" for ever), and a segment left behind by a job that died during ITS meeting is recognised, not joined:
+  // rank 0 removes the name and creates the segment anew (O_EXCL), stamping it with its pid and start time; a joiner takes a segment
+  // only while its creator is alive and not everybody has arrived in it yet, and otherwise lets go of it and opens the name again.
+  const double INIT_WAIT_S = 120.0;
+  const auto t_init = std::chrono::steady_clock::now();
+  auto init_left = [&]() { return INIT_WAIT_S - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_init).count(); };
+  auto fail = [&](int fd_) { if (fd_ >= 0) close(fd_); if (s->base && s->base != MAP_FAILED) munmap(s->base, s->total); delete s; };
   int fd = -1;
   if (s->rank == 0) {
     shm_unlink(s->name);
     fd = shm_open(s->name, O_CREAT | O_EXCL | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, (off_t)s->total)) TMHIP_FAIL("tmhip_comm_init_shm: cannot create %s (%zu bytes): %s", s->name, s->total, strerror(errno));
+    if (fd < 0 || ftruncate(fd, (off_t)s->total)) {
+      fprintf(stderr, "[tmlqcd_hip] tmhip_comm_init_shm: cannot create %s (%zu bytes): %s\n", s->name, s->total, strerror(errno));
+      fail(fd);
+      return 1;
+    }
+    s->base = mmap(nullptr, s->total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd); fd = -1;
+    if (s->base == MAP_FAILED) { fprintf(stderr, "[tmlqcd_hip] tmhip_comm_init_shm: mmap of %s failed: %s\n", s->name, strerror(errno)); fail(-1); return 1; }
+    s->hdr = (Header *)s->base;       // (a fresh segment is zero-filled: counters and sequence numbers start at 0)
+    s->hdr->nranks = s->nranks; s->hdr->mailbox_bytes = s->mailbox_bytes;
+    s->hdr->creator_pid = (int)getpid();
+    s->hdr->nonce = (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count();
+    s->hdr->magic.store(MAGIC, std::memory_order_release);
+    s->hdr->arrived.fetch_add(1);
   } else {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
+    for (;;) {   // until this rank sits in a segment that fills up
+      if (init_left() <= 0) { fprintf(stderr, "[tmlqcd_hip] tmhip_comm_init_shm: rank 0 did not create a live %s within %.0f s\n", s->name, INIT_WAIT_S); fail(fd); return 1; }
       fd = shm_open(s->name, O_RDWR, 0600);
       struct stat st;
-      if (fd >= 0 && !fstat(fd, &st) && (size_t)st.st_size == s->total) break;
-      if (fd >= 0) { close(fd); fd = -1; }
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) TMHIP_FAIL("tmhip_comm_init_shm: rank 0 did not create %s", s->name);
-      std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      if (fd < 0 || fstat(fd, &st) || (size_t)st.st_size != s->total) {
+        if (fd >= 0) { close(fd); fd = -1; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        continue;
+      }
+      const ino_t ino = st.st_ino;
+      void *b = mmap(nullptr, s->total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd); fd = -1;
+      if (b == MAP_FAILED) { fprintf(stderr, "[tmlqcd_hip] tmhip_comm_init_shm: mmap of %s failed: %s\n", s->name, strerror(errno)); fail(-1); return 1; }
+      Header *h = (Header *)b;
+      // wait (briefly) for the creator's stamp, then judge the segment
+      bool seated = false;
+      for (int spin = 0; spin < 400 && init_left() > 0; spin++) {
+        if (h->magic.load(std::memory_order_acquire) == MAGIC) {
+          const bool alive = h->creator_pid > 0 && (kill((pid_t)h->creator_pid, 0) == 0 || errno == EPERM);
+          if (h->nranks != s->nranks || h->mailbox_bytes != s->mailbox_bytes) {
+            fprintf(stderr, "[tmlqcd_hip] tmhip_comm_init_shm: %s belongs to another job (ranks / lattice differ)\n", s->name);
+            munmap(b, s->total); fail(-1);
+            return 1;
+          }
+          // claim a seat; a segment in which everybody had already arrived (or whose creator is gone) is a leftover of a dead run
+          if (alive) {
+            if (h->arrived.fetch_add(1) < s->nranks) seated = true;
+            else h->arrived.fetch_sub(1);
+          }
+          break;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      }
+      // seated: wait for the others -- but keep an eye on the NAME: if it now leads to another segment (or to none, while seats are still
+      // empty here), this one is the leftover of a run that died during its meeting and the live run's rank 0 has started over
+      bool full = false, stale = !seated;
+      for (unsigned it = 0; seated && !full && !stale && init_left() > 0; it++) {
+        full = h->arrived.load() >= s->nranks;
+        if (full) break;
+        if (it % 64 == 63) {
+          const int fd2 = shm_open(s->name, O_RDWR, 0600);
+          struct stat st2;
+          if (fd2 < 0) stale = h->arrived.load() < s->nranks;
+          else { stale = !fstat(fd2, &st2) && st2.st_ino != ino; close(fd2); }
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(it < 2000 ? 50 : 2000));
+      }
+      if (full) { s->base = b; s->hdr = h; break; }
+      if (seated && !stale) { fprintf(stderr, "[tmlqcd_hip] tmhip_comm_init_shm: only %d of %d ranks arrived in %s within %.0f s\n", h->arrived.load(), s->nranks, s->name, INIT_WAIT_S); munmap(b, s->total); fail(-1); return 1; }
+      munmap(b, s->total);
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
   }
-  s->base = mmap(nullptr, s->total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (s->base == MAP_FAILED) TMHIP_FAIL("tmhip_comm_init_shm: mmap of %s failed: %s", s->name, strerror(errno));
-  s->hdr = (Header *)s->base;
-  if (s->rank == 0) {     // (a fresh segment is zero-filled: counters and sequence numbers start at 0)
-    s->hdr->nranks = s->nranks; s->hdr->mailbox_bytes = s->mailbox_bytes;
-    s->hdr->magic.store(MAGIC, std::memory_order_release);
-  } else if (!wait_for(s, [&] { return s->hdr->magic.load(std::memory_order_acquire) == MAGIC; }) || s->hdr->nranks != s->nranks || s->hdr->mailbox_bytes != s->mailbox_bytes) {
-    TMHIP_FAIL("tmhip_comm_init_shm: %s belongs to another job (ranks / lattice differ)", s->name);
+  if (s->rank == 0) {
+    const double saved = s->timeout_s;
+    s->timeout_s = init_left() > 1.0 ? init_left() : 1.0;           // bounded, also with flag_timeout 0
+    const bool all = wait_for(s, [&] { return s->hdr->arrived.load() >= s->nranks; });
+    s->timeout_s = saved;
+    if (!all) {
+      fprintf(stderr, "[tmlqcd_hip] tmhip_comm_init_shm: only %d of %d ranks arrived in %s within %.0f s\n", s->hdr->arrived.load(), s->nranks, s->name, INIT_WAIT_S);
+      shm_unlink(s->name);
+      fail(-1);
+      return 1;
+    }
+    s->failed.store(0);
   }
-  s->hdr->arrived.fetch_add(1);
-  if (!wait_for(s, [&] { return s->hdr->arrived.load() == s->nranks; })) TMHIP_FAIL("tmhip_comm_init_shm: only %d of %d ranks arrived", s->hdr->arrived.load(), s->nranks);
   if (s->rank == 0) shm_unlink(s->name);   // everybody has it mapped: the name can go, the memory goes with the last rank
   for (int k = 0; k < 2; k++) {
     TMHIP_CHECK(hipHostMalloc((void **)&s->stage_send[k], s->mailbox_bytes, hipHostMallocDefault));
