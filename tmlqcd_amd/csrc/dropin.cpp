@@ -15,6 +15,7 @@
 
 #include <atomic>
 #include <cerrno>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <pthread.h>
 #include <signal.h>
@@ -485,35 +486,45 @@ const char *unwatchable(const void *host, size_t bytes) {
   const uintptr_t a = (uintptr_t)host, b = a + bytes;
   FILE *fp = fopen("/proc/self/maps", "r");
   if (!fp) return "cannot read /proc/self/maps";
-  const char *why = "not mapped";
+  // The array may lie in SEVERAL lines: this library's own mprotect calls (a neighbouring field's read-only or closed pages) split the
+  // block's mapping by protection.  So the contiguous run of private anonymous lines around it is taken as a whole, whatever their
+  // permissions are at the moment; it must cover [a, b).
+  const char *why = nullptr;
   char line[512];
-  bool found = false, arena_candidate = false;
-  unsigned long flo = 0, fhi = 0;
+  bool in_run = false, last_none = false;
+  unsigned long first_lo = 0, covered = 0;
+  const unsigned long ARENA = (unsigned long)64 << 20;     // glibc's HEAP_MAX_SIZE
   while (fgets(line, sizeof(line), fp)) {
     unsigned long lo = 0, hi = 0, off = 0, ino = 0; char perm[8] = "", dev[16] = ""; int consumed = 0;
     if (sscanf(line, "%lx-%lx %7s %lx %15s %lu %n", &lo, &hi, perm, &off, dev, &ino, &consumed) < 6) continue;
     const char *name = line + consumed;
-    if (found) {   // the line after the array's mapping: a thread arena is read-write memory followed by its PROT_NONE reserve up to the 64 MB boundary
-      if (arena_candidate && lo == fhi && !strncmp(perm, "---p", 4) && hi == flo + ((unsigned long)64 << 20)) why = "inside a thread's malloc arena";
+    const bool heap = strstr(name, "[heap]") != nullptr;
+    if (!g_heap_lo && heap) g_heap_lo = lo;
+    const bool private_anon = perm[3] == 'p' && ino == 0 && (!name[0] || name[0] == '\n');
+    if (!in_run) {
+      if (a < lo || a >= hi) continue;
+      in_run = true; first_lo = lo; covered = hi;
+      if (heap) { why = "inside the malloc heap"; break; }
+      if (perm[3] != 'p') { why = "a shared mapping"; break; }
+      if (!private_anon) { why = "a file-backed or named mapping"; break; }
+      last_none = !strncmp(perm, "---", 3);
+      continue;
+    }
+    if (lo != covered || !private_anon) {       // the run ends here
+      if (covered < b) why = lo != covered ? "not mapped contiguously" : "spans mappings of different kinds";
       break;
     }
-    if (!g_heap_lo && strstr(name, "[heap]")) g_heap_lo = lo;
-    if (a >= lo && a < hi) {
-      found = true; flo = lo; fhi = hi;
-      if (b > hi) { why = "spans several mappings"; break; }
-      if (strstr(name, "[heap]")) { why = "inside the malloc heap"; break; }
-      if (perm[3] != 'p') { why = "a shared mapping"; break; }
-      if (ino != 0 || (name[0] && name[0] != '\n')) { why = "a file-backed or named mapping"; break; }
-      if (perm[0] != 'r' || perm[1] != 'w') { why = "not read-write memory"; break; }
-      why = nullptr;
-      arena_candidate = (lo % ((unsigned long)64 << 20)) == 0 && hi - lo <= ((unsigned long)64 << 20);
-      if (arena_candidate && hi - lo == ((unsigned long)64 << 20)) { why = "inside a thread's malloc arena"; break; }   // (a full arena has no reserve behind it)
-      if (!arena_candidate) break;
-    }
+    covered = hi; last_none = !strncmp(perm, "---", 3);
+    if (covered - first_lo > ARENA) break;        // (longer than any arena: enough is known)
   }
   fclose(fp);
-  if (!g_heap_lo) g_heap_lo = 1;   // (the heap line comes before any mmap region: if it was not seen up to the array's line, take the break as it is)
-  return why;
+  if (!g_heap_lo) g_heap_lo = 1;   // (the heap line comes before any mmap region: if it was not seen up to the array's line, there is none)
+  if (!in_run) return "not mapped";
+  if (why) return why;
+  if (covered < b) return "not mapped contiguously";
+  // a thread's arena: 64 MB-aligned, read-write at the bottom, its PROT_NONE reserve up to the 64 MB boundary
+  if (first_lo % ARENA == 0 && covered == first_lo + ARENA && last_none) return "inside a thread's malloc arena";
+  return nullptr;
 }
 
 Mirror &mirror(tmhip_ctx *c, const void *host, int kind, int n = 0) {
@@ -631,7 +642,12 @@ void lazy_fault(int sig, siginfo_t *si, void *uctx) {
   // handler would be a bug of this handler: let it crash instead of recursing.
   const bool nested = in_handler_here();
   static const bool trace = getenv("TMLQCD_HIP_LAZY_DEBUG") != nullptr && atoi(getenv("TMLQCD_HIP_LAZY_DEBUG")) > 1;
-  if (trace) { char m[128]; const int n = snprintf(m, sizeof(m), "[lazy] fault %p %s enter\n", si->si_addr, (((ucontext_t *)uctx)->uc_mcontext.gregs[REG_ERR] & 2) ? "store" : "load"); (void)!write(2, m, (size_t)n); }
+  if (trace) {   // (debugging aid, TMLQCD_HIP_LAZY_DEBUG=2: names the object the faulting instruction lives in -- dladdr is not async-signal-safe)
+    Dl_info di; memset(&di, 0, sizeof(di));
+    void *ip = (void *)((ucontext_t *)uctx)->uc_mcontext.gregs[REG_RIP];
+    dladdr(ip, &di);
+    char m[384]; const int n = snprintf(m, sizeof(m), "[lazy] fault %p %s enter, instruction %p in %s (%s)\n", si->si_addr, (((ucontext_t *)uctx)->uc_mcontext.gregs[REG_ERR] & 2) ? "store" : "load", ip, di.dli_fname ? di.dli_fname : "?", di.dli_sname ? di.dli_sname : "?"); (void)!write(2, m, (size_t)n);
+  }
   if (g_ctx && si->si_code == SEGV_ACCERR && !nested) {
     RegLock lk;
     g_handler_thread.store((uintptr_t)pthread_self(), std::memory_order_relaxed);
