@@ -86,7 +86,7 @@ def test_hopping_matrix_nocom(ieo):
     # split lattice (self-exchange): a communicating call leaves k1's faces in the receive buffers, the nocom call on k2 then
     # uses them for the two t-hops that cross the boundary -- everything else comes from k2.  By linearity the expected field is
     # H k2 + (crossing hops of k1 - k2): H of the difference restricted to slice T-1 seen from slice 0, and to slice 0 from T-1.
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         lat.set_loopback(mode)
         lat.Hopping_Matrix(ieo, dl, d1)
         assert rel_err(dl.download(), H(k1)) < TOL

@@ -71,6 +71,7 @@ struct TmhipDirect {
   unsigned int *peer_arr[2];    // [0] the up neighbour's arr[1], [1] the down neighbour's arr[0]
   unsigned int *count;          // sharded count-in words of the kernels that push ahead: [1 + 32 shards][32 words] (faces_count_in, hopping_impl.inc)
   unsigned int push_seq;        // pushes issued so far (the same number on every rank: all ranks run the same sequence of stencils)
+  unsigned int last_push;       // the push the last communicating stencil consumed (Hopping_Matrix_nocom reads those faces again)
   const void *ahead_field; unsigned int ahead_push;   // the field whose faces were pushed AHEAD by the stencil that wrote it, and under which number
   int sharers;                  // ranks of this job that sit on this physical GPU (1 in production; the one-GPU rehearsals have more)
 };
