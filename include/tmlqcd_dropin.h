@@ -218,12 +218,13 @@ void tmlqcd_hip_sync_momenta_to_host(hamiltonian_field_t *const hf);
  *   arrays the device has read are write-protected, so a host store invalidates the mirror.  An UNMODIFIED host program then runs its
  *   stencil / operator loops at the HBM rate (also: environment TMLQCD_HIP_RESIDENCY=lazy).  Opt-in, for two reasons.  System calls
  *   do not fault: a field passed to write(2) / MPI while its host copy is stale must be synchronised first (tmlqcd_hip_sync_to_host).
- *   And arrays that go back to the allocator: a block the allocator unmaps (glibc: anything above its mmap threshold, which the
- *   library pins at 128 KB when the mode is switched on) is recognised when its address comes back -- a watched mirror is probed
- *   before it is trusted.  An array INSIDE the malloc heap (glibc serves a request from the heap whenever a free chunk fits, whatever the
- *   threshold says) is never watched -- its pages also hold the allocator's bookkeeping and the program's other data: it is copied on every
- *   call as in the coherent mode.  tmLQCD's fields, one calloc of hundreds of MB, are mappings of their own.  TMLQCD_HIP_LAZY_DEBUG=1 in the
- *   environment reports a SIGSEGV that is not the library's before it is passed on to the program's own handler. */
+ *   And arrays that go back to the allocator: a block the allocator unmaps (glibc: anything above its mmap threshold; the library
+ *   leaves the program's malloc settings alone) is recognised when its address comes back -- a watched mirror is probed before it is
+ *   trusted.  An array INSIDE a malloc arena (the main heap or a thread's: glibc serves a request from an arena whenever a free chunk
+ *   fits), or in a shared / file-backed / named mapping, is never watched -- recognised from /proc/self/maps when it is first seen, it is
+ *   copied on every call as in the coherent mode.  tmLQCD's fields, one calloc of hundreds of MB, are mappings of their own.  The SIGSEGV
+ *   handler allocates nothing.  TMLQCD_HIP_LAZY_DEBUG=1 in the environment reports which arrays are not watched and why, and a SIGSEGV that
+ *   is not the library's before it is passed on to the program's own handler. */
 enum { TMLQCD_HIP_COHERENT = 0, TMLQCD_HIP_RESIDENT = 1, TMLQCD_HIP_LAZY = 2 };
 /* Device versions of sw_term(g_gauge_field, kappa, c_sw) / sw_invert(ieo, mu) (operator/clover_term.c:88,
  * operator/clover_invert.c:170).  They carry their own names because the reference keeps other, unrelated functions in
