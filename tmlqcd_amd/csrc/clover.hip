@@ -609,13 +609,32 @@ __global__ __launch_bounds__(256) void sw_pack_slabs_kernel(v2d *__restrict__ ou
 #else
 #define SWT_STEP() SW_STEP()
 #endif
+// Block order (round 4, review item 6).  The leaves of a site reach one step in every direction, so a link is wanted by the blocks of
+// its own (t, x) row, of the rows x +- 1 and of the time-slices t +- 1.  In the plain order (a contiguous eighth of the sites per XCD,
+// t slowest) a time-slice of links is 19 MB at 32^3 -- nothing of slice t is left in the 4 MB L2 when t + 1 comes by, and every link
+// was fetched ~4.7 times (5447 instead of 1152 bytes per site of one parity: profiles/r03_summary.md).  TILE order: an XCD owns tiles of
+// tx x-planes x tyb block-rows x all z (4 x 4 x 32 sites at 32^3: 0.3 MB of links per time-slice, 0.66 MB with the halo ring) and walks
+// each tile through ALL time-slices before it takes the next one; slices t - 1, t, t + 1 of tile + halo (2 MB) stay in L2 while t
+// advances, so a link comes in once per tile that owns or borders it.  tb = 0: the plain order.
+struct SwOrder { int tb, tx, tyb, nby, nty, ntiles, t0, nt; };
 template <class LD>
 __global__ __launch_bounds__(384, LD::min_blocks == 1 ? 1 : SWT_MINW) void sw_term_kernel(const LD ld, v2d *__restrict__ swd, unsigned gs, int LX, int LY, int LZ,
-                                                                                   int i_begin, int i_end, int chunk, double ka_csw_8) {
+                                                                                   int i_begin, int i_end, int chunk, double ka_csw_8, const SwOrder ord) {
   __shared__ v2d F[6][9][64];
   const int lane = threadIdx.x & 63;
   const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = blockIdx.x >> 3, sb = (blockIdx.x & 7) * chunk + (q >> 1), par = q & 1, opp = 1 - par;
+  const int q = blockIdx.x >> 3, par = q & 1, opp = 1 - par;
+  int sb;
+  if (ord.tb > 0) {
+    int r = q >> 1;
+    const int bx = r % ord.tb; r /= ord.tb;
+    const int tt = r % ord.nt, tile = (r / ord.nt) * 8 + (int)(blockIdx.x & 7);
+    if (tile >= ord.ntiles) return;
+    const int tile_x = tile / ord.nty, tile_y = tile - tile_x * ord.nty, bxx = bx / ord.tyb, bxy = bx - bxx * ord.tyb;
+    sb = (tt * LX + tile_x * ord.tx + bxx) * ord.nby + tile_y * ord.tyb + bxy;      // (whole time-slices from i_begin on)
+  } else {
+    sb = (blockIdx.x & 7) * chunk + (q >> 1);
+  }
   if (sb * 64 >= i_end - i_begin) return;
   const int i = i_begin + sb * 64 + lane;
   const bool active = i < i_end;
@@ -671,7 +690,7 @@ __global__ __launch_bounds__(384, LD::min_blocks == 1 ? 1 : SWT_MINW) void sw_te
       case 4: a = itimes(m3 - e3);             r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][2][0]
       default: a = itimes(m3 + e3);            r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][2][1]
     }
-    dst[(size_t)((unsigned)e * gs)] = r;
+    __builtin_nontemporal_store(r, dst + (size_t)((unsigned)e * gs));     // written once, read by other kernels: must not push the links out of L2
   }
 }
 
@@ -761,8 +780,22 @@ int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c
     if (!ctx->gauge_copy_current && tmhip_resort_gauge(ctx)) return 1;     // the SoA planes the interior reads must come from these links
     const SwFastLd ld{ctx->gauge, (unsigned)ctx->gs, nullptr, 0u, ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->Vh};
     const int chunk = ((ie - ib + 63) / 64 + 7) / 8;
-    hipLaunchKernelGGL((sw_term_kernel<SwFastLd>), dim3(chunk * 16), dim3(384), 0, ctx->stream, ld, ctx->sw, (unsigned)ctx->gs, ctx->g.LX, ctx->g.LY, ctx->g.LZ,
-                       ib, ie, chunk, c);
+    // tile order whenever a 64-site block is whole z-rows of one (t, x) row and the range is whole time-slices ("swterm_order" 0: plain order)
+    SwOrder ord = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int LZh = ctx->g.LZ / 2, rpb = LZh > 0 && 64 % LZh == 0 ? 64 / LZh : 0;
+    int grid = chunk * 16;
+    if (ctx->opt_swterm_order && rpb > 0 && ctx->g.LY % rpb == 0 && ib % ctx->face == 0 && ie % ctx->face == 0 && ctx->face % 64 == 0) {
+      ord.nby = ctx->g.LY / rpb;
+      ord.tx = ctx->g.LX % 4 == 0 ? 4 : (ctx->g.LX % 2 == 0 ? 2 : 1);
+      ord.tyb = rpb >= 4 ? 1 : ((4 / rpb) <= ord.nby && ord.nby % (4 / rpb) == 0 ? 4 / rpb : 1);
+      ord.nty = ord.nby / ord.tyb;
+      ord.ntiles = (ctx->g.LX / ord.tx) * ord.nty;
+      ord.tb = ord.tx * ord.tyb;
+      ord.t0 = ib / ctx->face; ord.nt = (ie - ib) / ctx->face;
+      grid = 8 * ((ord.ntiles + 7) / 8) * ord.nt * ord.tb * 2;
+    }
+    hipLaunchKernelGGL((sw_term_kernel<SwFastLd>), dim3(grid), dim3(384), 0, ctx->stream, ld, ctx->sw, (unsigned)ctx->gs, ctx->g.LX, ctx->g.LY, ctx->g.LZ,
+                       ib, ie, chunk, c, ord);
   }
   if (split) {
     LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, 1};
@@ -771,7 +804,7 @@ int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c
     for (int w = 0; w < (ctx->g.T > 1 ? 2 : 1); w++) {
       const int fb = w ? ctx->Vh - ctx->face : 0;
       hipLaunchKernelGGL((sw_term_kernel<SwEdgeLd>), dim3(chunk * 16), dim3(384), 0, ctx->stream, ld, ctx->sw, (unsigned)ctx->gs, ctx->g.LX, ctx->g.LY, ctx->g.LZ,
-                         fb, fb + ctx->face, chunk, c);
+                         fb, fb + ctx->face, chunk, c, SwOrder{0, 0, 0, 0, 0, 0, 0, 0});
     }
   }
   TMHIP_CHECK(hipGetLastError());

@@ -154,7 +154,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
     if (e && *e) { char *end = nullptr; const double v = strtod(e, &end); if (end != e && v >= 0.0) sec = v; }
     ctx->flag_timeout_ticks = (unsigned long long)(sec * 1.0e8);
   }
-  ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_recon = 0; ctx->opt_swall_order = 1; ctx->opt_gauge_cache = -1;
+  ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_recon = 0; ctx->opt_swall_order = 1; ctx->opt_swterm_order = 1; ctx->opt_gauge_cache = -1;
   ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks
@@ -306,6 +306,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
   else if (!strcmp(name, "gauge_cache")) { if (value < -1 || value > 1) TMHIP_FAIL("gauge_cache must be -1 (automatic), 0 or 1"); ctx->opt_gauge_cache = value; }
   else if (!strcmp(name, "swall_order")) { if (value < 0 || value > 1) TMHIP_FAIL("swall_order must be 0 (chunk per XCD) or 1 (slab order, default)"); ctx->opt_swall_order = value; }
+  else if (!strcmp(name, "swterm_order")) { if (value < 0 || value > 1) TMHIP_FAIL("swterm_order must be 0 (chunk per XCD) or 1 (tiles through all time-slices, default)"); ctx->opt_swterm_order = value; }
   else if (!strcmp(name, "occ32")) { if (value < 0 || value > 8) TMHIP_FAIL("occ32 must be in [0, 8]"); ctx->opt_occ32 = value; }
   else if (!strcmp(name, "gauge_recon")) {
     if (value != 12 && value != 18 && value != 0) TMHIP_FAIL("gauge_recon must be 12 or 18");
