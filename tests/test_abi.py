@@ -131,3 +131,32 @@ def test_c_host_program_links_against_the_drop_in_at_link_time(c_host_program):
     defined = subprocess.run(["nm", "-D", "--defined-only", c_host_program], capture_output=True, text=True, check=True).stdout
     for g in ("g_gauge_field", "g_update_gauge_copy", "ka0", "VOLUME"):       # exported by the executable for the library to read
         assert g in defined, g
+
+
+def test_register_budget_guard_of_the_build():
+    """tools/check_resources.py (a prerequisite of libtmlqcd_hip.so in the Makefile): it must FAIL on a default-dispatch stencil
+    instance that spills or drops below three waves per SIMD, pass on a clean one, and the table the last build committed must
+    say that nothing failed."""
+    import subprocess
+    import sys
+    import tempfile
+    tool = os.path.join(ROOT, "tools", "check_resources.py")
+
+    def remarks(name, vgpr, scratch, occ):
+        head = "x.hip:1:1: remark: "
+        return "\n".join([head + "Function Name: %s [-Rpass-analysis=kernel-resource-usage]" % name,
+                          head + "    TotalSGPRs: 40 [-Rpass-analysis=kernel-resource-usage]",
+                          head + "    VGPRs: %d [-Rpass-analysis=kernel-resource-usage]" % vgpr,
+                          head + "    AGPRs: 0 [-Rpass-analysis=kernel-resource-usage]",
+                          head + "    ScratchSize [bytes/lane]: %d [-Rpass-analysis=kernel-resource-usage]" % scratch,
+                          head + "    Occupancy [waves/SIMD]: %d [-Rpass-analysis=kernel-resource-usage]" % occ,
+                          head + "    LDS Size [bytes/block]: 0 [-Rpass-analysis=kernel-resource-usage]"]) + "\n"
+    k = "_ZN5hop6410hop_kernelILi0ELi1ELb1ELi256ELi3ELin1ELi64EEEvNS_7HopArgsE"      # hop64::hop_kernel<0, 1, true, 256, 3, -1, 64>: the split-path instance of round 3's accident
+    with tempfile.TemporaryDirectory() as d:
+        for tag, text, want in (("clean", remarks(k, 156, 0, 3), 0), ("spill", remarks(k, 168, 352, 3), 1), ("fat", remarks(k, 246, 0, 2), 1)):
+            f = os.path.join(d, tag + ".ru.txt")
+            open(f, "w").write(text)
+            r = subprocess.run([sys.executable, tool, f], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            assert r.returncode == want, (tag, r.stdout, r.stderr)
+    table = open(os.path.join(ROOT, "profiles", "r04_resource_usage.txt")).read()
+    assert " 0 failing" in table and "hop64::hop_kernel<0, 3, true, 256, 3, -1, 64>" in table

@@ -2,7 +2,9 @@
 Qtm_pm_psi, a global norm and a cg_her solve, checked slab by slab against the unsplit lattice computed on rank 0's GPU.
 For a node with N >= 2 GPUs -- RCCL refuses two ranks on one device ("invalid usage"), so a one-GPU box cannot run it; there the
 multi-rank code is rehearsed by the loopback modes and the two-context tests.
-Usage: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port 29544 tools/multi_rank_check.py"""
+FACES=direct in the environment: the half-spinor faces over the direct carrier (tmhip_comm_init_ipc: stores into the neighbour GPUs' IPC-mapped
+receive buffers over xGMI) instead of ncclSend / ncclRecv -- the first thing to run on a node with >= 2 GPUs after the plain check.
+Usage: [FACES=direct] python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port 29544 tools/multi_rank_check.py"""
 import os
 import sys
 
@@ -24,7 +26,9 @@ if rank == 0:
     uid.copy_(torch.tensor(list(lat.comm_unique_id()), dtype=torch.uint8))
 dist.broadcast(uid, 0)
 lat.comm_init(bytes(uid.tolist()))
-print("rank %d: communicator up" % rank, flush=True)
+if os.environ.get("FACES") == "direct":
+    lat.comm_init_ipc()
+print("rank %d: communicator up, faces direct: %s" % (rank, lat.comm_faces_direct()), flush=True)
 lat.set_gauge(syn.gauge_field(7, T, L, L, L, world, rank))
 src = syn.spinor_field_eo(8, 0, T, L, L, L, world, rank)
 k, l, q = lat.field(src), lat.field(), lat.field()
