@@ -223,7 +223,7 @@ def test_split_path_deadline_is_reported_once_and_cleared(setup16):
     dk.free(); dl.free()
 
 
-@pytest.mark.parametrize("dims", [(2, 2, 2, 2), (4, 2, 2, 2), (2, 4, 6, 2), (24, 4, 4, 4), (4, 4, 4, 16), (6, 10, 2, 4)])
+@pytest.mark.parametrize("dims", [(2, 2, 2, 2), (4, 2, 2, 2), (2, 4, 6, 2), (24, 4, 4, 4), (4, 4, 4, 16), (6, 10, 2, 4), (2, 8, 8, 4), (2, 8, 8, 8)])
 def test_small_and_ragged_lattices(dims):
     """The shapes of the reference's own operator regression (hopping_test: L in 4..16, T in 4..24,
     test/hopping_test_generate_script:17-31) plus the smallest legal lattice; every direction wraps."""
@@ -243,16 +243,20 @@ def test_small_and_ragged_lattices(dims):
         dk, dl = lat.field(k), lat.field()
         lat.Hopping_Matrix(ieo, dl, dk)
         assert rel_err(dl.download(), ref[:N]) < TOL
-        lat.set_loopback(1)
-        lat.Hopping_Matrix(ieo, dl, dk)
-        lat.set_loopback(0)
-        assert rel_err(dl.download(), ref[:N]) < TOL
+        for loop in (1, 3):      # 3: the direct carrier -- faces that are not whole waves take its two-kernel form with the per-lane stencil; (2, 8, 8, .): T_local = 2, every site a boundary site, in its one-kernel form
+            lat.set_loopback(loop)
+            lat.Hopping_Matrix(ieo, dl, dk)
+            lat.set_loopback(0)
+            assert rel_err(dl.download(), ref[:N]) < TOL, loop
     q = random_spinor(9, N)
     ref = orc.new_field(); orc.op("Qtm_pm_psi", ref, q.copy())
     dq, dl = lat.field(q), lat.field()
-    lat.Qtm_pm_psi(dl, dq)
-    assert rel_err(dl.download(), ref[:N]) < TOL
-    assert abs(lat.square_norm(dl, N) - orc.square_norm(ref, N)) <= TOL * orc.square_norm(ref, N)
+    for loop in (0, 3):
+        lat.set_loopback(loop)
+        lat.Qtm_pm_psi(dl, dq)
+        assert rel_err(dl.download(), ref[:N]) < TOL, loop
+        assert abs(lat.square_norm(dl, N) - orc.square_norm(ref, N)) <= TOL * orc.square_norm(ref, N)
+    lat.set_loopback(0)
     lat.close()
 
 
