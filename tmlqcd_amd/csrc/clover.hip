@@ -617,13 +617,47 @@ __global__ __launch_bounds__(256) void sw_pack_slabs_kernel(v2d *__restrict__ ou
 // each tile through ALL time-slices before it takes the next one; slices t - 1, t, t + 1 of tile + halo (2 MB) stay in L2 while t
 // advances, so a link comes in once per tile that owns or borders it.  tb = 0: the plain order.
 struct SwOrder { int tb, tx, tyb, nby, nty, ntiles, t0, nt; };
+// The four plaquette leaves around x in the (k, l) plane (clover_term.c:104-154), two at a time: A = the leaves in the +k+l and -k+l
+// quadrants, B = those in -k-l and +k-l.  Q is set (init) or added to.
 template <class LD>
-__global__ __launch_bounds__(384, LD::min_blocks == 1 ? 1 : SWT_MINW) void sw_term_kernel(const LD ld, v2d *__restrict__ swd, unsigned gs, int LX, int LY, int LZ,
+__device__ __forceinline__ void sw_leaves_a(M3 &Q, const LD &ld, const SwSite &x, int par, int k, int l, bool init) {
+  const int opp = 1 - par;
+  const SwSite xmk = sw_shift(x, k, -1);
+  const typename LD::Loc l0 = ld.locate(x), lpk = ld.locate(sw_shift(x, k, 1)), lpl = ld.locate(sw_shift(x, l, 1)), lmk = ld.locate(xmk), lplmk = ld.locate(sw_shift(xmk, l, 1));
+  M3 v1, v2;
+  v1 = m3_mulf<false, false>(ld.link(l0, par, k), ld.link(lpk, opp, l));
+  v2 = m3_mulf<false, false>(ld.link(l0, par, l), ld.link(lpl, opp, k));
+  if (init) Q = m3_mulf<false, true>(v1, v2); else m3_acc(Q, m3_mulf<false, true>(v1, v2));
+  SWT_STEP();
+  v1 = m3_mulf<false, true>(ld.link(l0, par, l), ld.link(lplmk, par, k));
+  v2 = m3_mulf<true, false>(ld.link(lmk, opp, l), ld.link(lmk, opp, k));
+  m3_acc(Q, m3_mulf<false, false>(v1, v2));
+}
+template <class LD>
+__device__ __forceinline__ void sw_leaves_b(M3 &Q, const LD &ld, const SwSite &x, int par, int k, int l, bool init) {
+  const int opp = 1 - par;
+  const SwSite xmk = sw_shift(x, k, -1);
+  const typename LD::Loc l0 = ld.locate(x), lmk = ld.locate(xmk), lml = ld.locate(sw_shift(x, l, -1)), lmkml = ld.locate(sw_shift(xmk, l, -1)), lpkml = ld.locate(sw_shift(sw_shift(x, k, 1), l, -1));
+  M3 v1, v2;
+  v1 = m3_mulf<false, false>(ld.link(lmkml, par, l), ld.link(lmk, opp, k));
+  v2 = m3_mulf<false, false>(ld.link(lmkml, par, k), ld.link(lml, opp, l));
+  if (init) Q = m3_mulf<true, false>(v1, v2); else m3_acc(Q, m3_mulf<true, false>(v1, v2));
+  SWT_STEP();
+  v1 = m3_mulf<true, false>(ld.link(lml, opp, l), ld.link(lml, opp, k));
+  v2 = m3_mulf<false, true>(ld.link(lpkml, par, l), ld.link(l0, par, k));
+  m3_acc(Q, m3_mulf<false, false>(v1, v2));
+}
+// Block = 64 sites of one parity x FOUR waves (round 4).  At 206-228 VGPRs a SIMD holds two waves, a CU eight: the six-wave block of
+// rounds 2-3 (one plane per wave) left two of the eight slots empty and one block per CU.  Now the 6 planes x 2 leaf pairs = 12 half-works
+// of a block are spread evenly: wave w does both halves of plane w (0 .. 3), then one half of plane 4 + (w >> 1); two blocks share a CU
+// (2 x 54 KB of LDS).  The F_kl of planes 4 and 5 are completed in LDS by the second of their two waves, behind a barrier.
+template <class LD>
+__global__ __launch_bounds__(256, LD::min_blocks == 1 ? 1 : SWT_MINW) void sw_term_kernel(const LD ld, v2d *__restrict__ swd, unsigned gs, int LX, int LY, int LZ,
                                                                                    int i_begin, int i_end, int chunk, double ka_csw_8, const SwOrder ord) {
   __shared__ v2d F[6][9][64];
   const int lane = threadIdx.x & 63;
-  const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = blockIdx.x >> 3, par = q & 1, opp = 1 - par;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = blockIdx.x >> 3, par = q & 1;
   int sb;
   if (ord.tb > 0) {
     int r = q >> 1;
@@ -648,49 +682,55 @@ __global__ __launch_bounds__(384, LD::min_blocks == 1 ? 1 : SWT_MINW) void sw_te
     x.x = r % LX; x.t = r / LX;
     x.z = 2 * kz + ((x.t + x.x + x.y + par) & 1);
   }
-  const int k = p < 3 ? 0 : (p < 5 ? 1 : 2), l = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
-  const SwSite xpk = sw_shift(x, k, 1), xmk = sw_shift(x, k, -1);
-  const typename LD::Loc l0 = ld.locate(x), lpk = ld.locate(xpk), lpl = ld.locate(sw_shift(x, l, 1)), lmk = ld.locate(xmk), lml = ld.locate(sw_shift(x, l, -1));
-  const typename LD::Loc lpkml = ld.locate(sw_shift(xpk, l, -1)), lplmk = ld.locate(sw_shift(xmk, l, 1)), lmkml = ld.locate(sw_shift(xmk, l, -1));
-  M3 Q, v1, v2;
-  v1 = m3_mul<false, false>(ld.link(l0, par, k), ld.link(lpk, opp, l));
-  v2 = m3_mul<false, false>(ld.link(l0, par, l), ld.link(lpl, opp, k));
-  Q = m3_mul<false, true>(v1, v2);
+  auto plane_kl = [](int p, int &k, int &l) { k = p < 3 ? 0 : (p < 5 ? 1 : 2); l = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3); };   // p = (01, 02, 03, 12, 13, 23)
+  M3 Q;
+  int k, l;
+  plane_kl(w, k, l);
+  sw_leaves_a(Q, ld, x, par, k, l, true);
   SWT_STEP();
-  v1 = m3_mul<false, true>(ld.link(l0, par, l), ld.link(lplmk, par, k));
-  v2 = m3_mul<true, false>(ld.link(lmk, opp, l), ld.link(lmk, opp, k));
-  m3_acc(Q, m3_mul<false, false>(v1, v2));
-  SWT_STEP();
-  v1 = m3_mul<false, false>(ld.link(lmkml, par, l), ld.link(lmk, opp, k));
-  v2 = m3_mul<false, false>(ld.link(lmkml, par, k), ld.link(lml, opp, l));
-  m3_acc(Q, m3_mul<true, false>(v1, v2));
-  SWT_STEP();
-  v1 = m3_mul<true, false>(ld.link(lml, opp, l), ld.link(lml, opp, k));
-  v2 = m3_mul<false, true>(ld.link(lpkml, par, l), ld.link(l0, par, k));
-  m3_acc(Q, m3_mul<false, false>(v1, v2));
+  sw_leaves_b(Q, ld, x, par, k, l, false);
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int b = 0; b < 3; b++) F[p][3 * a + b][lane] = Q.e[3 * a + b] - m3_conj(Q.e[3 * b + a]);
+    for (int b = 0; b < 3; b++) F[w][3 * a + b][lane] = Q.e[3 * a + b] - m3_conj(Q.e[3 * b + a]);
+  SWT_STEP();
+  const int p2 = 4 + (w >> 1), second = w & 1;       // wave-uniform
+  plane_kl(p2, k, l);
+  if (second) sw_leaves_b(Q, ld, x, par, k, l, true); else sw_leaves_a(Q, ld, x, par, k, l, true);
+  if (!second) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) F[p2][3 * a + b][lane] = Q.e[3 * a + b] - m3_conj(Q.e[3 * b + a]);
+  }
+  __syncthreads();
+  if (second) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) F[p2][3 * a + b][lane] += Q.e[3 * a + b] - m3_conj(Q.e[3 * b + a]);
+  }
   __syncthreads();
   if (!active) return;
-  v2d *dst = swd + ((size_t)par * 54 + (size_t)p * 9) * gs + i;      // wave p writes block p = 2a + b of sw[x][a][b]
   auto itimes = [](v2d a) { return v2d{-a.y, a.x}; };
+  for (int p = w; p < 6; p += 4) {                                     // block p = 2a + b of sw[x][a][b]: waves 0, 1 write two of them
+    v2d *dst = swd + ((size_t)par * 54 + (size_t)p * 9) * gs + i;
 #pragma unroll
-  for (int e = 0; e < 9; e++) {
-    const v2d e1 = F[0][e][lane], e2 = F[1][e][lane], e3 = F[2][e][lane], m3 = F[3][e][lane], f13 = F[4][e][lane], m1 = F[5][e][lane];
-    const v2d m2 = v2d{-f13.x, -f13.y};
-    const double one = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
-    v2d a, r;
-    switch (p) {
-      case 0: a = itimes(e3 - m3);             r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][0][0]
-      case 1: a = itimes(e3 + m3);             r = v2d{one - ka_csw_8 * a.x, -ka_csw_8 * a.y}; break;    // sw[x][0][1]
-      case 2: a = itimes(e1 - m1) + (e2 - m2); r = v2d{ka_csw_8 * a.x, ka_csw_8 * a.y}; break;           // sw[x][1][0]
-      case 3: a = itimes(e1 + m1) + (e2 + m2); r = v2d{-ka_csw_8 * a.x, -ka_csw_8 * a.y}; break;         // sw[x][1][1]
-      case 4: a = itimes(m3 - e3);             r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][2][0]
-      default: a = itimes(m3 + e3);            r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][2][1]
+    for (int e = 0; e < 9; e++) {
+      const v2d e1 = F[0][e][lane], e2 = F[1][e][lane], e3 = F[2][e][lane], m3 = F[3][e][lane], f13 = F[4][e][lane], m1 = F[5][e][lane];
+      const v2d m2 = v2d{-f13.x, -f13.y};
+      const double one = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+      v2d a, r;
+      switch (p) {
+        case 0: a = itimes(e3 - m3);             r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][0][0]
+        case 1: a = itimes(e3 + m3);             r = v2d{one - ka_csw_8 * a.x, -ka_csw_8 * a.y}; break;    // sw[x][0][1]
+        case 2: a = itimes(e1 - m1) + (e2 - m2); r = v2d{ka_csw_8 * a.x, ka_csw_8 * a.y}; break;           // sw[x][1][0]
+        case 3: a = itimes(e1 + m1) + (e2 + m2); r = v2d{-ka_csw_8 * a.x, -ka_csw_8 * a.y}; break;         // sw[x][1][1]
+        case 4: a = itimes(m3 - e3);             r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][2][0]
+        default: a = itimes(m3 + e3);            r = v2d{one + ka_csw_8 * a.x, ka_csw_8 * a.y}; break;     // sw[x][2][1]
+      }
+      __builtin_nontemporal_store(r, dst + (size_t)((unsigned)e * gs));     // written once, read by other kernels: must not push the links out of L2
     }
-    __builtin_nontemporal_store(r, dst + (size_t)((unsigned)e * gs));     // written once, read by other kernels: must not push the links out of L2
   }
 }
 
@@ -794,7 +834,7 @@ int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c
       ord.t0 = ib / ctx->face; ord.nt = (ie - ib) / ctx->face;
       grid = 8 * ((ord.ntiles + 7) / 8) * ord.nt * ord.tb * 2;
     }
-    hipLaunchKernelGGL((sw_term_kernel<SwFastLd>), dim3(grid), dim3(384), 0, ctx->stream, ld, ctx->sw, (unsigned)ctx->gs, ctx->g.LX, ctx->g.LY, ctx->g.LZ,
+    hipLaunchKernelGGL((sw_term_kernel<SwFastLd>), dim3(grid), dim3(256), 0, ctx->stream, ld, ctx->sw, (unsigned)ctx->gs, ctx->g.LX, ctx->g.LY, ctx->g.LZ,
                        ib, ie, chunk, c, ord);
   }
   if (split) {
@@ -803,7 +843,7 @@ int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c
     const int chunk = ((ctx->face + 63) / 64 + 7) / 8;
     for (int w = 0; w < (ctx->g.T > 1 ? 2 : 1); w++) {
       const int fb = w ? ctx->Vh - ctx->face : 0;
-      hipLaunchKernelGGL((sw_term_kernel<SwEdgeLd>), dim3(chunk * 16), dim3(384), 0, ctx->stream, ld, ctx->sw, (unsigned)ctx->gs, ctx->g.LX, ctx->g.LY, ctx->g.LZ,
+      hipLaunchKernelGGL((sw_term_kernel<SwEdgeLd>), dim3(chunk * 16), dim3(256), 0, ctx->stream, ld, ctx->sw, (unsigned)ctx->gs, ctx->g.LX, ctx->g.LY, ctx->g.LZ,
                          fb, fb + ctx->face, chunk, c, SwOrder{0, 0, 0, 0, 0, 0, 0, 0});
     }
   }
