@@ -299,7 +299,7 @@ def test_cg_fused_split_path_wide_short_local_lattice():
 def test_cg_fused_with_one_communicator_for_faces_and_reductions():
     """The fallback of an RCCL without ncclCommSplit, forced ("comm_split" 0): the scalar all-reduces of the fused CG iteration run
     on the SAME communicator as the face exchange, from the other stream.  Correct because the exchange of a stencil has completed
-    before anything enqueued behind that stencil on the main stream starts (launch_split, hopping_impl.inc).  One-rank RCCL
+    before anything enqueued behind that stencil on the main stream starts (launch_split, hopping_split.inc).  One-rank RCCL
     loopback on 8 x 16^3 == the unsplit solve; the library says which form it runs."""
     from oracle.oraclebind import Oracle
     from tmlqcd_amd import Lattice

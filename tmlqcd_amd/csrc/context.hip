@@ -623,7 +623,7 @@ static int comm_make_red(tmhip_ctx *ctx, int rank) {
   const ncclResult_t rs = ncclCommSplit(ctx->comm, 0, rank, &ctx->comm_red, nullptr);
   if (rs != ncclSuccess) {
     // (an RCCL without ncclCommSplit: every rank fails here alike.)  One communicator is enough for correctness: a reduction is never
-    // in flight together with a face exchange (hopping_impl.inc launch_split), so this is a fallback, not an error.
+    // in flight together with a face exchange (hopping_split.inc launch_split), so this is a fallback, not an error.
     fprintf(stderr, "[tmlqcd_hip] ncclCommSplit failed (%s): reductions share the face communicator\n", ncclGetErrorString(rs));
     ctx->comm_red = ctx->comm;
     return 0;

@@ -60,7 +60,7 @@ struct tmhip_field {
 // mapped into this process (hipIpcOpenMemHandle) and whoever produces the projected faces -- the pack kernel, the exterior kernel, the
 // boundary waves of a stencil kernel -- stores them there itself (write-through, system scope); the last wave to finish writes the push
 // number into the neighbours' words.  No copy, no kernel of a communication library, nothing on the receiving GPU's compute units.
-// Double-buffered by push parity; protocol and flow control: launch_direct (hopping_impl.inc), DESIGN.md section 7.
+// Double-buffered by push parity; protocol and flow control: launch_direct (hopping_split.inc), DESIGN.md section 7a.
 struct TmhipDirect {
   bool on;
   void *mine;                   // ONE uncached device allocation: [2 push parities][from up | from dn] faces, then the arrival words
@@ -120,7 +120,7 @@ struct tmhip_ctx {
   // Two communicators over the same ranks: `comm` carries the half-spinor faces on comm_stream, `comm_red` (ncclCommSplit of
   // `comm`) everything issued on the main stream (scalar all-reduces, force halos) -- no communicator is driven from two streams.
   // comm_split false: ncclCommSplit is unavailable (or switched off, "comm_split" 0) and comm_red == comm; still correct, because
-  // a face exchange is never in flight together with a main-stream collective (launch_split, hopping_impl.inc).
+  // a face exchange is never in flight together with a main-stream collective (launch_split, hopping_split.inc).
   ncclComm_t comm, comm_red; bool comm_ready; bool comm_split; bool loopback; bool loopback_rccl;
   struct TmhipShm *shm;   // != nullptr: the ranks talk through the host-staged shared-memory transport (xfer_shm.hip) instead of RCCL; everything on `stream`
   v2d *send_up, *send_dn, *recv_up, *recv_dn;   // [6][face] each
