@@ -442,7 +442,7 @@ def comm_labels(R, S, faces):
     `ring_nranks` whatever built it, `faces` = what carries the half-spinor faces."""
     nf, nr = S.comm_count()
     direct, sharers = S.comm_faces_direct()
-    return {"transport": R.ring, "faces": "direct" if direct else R.ring, "ring_nranks": [nf, nr],
+    return {"transport": R.ring, "faces": "direct" if direct else R.ring, "sums": "direct" if S.comm_sums_direct() else R.ring, "ring_nranks": [nf, nr],
             "rccl_nranks": [nf, nr] if R.ring == "rccl" else None, "comm_split": S.comm_is_split() if R.ring == "rccl" else None,
             "ranks_sharing_a_gpu": sharers if direct else None}
 
@@ -639,7 +639,7 @@ def rank_main(args, world, rank, local_rank):
     extra = {}
     t_run = time.perf_counter()
     faces_a = "direct" if R.faces_mode == "direct" else "comm"        # what carries the faces in the legs below ("auto": the communicator first)
-    LABELS = ("transport", "faces", "ring_nranks", "rccl_nranks", "comm_split", "ranks_sharing_a_gpu")
+    LABELS = ("transport", "faces", "sums", "ring_nranks", "rccl_nranks", "comm_split", "ranks_sharing_a_gpu")
     # ---------------------------------------------------------------- N > 1: multi-rank parity check + BASELINE configs[3] (strong scaling)
     Tg = 64
     if Tg % world or (Tg // world) % 2 or Tg // world < 2:

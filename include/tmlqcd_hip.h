@@ -292,6 +292,9 @@ int tmhip_comm_init_shm(tmhip_ctx *ctx, const char *job);
 int tmhip_comm_init_ipc(tmhip_ctx *ctx);
 /* 1 when the faces travel as direct stores (0: over the communicator); *sharers (may be NULL): ranks of the job on this rank's GPU */
 int tmhip_comm_faces_direct(tmhip_ctx *ctx, int *sharers);
+/* 1 when the scalar sums over the ranks travel as direct stores too (option "direct_sums", every rank's block mapped by every rank):
+ * MPI_Allreduce of linalg/square_norm.c:314 as ONE wave per rank, added in rank order (the same bits on every rank) */
+int tmhip_comm_sums_direct(tmhip_ctx *ctx);
 /* tmhip_comm_init builds TWO communicators over the same ranks: one for the half-spinor faces (second HIP stream), one
  * (ncclCommSplit of the first) for the scalar all-reduces of the linalg (MPI_Allreduce in linalg/square_norm.c:314) and the
  * force halos on the main stream.  Ranks in each as RCCL reports them (ncclCommCount); 0, 0 before tmhip_comm_init. */
@@ -344,6 +347,10 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *                neighbour's word after their seven local hops, add the hop across the cut, project their output and store the projection into the
  *                neighbour's buffer); 0: stencil kernel + exterior kernel (which waits and pushes); -1: one kernel while the boundary waves of a
  *                launch are at most 1024 / (ranks sharing this GPU)
+ *   "direct_sums" 1 (default) | 0 (before tmhip_comm_init_ipc): with the direct carrier every rank maps every rank's block and the scalar sums
+ *                over the ranks (square_norm .. with parallel = 1, the alpha and the stopping test of cg_her) are one wave that stores this
+ *                rank's partial sum into every rank's block and adds up its own row in rank order (the same bits on every rank) instead
+ *                of an ncclAllReduce
  *   "direct_order" bit 0 / bit 1: one-kernel form -- boundary time-slices dispatched first (else last) in a stencil whose faces are packed now /
  *                were pushed ahead by the stencil before (default 2)
  *   "prepack" 1 (default) | 0: T-split ranks -- the exterior kernel also projects the completed boundary slices of its output into the send buffers, so

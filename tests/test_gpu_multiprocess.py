@@ -59,7 +59,7 @@ def test_bench_with_the_direct_carrier_from_the_start():
     reductions and solves -- with the faces stored straight into the neighbours' IPC-mapped buffers, three processes on one GPU."""
     rec, err = _bench(3, TMLQCD_BENCH_TRANSPORT="ipc")
     assert rec["rank_check"]["ok"] is True and rec["rank_check"]["faces"] == "direct", rec["rank_check"]
-    assert rec["faces"] == "direct" and rec["transport"] == "shm" and rec["ranks_sharing_a_gpu"] == 3 and "faces_direct" not in rec
+    assert rec["faces"] == "direct" and rec["sums"] == "direct" and rec["transport"] == "shm" and rec["ranks_sharing_a_gpu"] == 3 and "faces_direct" not in rec
     assert rec["strong"]["value"] > 0 and rec["cg"]["iters_per_s"] > 0 and abs(rec["hermiticity_rel_dev"]) < 1e-12
     assert "gave up" not in err
 

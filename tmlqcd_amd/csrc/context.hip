@@ -146,7 +146,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
-  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_split_pipe = 0; ctx->opt_direct_form = -1; ctx->opt_direct_order = 2;
+  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_split_pipe = 0; ctx->opt_direct_form = -1; ctx->opt_direct_order = 2; ctx->opt_direct_sums = 1;
   {
     // bound of the device-side waits for the neighbours' faces: TMLQCD_HIP_FLAG_TIMEOUT_S in the environment (0 = none), default 120 s
     double sec = 120.0;
@@ -299,6 +299,7 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "split_sync")) { if (value < 0 || value > 1) TMHIP_FAIL("split_sync must be 0 (the exterior kernel and the pack kernel wait for a word of the other stream) or 1 (the streams are ordered by HIP events: no wait on the device)"); ctx->opt_split_sync = value; }
   else if (!strcmp(name, "flag_timeout_ms")) { if (value < 0) TMHIP_FAIL("flag_timeout_ms must be >= 0 (0 = wait without bound)"); ctx->flag_timeout_ticks = (unsigned long long)value * 100000ull; }
   else if (!strcmp(name, "direct_form")) { if (value < -1 || value > 1) TMHIP_FAIL("direct_form must be -1 (automatic), 0 (stencil + exterior kernel) or 1 (one kernel per stencil whenever the shape allows)"); ctx->opt_direct_form = value; }
+  else if (!strcmp(name, "direct_sums")) { if (ctx->direct.on) TMHIP_FAIL("direct_sums must be set before tmhip_comm_init_ipc"); ctx->opt_direct_sums = value != 0; }
   else if (!strcmp(name, "direct_order")) { if (value < 0 || value > 3) TMHIP_FAIL("direct_order: bit 0 / bit 1 = boundary time-slices first for a stencil whose faces are packed now / were pushed ahead"); ctx->opt_direct_order = value; }
   else if (!strcmp(name, "prepack")) { ctx->opt_prepack = value != 0; ctx->prepacked = nullptr; }
   else if (!strcmp(name, "split_pipe")) { if (value < 0 || value > 2) TMHIP_FAIL("split_pipe must be 0 (off, default), 1 (local lattices of >= 262144 sites per parity) or 2 (every size)"); ctx->opt_split_pipe = value; ctx->prepacked = nullptr; ctx->ahead_field = nullptr; }

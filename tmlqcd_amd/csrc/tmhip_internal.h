@@ -61,6 +61,7 @@ struct tmhip_field {
 // boundary waves of a stencil kernel -- stores them there itself (write-through, system scope); the last wave to finish writes the push
 // number into the neighbours' words.  No copy, no kernel of a communication library, nothing on the receiving GPU's compute units.
 // Double-buffered by push parity; protocol and flow control: launch_direct (hopping_split.inc), DESIGN.md section 7a.
+#define TMHIP_DIRECT_MAX_RANKS 64
 struct TmhipDirect {
   bool on;
   void *mine;                   // ONE uncached device allocation: [2 push parities][from up | from dn] faces, then the arrival words
@@ -74,6 +75,11 @@ struct TmhipDirect {
   unsigned int last_push;       // the push the last communicating stencil consumed (Hopping_Matrix_nocom reads those faces again)
   const void *ahead_field; unsigned int ahead_push;   // the field whose faces were pushed AHEAD by the stencil that wrote it, and under which number
   int sharers;                  // ranks of this job that sit on this physical GPU (1 in production; the one-GPU rehearsals have more)
+  // direct sums (tmhip_direct_allreduce): every rank's block is mapped (not only the ring neighbours'), a rank stores its partial sum into
+  // slot [parity of the reduction's number][its rank] of EVERY rank and adds up its own row in rank order -- the same bits everywhere
+  bool sums_on;
+  void *peer_all[TMHIP_DIRECT_MAX_RANKS];   // mapping of rank r's block (nullptr: not mapped; [me] = mine)
+  unsigned long long sum_seq;   // reductions done so far (the same number on every rank)
 };
 
 struct tmhip_ctx {
@@ -153,6 +159,7 @@ struct tmhip_ctx {
   int opt_recon;                                                        // 12 = rebuild the third row of every link in registers (opt-in)
   int opt_split_sync;                                                   // 0: the exterior kernel / the pack kernel wait for a flag of the other stream (default); 1: HIP events, no device-side wait
   int opt_direct_form;                                                  // direct carrier: -1 automatic (one kernel per stencil while the boundary waves fit the wait budget), 0 stencil + exterior kernel, 1 one kernel whenever the shape allows
+  int opt_direct_sums;                                                  // 1 (default): with the direct carrier the scalar sums over the ranks travel the same way (tmhip_direct_allreduce) instead of ncclAllReduce
   int opt_direct_order;                                                 // direct carrier, one-kernel form: bit 0 / bit 1 = boundary time-slices FIRST for a stencil whose faces are packed now / were pushed ahead (else last)
   int opt_split_pipe;                                                   // 1: boundary slices first, exterior kernel beside the stencil kernel, faces of a chain's next stencil exchanged ahead (hopping_impl.inc, launch_pipe)
   int opt_prepack;                                                      // 1 (default): the exterior kernel projects the faces of its output for the next stencil of a chain
@@ -196,6 +203,7 @@ int tmhip_shm_allgather(tmhip_ctx *ctx, hipStream_t st, const void *mine, void *
 // ---- direct face carrier (xfer_ipc.hip) ----
 int tmhip_direct_init_self(tmhip_ctx *ctx);   // loopback 3
 void tmhip_direct_destroy(tmhip_ctx *ctx);
+int tmhip_direct_allreduce(tmhip_ctx *ctx, double *x);   // sum of *x (device) over the ranks, in place, added in rank order; enqueued on ctx->stream (needs direct.sums_on)
 
 // ---- launch helpers implemented across the .hip files ----
 enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_TM_SUB_G5_DOT = 4, EPI_CLOVER_INV = 5, EPI_CLOVER_G5 = 6, EPI_CLOVER = 7,

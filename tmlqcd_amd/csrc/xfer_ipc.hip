@@ -82,10 +82,55 @@ int tmhip_direct_init_self(tmhip_ctx *ctx) {
 void tmhip_direct_destroy(tmhip_ctx *ctx) {
   TmhipDirect &d = ctx->direct;
   if (!d.mine) return;
-  for (int k = 0; k < 2; k++) if (d.peer_map[k]) (void)hipIpcCloseMemHandle(d.peer_map[k]);
+  for (int r = 0; r < TMHIP_DIRECT_MAX_RANKS; r++) if (d.peer_all[r] && d.peer_all[r] != d.mine) (void)hipIpcCloseMemHandle(d.peer_all[r]);
   (void)hipFree(d.mine);
   if (d.count) (void)hipFree(d.count);
   memset(&d, 0, sizeof(d));
+}
+
+// ---- direct sums: MPI_Allreduce(..., MPI_SUM) of one double (linalg/square_norm.c:314, the alpha and the stopping test of cg_her) --------
+// One wave.  Lane r stores this rank's partial sum into slot [parity][me] of rank r's block (value, drained, then the reduction's number:
+// two stores in order, nothing relies on a 16-byte store arriving whole), waits -- bounded like every wait here -- until rank r's
+// contribution to THIS reduction sits in slot [parity][r] of its own block, and lane 0 adds the np values in rank order: the same bits
+// on every rank.  Two slot rows in turn are enough: a rank cannot be two reductions ahead of one whose contribution it still needs.
+struct SumSlot { double v; unsigned long long seq; };
+struct SumPeers { SumSlot *p[TMHIP_DIRECT_MAX_RANKS]; };
+__global__ __launch_bounds__(64) void direct_allreduce_kernel(double *x, SumSlot *mine, const SumPeers peers, int np, int me, unsigned long long seq,
+                                                              unsigned int *err, unsigned long long ticks) {
+  const int r = (int)threadIdx.x;
+  const int row = (int)(seq & 1ull) * TMHIP_DIRECT_MAX_RANKS;
+  double v = 0.0;
+  if (r < np) {
+    const double mine_v = *x;
+    SumSlot *dst = peers.p[r] + row + me;
+    __hip_atomic_store(&dst->v, mine_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const SumSlot *src = mine + row + r;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (ticks && __builtin_amdgcn_s_memrealtime() - t0 > ticks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    v = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  double total = 0.0;
+  for (int k = 0; k < np; k++) total += __shfl(v, k, 64);      // rank order, every lane alike
+  if (r == 0) *x = total;
+}
+
+int tmhip_direct_allreduce(tmhip_ctx *ctx, double *x) {
+  TmhipDirect &d = ctx->direct;
+  if (!d.on || !d.sums_on) TMHIP_FAIL("tmhip_direct_allreduce without the direct sums");
+  const int np = ctx->g.nproc_t;
+  const size_t off = 4 * face_bytes(ctx) + 1024;               // the slot rows lie behind the arrival words (alloc_mine)
+  SumPeers peers;
+  memset(&peers, 0, sizeof(peers));
+  for (int r = 0; r < np; r++) peers.p[r] = (SumSlot *)((char *)d.peer_all[r] + off);
+  hipLaunchKernelGGL(direct_allreduce_kernel, dim3(1), dim3(64), 0, ctx->stream, x, (SumSlot *)((char *)d.mine + off), peers, np, ctx->g.proc_t, ++d.sum_seq,
+                     ctx->sync_flags + 2, ctx->flag_timeout_ticks);
+  TMHIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 extern "C" {
@@ -121,25 +166,38 @@ int tmhip_comm_init_ipc(tmhip_ctx *ctx) {
   if (memcmp(&all[(size_t)me], &mine, sizeof(Card))) TMHIP_FAIL("tmhip_comm_init_ipc: the gather did not return this rank's own card in slot %d", me);
   d.sharers = 0;
   for (int r = 0; r < np; r++) if (!strncmp(all[(size_t)r].busid, mine.busid, sizeof(mine.busid))) d.sharers++;
-  // map the neighbours (one mapping when both are the same rank)
-  hipError_t e = hipIpcOpenMemHandle(&d.peer_map[0], all[(size_t)up].handle, hipIpcMemLazyEnablePeerAccess);
-  if (e == hipSuccess && dn != up) e = hipIpcOpenMemHandle(&d.peer_map[1], all[(size_t)dn].handle, hipIpcMemLazyEnablePeerAccess);
-  if (e != hipSuccess) fprintf(stderr, "[tmlqcd_hip] tmhip_comm_init_ipc: rank %d cannot map a neighbour's receive buffers (%s)\n", me, hipGetErrorString(e));
-  // all ranks or none: a rank that pushes to a neighbour that still posts receives would hang both
-  double bad = e != hipSuccess ? 1.0 : 0.0;
-  TMHIP_CHECK(hipMemcpyAsync(ctx->result_dev, &bad, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if (ctx->shm) { if (tmhip_shm_allreduce(ctx, ctx->stream, ctx->result_dev, 1)) return 1; }
-  else TMHIP_NCCL_CHECK(ncclAllReduce(ctx->result_dev, ctx->result_dev, 1, ncclDouble, ncclSum, ctx->comm_red, ctx->stream));
-  TMHIP_CHECK(hipMemcpyAsync(&bad, ctx->result_dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  // map the ring neighbours (faces) and -- for the sums -- everybody else too; [me] is this rank's own block
+  d.peer_all[me] = d.mine;
+  hipError_t e = hipSuccess, e_all = np <= TMHIP_DIRECT_MAX_RANKS && ctx->opt_direct_sums ? hipSuccess : hipErrorNotSupported;
+  for (int k = 1; k < np && k < TMHIP_DIRECT_MAX_RANKS; k++) {
+    const int r = (me + k) % np;                         // (neighbours first)
+    const bool ring = r == up || r == dn;
+    if (!ring && e_all != hipSuccess) continue;
+    const hipError_t er = hipIpcOpenMemHandle(&d.peer_all[r], all[(size_t)r].handle, hipIpcMemLazyEnablePeerAccess);
+    if (er != hipSuccess) {
+      d.peer_all[r] = nullptr;
+      if (ring) e = er; else e_all = er;
+      fprintf(stderr, "[tmlqcd_hip] tmhip_comm_init_ipc: rank %d cannot map rank %d's block (%s)\n", me, r, hipGetErrorString(er));
+    }
+  }
+  // all ranks or none: a rank that pushes to a neighbour that still posts receives would hang both (and the same for the sums)
+  double bad[2] = {e != hipSuccess ? 1.0 : 0.0, e_all != hipSuccess ? 1.0 : 0.0};
+  TMHIP_CHECK(hipMemcpyAsync(ctx->result_dev, bad, sizeof(bad), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->shm) { if (tmhip_shm_allreduce(ctx, ctx->stream, ctx->result_dev, 2)) return 1; }
+  else TMHIP_NCCL_CHECK(ncclAllReduce(ctx->result_dev, ctx->result_dev, 2, ncclDouble, ncclSum, ctx->comm_red, ctx->stream));
+  TMHIP_CHECK(hipMemcpyAsync(bad, ctx->result_dev, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
   TMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (tmhip_check_async_error(ctx)) return 1;
-  if (bad != 0.0) {
+  if (bad[0] != 0.0) {
     tmhip_direct_destroy(ctx);
-    TMHIP_FAIL("tmhip_comm_init_ipc: %d rank(s) could not map a neighbour: the faces stay on the communicator", (int)bad);
+    TMHIP_FAIL("tmhip_comm_init_ipc: %d rank(s) could not map a neighbour: the faces stay on the communicator", (int)bad[0]);
   }
-  point_at(ctx, 0, (char *)d.peer_map[0]);
-  point_at(ctx, 1, (char *)(dn != up ? d.peer_map[1] : d.peer_map[0]));
+  d.peer_map[0] = d.peer_map[1] = nullptr;               // (the mappings are kept in peer_all)
+  point_at(ctx, 0, (char *)d.peer_all[up]);
+  point_at(ctx, 1, (char *)d.peer_all[dn]);
   reset_state(ctx);
+  d.sum_seq = 0;
+  d.sums_on = bad[1] == 0.0;                              // every rank has every block: the scalar sums travel the same way as the faces
   d.on = true;
   return 0;
 }
@@ -150,5 +208,8 @@ int tmhip_comm_faces_direct(tmhip_ctx *ctx, int *sharers) {
   if (sharers) *sharers = ctx->direct.on ? ctx->direct.sharers : 0;
   return ctx->direct.on ? 1 : 0;
 }
+
+/* 1 when the scalar sums over the ranks travel as direct stores too (tmhip_direct_allreduce), 0: over the communicator */
+int tmhip_comm_sums_direct(tmhip_ctx *ctx) { return ctx->direct.on && ctx->direct.sums_on ? 1 : 0; }
 
 }  // extern "C"

@@ -139,6 +139,7 @@ def load_library():
         "tmhip_comm_init_shm": [vp, C.c_char_p],
         "tmhip_comm_init_ipc": [vp],
         "tmhip_comm_faces_direct": [vp, C.POINTER(i)],
+        "tmhip_comm_sums_direct": [vp],
         "tmhip_comm_set_loopback": [vp, i],
         "tmhip_comm_count": [vp, C.POINTER(i), C.POINTER(i)],
         "tmhip_comm_is_split": [vp],
@@ -627,6 +628,10 @@ class Lattice:
         n = C.c_int()
         v = self.lib.tmhip_comm_faces_direct(self.h, C.byref(n))
         return bool(v), n.value
+
+    def comm_sums_direct(self):
+        """True when the scalar sums over the ranks travel as direct stores into every rank's block (no communicator involved)"""
+        return bool(self.lib.tmhip_comm_sums_direct(self.h))
 
     def comm_count(self):
         """(ranks of the face communicator, ranks of the reduction communicator) as RCCL reports them; (0, 0) without one."""
