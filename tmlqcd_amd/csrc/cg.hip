@@ -304,6 +304,38 @@ __global__ __launch_bounds__(CG_SUM_BS) void cg_sum_scalar_kernel(const double *
   if (lw >= 0 && lw < NW) reinterpret_cast<double *>(st)[lw] = reinterpret_cast<const double *>(&ls)[lw];
 }
 
+// T-split ranks over the direct carrier: the same, with the sum over the ranks (tmhip_direct_sum_wave: one wave storing into every
+// rank's block) between the local sum and the scalar update -- ONE launch per reduction instead of sum kernel + all-reduce + scalar kernel
+template <int WHICH>
+__global__ __launch_bounds__(CG_SUM_BS) void cg_sum_xsum_scalar_kernel(const double *__restrict__ partials, int n, double *out, CgState *st, double *hist,
+                                                                       int hist_len, const TmhipSumArgs xs) {
+  constexpr int NW = sizeof(CgState) / sizeof(double);
+  __shared__ CgState ls;
+  __shared__ double sm[CG_SUM_BS / 64];
+  const int lw = (int)threadIdx.x - (CG_SUM_BS - 64);
+  if (lw >= 0 && lw < NW) reinterpret_cast<double *>(&ls)[lw] = reinterpret_cast<const double *>(st)[lw];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += CG_SUM_BS) acc += partials[i];
+  acc = cg_wave_reduce(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  // `done` is a function of global sums: the same on every rank, so a reduction that is skipped is skipped by everybody (its number with it)
+  if (ls.done) { if (WHICH == 0 && threadIdx.x == 0) st->x_pending = 0; return; }   // block-uniform
+  if (threadIdx.x < 64) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < CG_SUM_BS / 64; w++) tot += sm[w];
+    const double gtot = tmhip_direct_sum_wave(tot, xs);
+    if (threadIdx.x == 0) {
+      double g = gtot;
+      *out = g;
+      cg_scalar_update<WHICH>(&ls, &g, hist, hist_len);
+    }
+  }
+  __syncthreads();
+  if (lw >= 0 && lw < NW) reinterpret_cast<double *>(st)[lw] = reinterpret_cast<const double *>(&ls)[lw];
+}
+
 int tmhip_apply_op(tmhip_ctx *ctx, int op, tmhip_field *l, tmhip_field *k) {
   switch (op) {
     case TMHIP_OP_QTM_PM: return tmhip_Qtm_pm_psi(ctx, l, k);
@@ -359,7 +391,11 @@ static int cg_allreduce(tmhip_ctx *ctx, double *x) {
 template <int WHICH>
 static int cg_reduce_update(tmhip_ctx *ctx, int n, CgState *st, double *hist, int hist_len) {
   double *sum = ctx->result_dev + 1;
-  if (tmhip_reduce_over_ranks(ctx)) {
+  if (tmhip_reduce_over_ranks(ctx) && ctx->direct.on && ctx->direct.sums_on) {
+    TmhipSumArgs xs;
+    if (tmhip_direct_sum_args(ctx, &xs)) return 1;
+    hipLaunchKernelGGL(cg_sum_xsum_scalar_kernel<WHICH>, dim3(1), dim3(CG_SUM_BS), 0, ctx->stream, ctx->partials, n, sum, st, hist, hist_len, xs);
+  } else if (tmhip_reduce_over_ranks(ctx)) {
     hipLaunchKernelGGL(cg_sum_kernel, dim3(1), dim3(CG_SUM_BS), 0, ctx->stream, ctx->partials, n, sum, st);
     if (cg_allreduce(ctx, sum)) return 1;
     hipLaunchKernelGGL(cg_scalar_kernel<WHICH>, dim3(1), dim3(64), 0, ctx->stream, st, sum, hist, hist_len);

@@ -203,6 +203,34 @@ int tmhip_shm_allgather(tmhip_ctx *ctx, hipStream_t st, const void *mine, void *
 // ---- direct face carrier (xfer_ipc.hip) ----
 int tmhip_direct_init_self(tmhip_ctx *ctx);   // loopback 3
 void tmhip_direct_destroy(tmhip_ctx *ctx);
+// One wave's part of a direct sum (all 64 lanes call it; every lane returns the total): lane r stores this rank's value into slot
+// [row of the reduction's number][me] of rank r's block -- value, drained, then the number: two stores in order, nothing relies on a
+// 16-byte store arriving whole --, waits (bounded) for rank r's contribution to THIS reduction in the rank's own row, and the np values
+// are added in rank order: the same bits on every rank.
+struct TmhipSumSlot { double v; unsigned long long seq; };
+struct TmhipSumArgs { TmhipSumSlot *peer[TMHIP_DIRECT_MAX_RANKS]; TmhipSumSlot *mine; int np, me; unsigned long long seq; unsigned int *err; unsigned long long ticks; };
+__device__ __forceinline__ double tmhip_direct_sum_wave(double mine_v, const TmhipSumArgs &a) {
+  const int r = (int)(threadIdx.x & 63);
+  const int row = (int)(a.seq & 1ull) * TMHIP_DIRECT_MAX_RANKS;
+  double v = 0.0;
+  if (r < a.np) {
+    TmhipSumSlot *dst = a.peer[r] + row + a.me;
+    __hip_atomic_store(&dst->v, mine_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&dst->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const TmhipSumSlot *src = a.mine + row + r;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.seq) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (a.ticks && __builtin_amdgcn_s_memrealtime() - t0 > a.ticks) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    v = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  double total = 0.0;
+  for (int k = 0; k < a.np; k++) total += __shfl(v, k, 64);
+  return total;
+}
+int tmhip_direct_sum_args(tmhip_ctx *ctx, TmhipSumArgs *out);   // the arguments of the NEXT direct sum of this context (advances its number)
 int tmhip_direct_allreduce(tmhip_ctx *ctx, double *x);   // sum of *x (device) over the ranks, in place, added in rank order; enqueued on ctx->stream (needs direct.sums_on)
 
 // ---- launch helpers implemented across the .hip files ----

@@ -89,46 +89,31 @@ void tmhip_direct_destroy(tmhip_ctx *ctx) {
 }
 
 // ---- direct sums: MPI_Allreduce(..., MPI_SUM) of one double (linalg/square_norm.c:314, the alpha and the stopping test of cg_her) --------
-// One wave.  Lane r stores this rank's partial sum into slot [parity][me] of rank r's block (value, drained, then the reduction's number:
-// two stores in order, nothing relies on a 16-byte store arriving whole), waits -- bounded like every wait here -- until rank r's
-// contribution to THIS reduction sits in slot [parity][r] of its own block, and lane 0 adds the np values in rank order: the same bits
-// on every rank.  Two slot rows in turn are enough: a rank cannot be two reductions ahead of one whose contribution it still needs.
-struct SumSlot { double v; unsigned long long seq; };
-struct SumPeers { SumSlot *p[TMHIP_DIRECT_MAX_RANKS]; };
-__global__ __launch_bounds__(64) void direct_allreduce_kernel(double *x, SumSlot *mine, const SumPeers peers, int np, int me, unsigned long long seq,
-                                                              unsigned int *err, unsigned long long ticks) {
-  const int r = (int)threadIdx.x;
-  const int row = (int)(seq & 1ull) * TMHIP_DIRECT_MAX_RANKS;
-  double v = 0.0;
-  if (r < np) {
-    const double mine_v = *x;
-    SumSlot *dst = peers.p[r] + row + me;
-    __hip_atomic_store(&dst->v, mine_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const SumSlot *src = mine + row + r;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((long long)(__hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-      __builtin_amdgcn_s_sleep(4);
-      if (ticks && __builtin_amdgcn_s_memrealtime() - t0 > ticks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-    }
-    v = __hip_atomic_load(&src->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  double total = 0.0;
-  for (int k = 0; k < np; k++) total += __shfl(v, k, 64);      // rank order, every lane alike
-  if (r == 0) *x = total;
+// tmhip_direct_sum_wave (tmhip_internal.h) is one wave's exchange; here it is a kernel of its own, and cg.hip puts it between the sum of a
+// stencil's partial sums and the scalar update of the CG state, in one launch.  Two slot rows in turn are enough: a rank cannot be two
+// reductions ahead of one whose contribution it still needs.
+__global__ __launch_bounds__(64) void direct_allreduce_kernel(double *x, const TmhipSumArgs a) {
+  const double total = tmhip_direct_sum_wave(*x, a);
+  if (threadIdx.x == 0) *x = total;
+}
+
+int tmhip_direct_sum_args(tmhip_ctx *ctx, TmhipSumArgs *out) {
+  TmhipDirect &d = ctx->direct;
+  if (!d.on || !d.sums_on) TMHIP_FAIL("a direct sum without the direct sums (tmhip_comm_init_ipc, option direct_sums)");
+  const size_t off = 4 * face_bytes(ctx) + 1024;               // the slot rows lie behind the arrival words (alloc_mine)
+  memset(out, 0, sizeof(*out));
+  out->np = ctx->g.nproc_t; out->me = ctx->g.proc_t;
+  for (int r = 0; r < out->np; r++) out->peer[r] = (TmhipSumSlot *)((char *)d.peer_all[r] + off);
+  out->mine = (TmhipSumSlot *)((char *)d.mine + off);
+  out->seq = ++d.sum_seq;
+  out->err = ctx->sync_flags + 2; out->ticks = ctx->flag_timeout_ticks;
+  return 0;
 }
 
 int tmhip_direct_allreduce(tmhip_ctx *ctx, double *x) {
-  TmhipDirect &d = ctx->direct;
-  if (!d.on || !d.sums_on) TMHIP_FAIL("tmhip_direct_allreduce without the direct sums");
-  const int np = ctx->g.nproc_t;
-  const size_t off = 4 * face_bytes(ctx) + 1024;               // the slot rows lie behind the arrival words (alloc_mine)
-  SumPeers peers;
-  memset(&peers, 0, sizeof(peers));
-  for (int r = 0; r < np; r++) peers.p[r] = (SumSlot *)((char *)d.peer_all[r] + off);
-  hipLaunchKernelGGL(direct_allreduce_kernel, dim3(1), dim3(64), 0, ctx->stream, x, (SumSlot *)((char *)d.mine + off), peers, np, ctx->g.proc_t, ++d.sum_seq,
-                     ctx->sync_flags + 2, ctx->flag_timeout_ticks);
+  TmhipSumArgs a;
+  if (tmhip_direct_sum_args(ctx, &a)) return 1;
+  hipLaunchKernelGGL(direct_allreduce_kernel, dim3(1), dim3(64), 0, ctx->stream, x, a);
   TMHIP_CHECK(hipGetLastError());
   return 0;
 }
