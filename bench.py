@@ -434,6 +434,8 @@ def make_lattice(ph, R, T, L, args, nproc_t, faces="comm"):
             ph.step("comm_init_ipc", lat.comm_init_ipc)
     if args.loopback and R.world == 1:
         lat.set_loopback(args.loopback)
+        if faces == "direct" and args.loopback == 2:
+            lat.comm_init_ipc()     # behind the one-rank RCCL communicator: the collective set-up over RCCL with np = 1, the rank its own neighbour
     return lat
 
 
@@ -690,7 +692,7 @@ def rank_main(args, world, rank, local_rank):
         f0, f1, f2 = box["f"]
         dt, ev_ms = time_hopping(hl, R, lat, f0, f1, f2, args.steps, args.warmup)
         gpu_out = f2.download() if (rank == 0 and world == 1 and not args.no_cpu) else None
-        try_direct = world > 1 and R.faces_mode == "auto"
+        try_direct = (world > 1 or (args.rehearse_split and args.loopback == 2)) and R.faces_mode == "auto"
         f2_ref = f2.download() if try_direct else None         # this rank's slab of H_oe H_eo f0: what the other carrier has to reproduce
         # --- CG part of the metric: cg_her on Qtm_pm_psi (solver/cg_her.c:91-126)
         P, Q = box["PQ"]

@@ -288,7 +288,9 @@ int tmhip_comm_init_shm(tmhip_ctx *ctx, const char *job);
  * xchange/xchange_halffield.c:176-263 (operator/halfspinor_body.c:281-317) for the faces; sums and the other halos stay on the
  * communicator.  No copy, no kernel of a communication library, nothing on the receiver's compute units; on lattices whose boundary
  * waves fit the wait budget a stencil of a T-split rank is ONE kernel ("direct_form").  Non-zero (and the faces stay on the communicator,
- * on EVERY rank) when some rank cannot map a neighbour. */
+ * on EVERY rank) when some rank cannot map a neighbour.  A single rank behind the one-rank RCCL communicator of
+ * tmhip_comm_set_loopback(ctx, 2) may call it too: the collective set-up runs over RCCL with np = 1 and the rank becomes its own
+ * neighbour (the single-GPU rehearsal of this function and of the direct sums). */
 int tmhip_comm_init_ipc(tmhip_ctx *ctx);
 /* 1 when the faces travel as direct stores (0: over the communicator); *sharers (may be NULL): ranks of the job on this rank's GPU */
 int tmhip_comm_faces_direct(tmhip_ctx *ctx, int *sharers);

@@ -485,3 +485,39 @@ def test_linalg_empty_and_out_of_range_site_counts(setup):
         with pytest.raises(TmHipError):
             lat.assign_add_mul_r(da, db, 1.0, bad)
     da.free(); db.free()
+
+
+def test_direct_carrier_set_up_over_a_one_rank_rccl_communicator():
+    """tmhip_comm_init_ipc's collective set-up as it runs between GPUs -- the gather of the IPC cards and the all-or-none sum over RCCL
+    (ncclAllGather / ncclAllReduce on the reduction communicator) -- rehearsed behind the one-rank communicator of loopback 2, where
+    the rank becomes its own neighbour: faces as direct stores, the scalar sums as direct sums (one wave, np = 1), cg_her with the
+    reduction fused into one launch.  Everything must equal the unsplit lattice."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T, L = 8, 16
+    lat = Lattice(T, L, L, L, kappa=0.13, mu=0.015)
+    orc = Oracle(T, L, L, L, kappa=0.13, mu=0.015, threads=8)
+    g = syn.gauge_field(41, T, L, L, L)
+    lat.set_gauge(g); orc.set_gauge(g)
+    N = lat.Vh
+    q = syn.spinor_field_eo(42, 1, T, L, L, L)
+    lat.set_loopback(2)
+    lat.comm_init_ipc()
+    assert lat.comm_faces_direct() == (True, 1) and lat.comm_sums_direct() is True and lat.comm_count() == (1, 1)
+    dq, dl, dp = lat.field(q), lat.field(), lat.field()
+    ref = orc.new_field()
+    for ieo in (0, 1):
+        orc.Hopping_Matrix(ieo, ref, q); lat.Hopping_Matrix(ieo, dl, dq)
+        assert rel_err(dl.download(), ref[:N]) < TOL
+    orc.op("Qtm_pm_psi", ref, q.copy()); lat.Qtm_pm_psi(dl, dq)
+    assert rel_err(dl.download(), ref[:N]) < TOL
+    n_ref = orc.square_norm(ref, N)
+    assert abs(lat.square_norm(dl, N, 1) - n_ref) <= 1e-13 * n_ref            # parallel = 1: through the direct sum
+    P = orc.new_field()
+    it_ref, hist_ref = orc.cg_her(P, q.copy(), 500, 1e-20, 1, N)
+    it, hist = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
+    assert abs(it - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9
+    m = min(len(hist), len(hist_ref)) - 1
+    assert np.allclose(hist[:m], hist_ref[:m], rtol=1e-6)
+    lat.close()

@@ -126,10 +126,14 @@ extern "C" {
 int tmhip_comm_init_ipc(tmhip_ctx *ctx) {
   TmhipDirect &d = ctx->direct;
   if (d.on) TMHIP_FAIL("tmhip_comm_init_ipc: the direct carrier is already on");
-  if (ctx->g.nproc_t < 2) return 0;
+  // A single rank has nothing to map -- except behind the one-rank RCCL communicator of loopback 2, where the whole collective set-up
+  // (gather of the cards, the all-or-none sum, both over RCCL) runs with np = 1 and the rank becomes its own neighbour: the single-GPU
+  // rehearsal of this function's RCCL calls and of the direct sums
+  if (ctx->g.nproc_t < 2 && !(ctx->loopback_rccl && ctx->comm_ready && !ctx->shm)) return 0;
   if (!ctx->comm_ready) TMHIP_FAIL("tmhip_comm_init_ipc: call tmhip_comm_init or tmhip_comm_init_shm first (the handles travel over that communicator)");
   TMHIP_CHECK(hipSetDevice(ctx->device));
   const int np = ctx->g.nproc_t, me = ctx->g.proc_t, up = (me + 1) % np, dn = (me + np - 1) % np;
+  if (d.mine) tmhip_direct_destroy(ctx);     // (a block of an earlier loopback 3)
   if (alloc_mine(ctx)) return 1;
   Card mine;
   memset(&mine, 0, sizeof(mine));
@@ -151,6 +155,7 @@ int tmhip_comm_init_ipc(tmhip_ctx *ctx) {
   if (memcmp(&all[(size_t)me], &mine, sizeof(Card))) TMHIP_FAIL("tmhip_comm_init_ipc: the gather did not return this rank's own card in slot %d", me);
   d.sharers = 0;
   for (int r = 0; r < np; r++) if (!strncmp(all[(size_t)r].busid, mine.busid, sizeof(mine.busid))) d.sharers++;
+  if (d.count == nullptr) TMHIP_FAIL("tmhip_comm_init_ipc: no count-in words");
   // map the ring neighbours (faces) and -- for the sums -- everybody else too; [me] is this rank's own block
   d.peer_all[me] = d.mine;
   hipError_t e = hipSuccess, e_all = np <= TMHIP_DIRECT_MAX_RANKS && ctx->opt_direct_sums ? hipSuccess : hipErrorNotSupported;
