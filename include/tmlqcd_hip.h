@@ -338,13 +338,9 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "split_sync" 0 (default) | 1: T-split ranks -- 0: the exterior kernel (main stream) and the pack kernel (comm stream) wait on the device for a
  *                flag of the other stream; 1: the two streams are ordered by HIP events, no wait on the device at all (slower: two events on the
  *                main stream per stencil)
- *   "split_pipe" 0 (default) | 1 | 2: T-split ranks -- the boundary time-slices are dispatched FIRST; a stencil whose faces are not there yet has its
- *                exterior kernel run on the comm stream beside the remaining slices, and the faces of the NEXT stencil of a chain (Qtm_pm_psi, a CG
- *                iteration, the benchmark loop) are exchanged while the current one is still running, so that one takes all eight hops inline with
- *                no exterior kernel.  Behind a ONE-rank RCCL communicator 32 x 32^3: 90-92 -> 95-97 % of the unsplit rate, 16 x 32^3 85 -> 88 %; loses
- *                on grids the chip holds at once and with plain device-to-device copies (profiles/r03_split_forms.md).  1: local lattices of 262144
- *                sites per parity or more; 2: always.  Off by default until it has run between two RCCL ranks.  An exchange ahead is never in flight
- *                together with a collective of the compute stream (the compute stream waits for it first)
+ *                ("split_pipe" of round 3 is gone: slower than the default form since the stencil kernel has one store path, and the direct carrier
+ *                does what it was for -- faces of a chain's next stencil on their way while the current one runs -- without an RCCL kernel;
+ *                profiles/r04_split_forms.md)
  *   "direct_form" -1 (default) | 0 | 1: the direct carrier (tmhip_comm_init_ipc) -- 1: one kernel per stencil (the boundary waves wait for their
  *                neighbour's word after their seven local hops, add the hop across the cut, project their output and store the projection into the
  *                neighbour's buffer); 0: stencil kernel + exterior kernel (which waits and pushes); -1: one kernel while the boundary waves of a

@@ -74,13 +74,13 @@ def test_fused_epilogues(setup16, ieo):
         f.free()
 
 
-@pytest.mark.parametrize("mode,split_sync,prepack,form", [(1, 0, 1, 0), (2, 0, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (1, 0, 0, 0), (2, 1, 0, 0), (1, 0, 1, 2), (2, 0, 1, 2),
+@pytest.mark.parametrize("mode,split_sync,prepack,form", [(1, 0, 1, 0), (2, 0, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (1, 0, 0, 0), (2, 1, 0, 0),
                                                           (3, 0, 1, "one/0"), (3, 0, 1, "one/1"), (3, 0, 1, "one/2"), (3, 0, 1, "one/3"), (3, 0, 1, "two/0")])
 def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, form):
     """Single-GPU self-test of the multi-GPU code path: faces packed, exchanged with self, the stencil over all sites with the hop
     across the cut added by the exterior kernel -- behind a flag (split_sync 0, default) or behind a HIP event (1) -- must equal the
     plain periodic stencil.  prepack 1 (default): the stencils of a chain (Qtm_pm_psi below) take their faces from the previous
-    stencil's exterior kernel instead of a pack kernel.  form 2: "split_pipe".  mode 3: the direct carrier onto oneself (the
+    stencil's exterior kernel instead of a pack kernel.  mode 3: the direct carrier onto oneself (the
     producing waves store the faces into the receiver's buffers): "one/<order>" = one kernel per stencil, boundary waves wait for
     their neighbour's word, with every dispatch order of the boundary slices; "two/0" = stencil + exterior kernel."""
     orc, lat = setup16
@@ -90,7 +90,6 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, form):
     dk, dl = lat.field(k), lat.field()
     lat.set_option("split_sync", split_sync)
     lat.set_option("prepack", prepack)
-    lat.set_option("split_pipe", 2 if form == 2 else 0)    # boundary slices first, exterior kernel beside the stencil kernel, faces of a chain exchanged ahead
     if mode == 3:
         lat.set_option("direct_form", 1 if form.startswith("one") else 0)
         lat.set_option("direct_order", int(form.split("/")[1]))
@@ -124,7 +123,7 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, form):
         assert rel_err(q.download(), qref[:N]) < TOL
         q.free()
         # the benchmark loop (benchmark.c:291-300): f1 = H_eo f0, f2 = H_oe f1, many times back to back -- every second stencil gathers
-        # the output of the one before (with split_pipe: its faces are exchanged while that one is still running)
+        # the output of the one before (direct carrier: its faces are pushed by the waves that complete its boundary slices)
         dk.upload(k)
         f1, f2 = lat.field(), lat.field()
         lat.bench_hopping(dk, f1, f2, 7)
@@ -144,7 +143,6 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, form):
         lat.set_loopback(0)
         lat.set_option("split_sync", 0)
         lat.set_option("prepack", 1)
-        lat.set_option("split_pipe", 0)
         lat.set_option("direct_form", -1); lat.set_option("direct_order", 2)
     dk.free(); dl.free()
 

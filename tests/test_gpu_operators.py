@@ -256,12 +256,12 @@ def test_cg_fused_scalar_product_path(fused):
     assert rel_err(dp.download(), Pc[:N]) < 1e-9          # P after exactly 7 updates, no extra / missing alpha p
     # the same solve on the split-phase path (T-split rank rehearsed on one GPU): with cg_fused_dot = 2 the reductions are
     # spread over the stencil kernel (all sites but the two boundary slices) and the exterior kernel (those two)
-    for mode, ss in ((1, 0), (2, 0), (1, 1), (2, 1), (1, 4), (2, 4), (3, 8), (3, 16)):      # ss = 1: HIP events instead of flags; 4: flags + "split_pipe"; 8 / 16: direct carrier, one kernel / stencil + exterior kernel
-        lat.set_option("split_sync", ss & 1); lat.set_option("split_pipe", 2 if ss & 4 else 0); lat.set_option("direct_form", 1 if ss & 8 else (0 if ss & 16 else -1))
+    for mode, ss in ((1, 0), (2, 0), (1, 1), (2, 1), (3, 8), (3, 16)):      # ss = 1: HIP events instead of flags; 8 / 16: direct carrier, one kernel / stencil + exterior kernel
+        lat.set_option("split_sync", ss & 1); lat.set_option("direct_form", 1 if ss & 8 else (0 if ss & 16 else -1))
         lat.set_loopback(mode)
         dp.zero()
         it4, hist4 = lat.cg_her(dp, dq, 500, 1e-20, 1, N)
-        lat.set_loopback(0); lat.set_option("split_sync", 0); lat.set_option("split_pipe", 0); lat.set_option("direct_form", -1)
+        lat.set_loopback(0); lat.set_option("split_sync", 0); lat.set_option("direct_form", -1)
         assert abs(it4 - it_ref) <= 1 and rel_err(dp.download(), P[:N]) < 1e-9, (mode, ss)
         m4 = min(len(hist4), len(hist_ref)) - 1
         assert np.allclose(hist4[:m4], hist_ref[:m4], rtol=1e-6)
@@ -284,8 +284,8 @@ def test_cg_fused_split_path_wide_short_local_lattice():
     P = orc.new_field()
     it_ref, hist_ref = orc.cg_her(P, q.copy(), 500, 1e-20, 1, N)
     dq, dp = lat.field(q), lat.field()
-    for loop, ss in ((0, 0), (1, 0), (2, 0), (1, 1), (1, 4), (2, 4), (3, 8), (3, 16)):      # ss 4: "split_pipe"; 8 / 16: direct carrier, one kernel / two kernels
-        lat.set_option("split_sync", ss & 1); lat.set_option("split_pipe", 2 if ss & 4 else 0); lat.set_option("direct_form", 1 if ss & 8 else (0 if ss & 16 else -1))
+    for loop, ss in ((0, 0), (1, 0), (2, 0), (1, 1), (3, 8), (3, 16)):      # ss 8 / 16: direct carrier, one kernel / two kernels
+        lat.set_option("split_sync", ss & 1); lat.set_option("direct_form", 1 if ss & 8 else (0 if ss & 16 else -1))
         lat.set_loopback(loop)
         dp.zero()
         it, hist = lat.cg_her(dp, dq, 500, 1e-20, 1, N)

@@ -2,7 +2,7 @@
 epilogue, compositions (chains), linalg kernels that rewrite fields between stencils, short cg_her solves, communication-free
 stencils (whose output is stale by construction and overwritten afterwards), uploads, and a comm stream that is held back at random
 points (a neighbour arriving late) -- against the SAME sequence on the unsplit lattice.  Every form of the split path (flags, HIP
-events, split_pipe; the direct carrier's one- and two-kernel forms) and all three self-exchanges (copies, one-rank RCCL communicator, direct stores) must reproduce the unsplit fields:
+events; the direct carrier's one- and two-kernel forms) and all three self-exchanges (copies, one-rank RCCL communicator, direct stores) must reproduce the unsplit fields:
 what this guards is the bookkeeping between stencils (sequence numbers, which field's faces sit in the send buffers, which faces
 were exchanged ahead), which no single-operation test exercises."""
 import numpy as np
@@ -80,7 +80,7 @@ def _run(lat, seed, nops, split, gen=None, skew=None):
     return out, scal
 
 
-FORMS = [("flags", {}), ("events", {"split_sync": 1}), ("no prepack", {"prepack": 0}), ("split_pipe", {"split_pipe": 2})]
+FORMS = [("flags", {}), ("events", {"split_sync": 1}), ("no prepack", {"prepack": 0})]
 # loopback 3 = the direct carrier (faces stored by the producing waves into "the neighbour's" buffers): its own two forms
 DIRECT_FORMS = [("one kernel, boundary last / first", {"direct_form": 1, "direct_order": 2}), ("one kernel, boundary first / last", {"direct_form": 1, "direct_order": 1}),
                 ("stencil + exterior kernel", {"direct_form": 0})]

@@ -380,7 +380,6 @@ static int cg_her_sync(tmhip_ctx *ctx, tmhip_field *P, tmhip_field *Q, int max_i
 static int cg_allreduce(tmhip_ctx *ctx, double *x) {
   if (tmhip_reduce_over_ranks(ctx)) {
     if (ctx->direct.on && ctx->direct.sums_on) return tmhip_direct_allreduce(ctx, x);   // one wave storing into every rank's block: no communicator involved
-    if (tmhip_comm_quiesce(ctx)) return 1;
     if (ctx->shm) return tmhip_shm_allreduce(ctx, ctx->stream, x, 1);
     TMHIP_NCCL_CHECK(ncclAllReduce(x, x, 1, ncclDouble, ncclSum, ctx->comm_red, ctx->stream));
   }

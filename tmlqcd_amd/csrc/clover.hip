@@ -533,6 +533,16 @@ __device__ __forceinline__ void sw_all_plane(double (&out)[8], const LD &ld, SwS
   out[6] = cs * (+a.e[7].x - a.e[5].x);
   out[7] = cs * ((-a.e[0].y - a.e[4].y + 2.0 * a.e[8].y) * 0.577350269189625);
 }
+// Tile order of the 64-site blocks of a launch (sw_term_kernel below has the reasoning; sw_all_gather_kernel shares it): tb = 0 plain order.
+struct SwOrder { int tb, tx, tyb, nby, nty, ntiles, t0, nt; };
+// site block of thread block blockIdx.x (r = its running number within the XCD and parity), or -1: beyond the last tile
+__device__ __forceinline__ int sw_tile_block(const SwOrder &ord, int LX, int r) {
+  const int bx = r % ord.tb; r /= ord.tb;
+  const int tt = r % ord.nt, tile = (r / ord.nt) * 8 + (int)(blockIdx.x & 7);
+  if (tile >= ord.ntiles) return -1;
+  const int tile_x = tile / ord.nty, tile_y = tile - tile_x * ord.nty, bxx = bx / ord.tyb, bxy = bx - bxx * ord.tyb;
+  return (tt * LX + tile_x * ord.tx + bxx) * ord.nby + tile_y * ord.tyb + bxy;      // (whole time-slices from i_begin on)
+}
 // block = 64 sites of one parity x 4 waves: wave w owns the links (site, mu = w), walks the three planes through them one after the
 // other (one body with RUN-TIME directions: twelve compile-time instances measured the same, at twelve times the code) and does the
 // link's one read-modify-write.  Sites: e/o index in [i_begin, i_end) of either parity.
@@ -541,12 +551,15 @@ __device__ __forceinline__ void sw_all_plane(double (&out)[8], const LD &ld, SwS
 // around those 64 + 64 sites are fetched once and re-used out of L2.
 template <class LD>
 __global__ __launch_bounds__(256, LD::min_blocks) void sw_all_gather_kernel(const LD ld, double *__restrict__ deriv, int LX, int LY, int LZ, int Vh,
-                                                               int i_begin, int i_end, int chunk, int slab, int nbt, double c) {
+                                                               int i_begin, int i_end, int chunk, int slab, int nbt, double c, const SwOrder ord) {
   const int lane = threadIdx.x & 63;
   const int mu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform, in a scalar register
   const int q = blockIdx.x >> 3;
   int sb;
-  if (slab > 0) {    // slab order: XCD j owns the j-th eighth of EVERY time-slice (nbt site blocks each) and marches through t
+  if (ord.tb > 0) {  // tile order ("swall_order" 2): an XCD walks a tile of tx x-planes x tyb block rows through all time-slices
+    sb = sw_tile_block(ord, LX, q >> 1);
+    if (sb < 0) return;
+  } else if (slab > 0) {    // slab order: XCD j owns the j-th eighth of EVERY time-slice (nbt site blocks each) and marches through t
     const int r = q >> 1, tt = r / slab, rr = (blockIdx.x & 7) * slab + (r - tt * slab);
     if (rr >= nbt) return;
     sb = tt * nbt + rr;
@@ -616,7 +629,6 @@ __global__ __launch_bounds__(256) void sw_pack_slabs_kernel(v2d *__restrict__ ou
 // tx x-planes x tyb block-rows x all z (4 x 4 x 32 sites at 32^3: 0.3 MB of links per time-slice, 0.66 MB with the halo ring) and walks
 // each tile through ALL time-slices before it takes the next one; slices t - 1, t, t + 1 of tile + halo (2 MB) stay in L2 while t
 // advances, so a link comes in once per tile that owns or borders it.  tb = 0: the plain order.
-struct SwOrder { int tb, tx, tyb, nby, nty, ntiles, t0, nt; };
 // The four plaquette leaves around x in the (k, l) plane (clover_term.c:104-154), two at a time: A = the leaves in the +k+l and -k+l
 // quadrants, B = those in -k-l and +k-l.  Q is set (init) or added to.
 template <class LD>
@@ -660,12 +672,8 @@ __global__ __launch_bounds__(256, LD::min_blocks == 1 ? 1 : SWT_MINW) void sw_te
   const int q = blockIdx.x >> 3, par = q & 1;
   int sb;
   if (ord.tb > 0) {
-    int r = q >> 1;
-    const int bx = r % ord.tb; r /= ord.tb;
-    const int tt = r % ord.nt, tile = (r / ord.nt) * 8 + (int)(blockIdx.x & 7);
-    if (tile >= ord.ntiles) return;
-    const int tile_x = tile / ord.nty, tile_y = tile - tile_x * ord.nty, bxx = bx / ord.tyb, bxy = bx - bxx * ord.tyb;
-    sb = (tt * LX + tile_x * ord.tx + bxx) * ord.nby + tile_y * ord.tyb + bxy;      // (whole time-slices from i_begin on)
+    sb = sw_tile_block(ord, LX, q >> 1);
+    if (sb < 0) return;
   } else {
     sb = (blockIdx.x & 7) * chunk + (q >> 1);
   }
@@ -802,6 +810,20 @@ static int clover_alloc(tmhip_ctx *ctx) {
 
 /* operator/clover_term.c:88 sw_term(gf, kappa, c_sw): gf is the host gauge field exactly as for tmhip_set_gauge
  * ([VOLUMEPLUSRAND][4] su3, halo slabs filled on T-split ranks).  Result stays in HBM (fetch with tmhip_get_clover). */
+// Tile order of a launch over the e/o sites [ib, ie) (whole time-slices): fills *ord and returns the grid, or 0 when the shape does not
+// allow it (a 64-site block must be whole z-rows of one (t, x) row).  txw: x-planes per tile.
+static int sw_tile_order(const tmhip_ctx *ctx, int ib, int ie, int txw, SwOrder *ord) {
+  const int LZh = ctx->g.LZ / 2, rpb = LZh > 0 && 64 % LZh == 0 ? 64 / LZh : 0;
+  if (!(rpb > 0 && ctx->g.LY % rpb == 0 && ib % ctx->face == 0 && ie % ctx->face == 0 && ctx->face % 64 == 0)) return 0;
+  ord->nby = ctx->g.LY / rpb;
+  ord->tx = ctx->g.LX % txw == 0 ? txw : (ctx->g.LX % 4 == 0 ? 4 : (ctx->g.LX % 2 == 0 ? 2 : 1));
+  ord->tyb = rpb >= 4 ? 1 : ((4 / rpb) <= ord->nby && ord->nby % (4 / rpb) == 0 ? 4 / rpb : 1);
+  ord->nty = ord->nby / ord->tyb;
+  ord->ntiles = (ctx->g.LX / ord->tx) * ord->nty;
+  ord->tb = ord->tx * ord->tyb;
+  ord->t0 = ib / ctx->face; ord->nt = (ie - ib) / ctx->face;
+  return 8 * ((ord->ntiles + 7) / 8) * ord->nt * ord->tb * 2;
+}
 int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_sw) {
   if (!gauge_host && !(ctx->gauge_raw && ctx->gauge_raw_valid)) TMHIP_FAIL("tmhip_sw_term: null gauge field and no links resident on the device");
   TMHIP_CHECK(hipSetDevice(ctx->device));
@@ -822,18 +844,8 @@ int tmhip_sw_term(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c
     const int chunk = ((ie - ib + 63) / 64 + 7) / 8;
     // tile order whenever a 64-site block is whole z-rows of one (t, x) row and the range is whole time-slices ("swterm_order" 0: plain order)
     SwOrder ord = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int LZh = ctx->g.LZ / 2, rpb = LZh > 0 && 64 % LZh == 0 ? 64 / LZh : 0;
     int grid = chunk * 16;
-    if (ctx->opt_swterm_order && rpb > 0 && ctx->g.LY % rpb == 0 && ib % ctx->face == 0 && ie % ctx->face == 0 && ctx->face % 64 == 0) {
-      ord.nby = ctx->g.LY / rpb;
-      ord.tx = ctx->g.LX % 4 == 0 ? 4 : (ctx->g.LX % 2 == 0 ? 2 : 1);
-      ord.tyb = rpb >= 4 ? 1 : ((4 / rpb) <= ord.nby && ord.nby % (4 / rpb) == 0 ? 4 / rpb : 1);
-      ord.nty = ord.nby / ord.tyb;
-      ord.ntiles = (ctx->g.LX / ord.tx) * ord.nty;
-      ord.tb = ord.tx * ord.tyb;
-      ord.t0 = ib / ctx->face; ord.nt = (ie - ib) / ctx->face;
-      grid = 8 * ((ord.ntiles + 7) / 8) * ord.nt * ord.tb * 2;
-    }
+    if (ctx->opt_swterm_order) { const int gt = sw_tile_order(ctx, ib, ie, 4, &ord); if (gt) grid = gt; }
     hipLaunchKernelGGL((sw_term_kernel<SwFastLd>), dim3(grid), dim3(256), 0, ctx->stream, ld, ctx->sw, (unsigned)ctx->gs, ctx->g.LX, ctx->g.LY, ctx->g.LZ,
                        ib, ie, chunk, c, ord);
   }
@@ -974,6 +986,7 @@ static int sw_all_prepare(tmhip_ctx *ctx, const void *gauge_host) {
   return 0;
 }
 static int sw_all_launch(tmhip_ctx *ctx, double kappa, double c_sw) {
+  const SwOrder plain = {0, 0, 0, 0, 0, 0, 0, 0};
   LexGeom g{ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->V, ctx->g.nproc_t > 1 ? 1 : 0};
   const double c = -2. * (kappa * c_sw / 8.);
   const bool split = ctx->g.nproc_t > 1;
@@ -985,8 +998,10 @@ static int sw_all_launch(tmhip_ctx *ctx, double kappa, double c_sw) {
       nbt = ctx->face / 64; slab = (nbt + 7) / 8;
       grid = 8 * slab * ((ie - ib) / ctx->face) * 2;
     }
+    SwOrder ord = plain;
+    if (ctx->opt_swall_order >= 2) { const int gt = sw_tile_order(ctx, ib, ie, ctx->opt_swall_order >= 4 ? ctx->opt_swall_order : 4, &ord); if (gt) grid = gt; }
     hipLaunchKernelGGL((sw_all_gather_kernel<SwFastLd>), dim3(grid), dim3(256), 0, ctx->stream, ld, ctx->deriv, ctx->g.LX,
-                       ctx->g.LY, ctx->g.LZ, ctx->Vh, ib, ie, chunk, slab, nbt, c);
+                       ctx->g.LY, ctx->g.LZ, ctx->Vh, ib, ie, chunk, slab, nbt, c, ord);
   }
   if (split) {     // the two t-faces, after the neighbours' swm / swp slices have arrived (same stream)
     const SwEdgeLd ld{(const v2d *)ctx->gauge_raw, (const v2d *)ctx->sw_ins, (unsigned)ctx->V, (const v2d *)ctx->swpm_halo_recv, g, ctx->Vh};
@@ -995,7 +1010,7 @@ static int sw_all_launch(tmhip_ctx *ctx, double kappa, double c_sw) {
       const int fb = w ? ctx->Vh - ctx->face : 0;
       const int chunk = ((ctx->face + 63) / 64 + 7) / 8;
       hipLaunchKernelGGL((sw_all_gather_kernel<SwEdgeLd>), dim3(chunk * 16), dim3(256), 0, ctx->stream, ld, ctx->deriv, ctx->g.LX,
-                         ctx->g.LY, ctx->g.LZ, ctx->Vh, fb, fb + ctx->face, chunk, 0, 0, c);
+                         ctx->g.LY, ctx->g.LZ, ctx->Vh, fb, fb + ctx->face, chunk, 0, 0, c, plain);
     }
   }
   TMHIP_CHECK(hipGetLastError());
@@ -1014,7 +1029,6 @@ int tmhip_sw_all(tmhip_ctx *ctx, const void *gauge_host, double kappa, double c_
   if (np > 1) {
     const size_t n = (size_t)2 * 30 * ctx->g.LX * ctx->g.LY * ctx->g.LZ;   // doubles per slice of insertion matrices
     double *snd = (double *)ctx->swpm_halo_send, *rcv = (double *)ctx->swpm_halo_recv;
-    if (tmhip_comm_quiesce(ctx)) return 1;
     if (ctx->shm) { if (tmhip_shm_ring(ctx, ctx->stream, snd, snd + n, rcv, rcv + n, n * sizeof(double))) return 1; }
     else {
     TMHIP_NCCL_CHECK(ncclGroupStart());

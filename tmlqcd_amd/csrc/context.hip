@@ -146,7 +146,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
-  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_split_pipe = 0; ctx->opt_direct_form = -1; ctx->opt_direct_order = 2; ctx->opt_direct_sums = 1;
+  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_direct_form = -1; ctx->opt_direct_order = 2; ctx->opt_direct_sums = 1;
   {
     // bound of the device-side waits for the neighbours' faces: TMLQCD_HIP_FLAG_TIMEOUT_S in the environment (0 = none), default 120 s
     double sec = 120.0;
@@ -302,11 +302,10 @@ int tmhip_set_option(tmhip_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "direct_sums")) { if (ctx->direct.on) TMHIP_FAIL("direct_sums must be set before tmhip_comm_init_ipc"); ctx->opt_direct_sums = value != 0; }
   else if (!strcmp(name, "direct_order")) { if (value < 0 || value > 3) TMHIP_FAIL("direct_order: bit 0 / bit 1 = boundary time-slices first for a stencil whose faces are packed now / were pushed ahead"); ctx->opt_direct_order = value; }
   else if (!strcmp(name, "prepack")) { ctx->opt_prepack = value != 0; ctx->prepacked = nullptr; }
-  else if (!strcmp(name, "split_pipe")) { if (value < 0 || value > 2) TMHIP_FAIL("split_pipe must be 0 (off, default), 1 (local lattices of >= 262144 sites per parity) or 2 (every size)"); ctx->opt_split_pipe = value; ctx->prepacked = nullptr; ctx->ahead_field = nullptr; }
   else if (!strcmp(name, "comm_split")) { if (ctx->comm_ready) TMHIP_FAIL("comm_split must be set before the communicator is created"); ctx->opt_comm_split = value != 0; }
   else if (!strcmp(name, "cg_fused_dot")) ctx->opt_cg_fused_dot = value;
   else if (!strcmp(name, "gauge_cache")) { if (value < -1 || value > 1) TMHIP_FAIL("gauge_cache must be -1 (automatic), 0 or 1"); ctx->opt_gauge_cache = value; }
-  else if (!strcmp(name, "swall_order")) { if (value < 0 || value > 1) TMHIP_FAIL("swall_order must be 0 (chunk per XCD) or 1 (slab order, default)"); ctx->opt_swall_order = value; }
+  else if (!strcmp(name, "swall_order")) { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) TMHIP_FAIL("swall_order must be 0 (chunk per XCD), 1 (slab order) or 2 (tile order; 4 / 8: tiles of that many x-planes)"); ctx->opt_swall_order = value; }
   else if (!strcmp(name, "swterm_order")) { if (value < 0 || value > 1) TMHIP_FAIL("swterm_order must be 0 (chunk per XCD) or 1 (tiles through all time-slices, default)"); ctx->opt_swterm_order = value; }
   else if (!strcmp(name, "occ32")) { if (value < 0 || value > 8) TMHIP_FAIL("occ32 must be in [0, 8]"); ctx->opt_occ32 = value; }
   else if (!strcmp(name, "gauge_recon")) {
@@ -676,7 +675,7 @@ int tmhip_comm_set_loopback(tmhip_ctx *ctx, int on) {
   if (on < 0 || on > 3) TMHIP_FAIL("loopback: 0 off, 1 device-to-device copies, 2 one-rank RCCL communicator, 3 direct carrier onto oneself");
   ctx->loopback = on != 0;
   ctx->loopback_rccl = on == 2;
-  ctx->prepacked = nullptr; ctx->ahead_field = nullptr; ctx->direct.ahead_field = nullptr;
+  ctx->prepacked = nullptr; ctx->direct.ahead_field = nullptr;
   if (on == 3) { if (tmhip_direct_init_self(ctx)) return 1; }
   else if (ctx->direct.on) {   // back to a carrier on the comm stream: everything pushed so far has been consumed or is abandoned
     TMHIP_CHECK(hipStreamSynchronize(ctx->stream)); TMHIP_CHECK(hipStreamSynchronize(ctx->comm_stream));

@@ -209,7 +209,6 @@ int tmhip_deriv_Sb(tmhip_ctx *ctx, int ieo, tmhip_field *l, tmhip_field *k, doub
   } else {
     if (!ctx->comm_ready) TMHIP_FAIL("nproc_t > 1 but tmhip_comm_init was not called");
     const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
-    if (tmhip_comm_quiesce(ctx)) return 1;
     if (ctx->shm) { if (tmhip_shm_ring(ctx, ctx->stream, ctx->force_send, nullptr, ctx->force_recv, nullptr, n * sizeof(double))) return 1; }
     else {
     TMHIP_NCCL_CHECK(ncclGroupStart());

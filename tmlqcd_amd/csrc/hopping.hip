@@ -53,13 +53,6 @@ int tmhip_launch_hopping_dot32(tmhip_ctx *ctx, int ieo, v2f *out, const v2f *in,
                                double cre, double cim, int *npartials, int mode, v2f *resid, const double *scal, const v2f *cw, int chained) {
   return hop32::launch_hopping_dot(ctx, ieo, out, in, p, dotv, cre, cim, npartials, mode, resid, scal, cw, chained);
 }
-int tmhip_comm_quiesce(tmhip_ctx *ctx) {
-  if (!ctx->comm_ready || !ctx->ahead_seq || ctx->quiesced_seq == ctx->ahead_seq) return 0;   // (keyed on the sequence number: ahead_field may have been given up while the exchange is still on its way)
-  hipLaunchKernelGGL(hop64::flag_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->sync_flags + 1, ctx->ahead_seq, ctx->sync_flags + 2, ctx->flag_timeout_ticks);
-  TMHIP_CHECK(hipGetLastError());
-  ctx->quiesced_seq = ctx->ahead_seq;
-  return 0;
-}
 bool tmhip_hopping_self_alpha_ok(const tmhip_ctx *ctx) {
   return hop64::use_split4(ctx) && ctx->opt_recon != 12 && ctx->Vh % 64 == 0 && ctx->Vh / 64 <= ctx->max_partials / 2;
 }

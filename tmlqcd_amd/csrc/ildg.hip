@@ -316,7 +316,6 @@ int sums_combine(tmhip_ctx *ctx, unsigned sums[2], bool any_nonzero = false) {
   if (!ctx->shm) TMHIP_NCCL_CHECK(ncclCommCount(ctx->comm_red, &n));
   if (n < 1 || n > ILDG_SLOTS) TMHIP_FAIL("sums_combine: %d ranks", n);
   TMHIP_CHECK(hipMemcpyAsync(ctx->io_sums, sums, 2 * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-  if (tmhip_comm_quiesce(ctx)) return 1;
   if (ctx->shm) { if (tmhip_shm_allgather(ctx, ctx->stream, ctx->io_sums, ctx->io_sums + 2, 2 * sizeof(unsigned))) return 1; }
   else TMHIP_NCCL_CHECK(ncclAllGather(ctx->io_sums, ctx->io_sums + 2, 2, ncclUint32, ctx->comm_red, ctx->stream));   // (io_sums holds 2 * ILDG_SLOTS words)
   std::vector<unsigned> h(2 * (size_t)n);

@@ -153,7 +153,6 @@ int tmhip_reduce_finish(tmhip_ctx *ctx, int nblocks, int parallel, double *out) 
     // MPI_Allreduce(..., MPI_SUM) of the reference (square_norm.c:314): one double over RCCL
     if (ctx->direct.on && ctx->direct.sums_on) { if (tmhip_direct_allreduce(ctx, ctx->result_dev)) return 1; }
     else {
-      if (tmhip_comm_quiesce(ctx)) return 1;
       if (ctx->shm) { if (tmhip_shm_allreduce(ctx, ctx->stream, ctx->result_dev, 1)) return 1; }
       else { TMHIP_NCCL_CHECK(ncclAllReduce(ctx->result_dev, ctx->result_dev, 1, ncclDouble, ncclSum, ctx->comm_red, ctx->stream)); }
     }

@@ -211,7 +211,6 @@ int tmhip_exchange_gauge_halo(tmhip_ctx *ctx) {
   v2d *first = raw, *last = raw + (size_t)(ctx->g.T - 1) * XYZ * 36;
   v2d *slab_up = raw + (size_t)ctx->V * 36, *slab_dn = slab_up + XYZ * 36;        // t = T, t = -1
   const int np = ctx->g.nproc_t, up = (ctx->g.proc_t + 1) % np, dn = (ctx->g.proc_t + np - 1) % np;
-  if (tmhip_comm_quiesce(ctx)) return 1;
   if (ctx->shm) return tmhip_shm_ring(ctx, ctx->stream, first, last, slab_up, slab_dn, n * sizeof(double));
   TMHIP_NCCL_CHECK(ncclGroupStart());
   TMHIP_NCCL_CHECK(ncclSend(first, n, ncclDouble, dn, ctx->comm_red, ctx->stream));    // our t = 0 is the down neighbour's t = T

@@ -134,11 +134,7 @@ struct tmhip_ctx {
   unsigned long long flag_timeout_ticks;           // bound of the device-side flag waits in ticks of the 100 MHz clock (0 = none)
   TmhipDirect direct;                              // the direct face carrier (off unless tmhip_comm_init_ipc / loopback 3)
   const void *prepacked;                           // the field whose boundary-slice projections sit in the send buffers (written by the last exterior kernel), or nullptr
-  // "split_pipe": sync_flags [3] boundary slices of the running stencil kernel stored (published by the last of their waves, counted in [4]),
-  // [5] exterior kernel of stencil n done (it runs on the comm stream).  ahead_field: the field whose faces have been exchanged AHEAD of the
-  // stencil that will gather it (complete once sync_flags[1] >= ahead_seq); bcount_total: waves counted in [4] so far
-  const void *ahead_field; unsigned int ahead_seq; unsigned int bcount_total;
-  unsigned int quiesced_seq;                       // the exchange ahead with this sequence number has been waited for on the compute stream (tmhip_comm_quiesce)
+  unsigned int bcount_total;                       // direct carrier: blocks of its pack kernels counted in sync_flags[4] so far (the count is cumulative, never reset)
   int last_ext_partials;                           // partial sums the last split-phase stencil's exterior kernel wrote in front of the stencil kernel's (0: it had none)
   // fermion-force accumulator (force.hip): double [2 parity][4 mu][8][Vh]
   double *deriv;
@@ -161,7 +157,6 @@ struct tmhip_ctx {
   int opt_direct_form;                                                  // direct carrier: -1 automatic (one kernel per stencil while the boundary waves fit the wait budget), 0 stencil + exterior kernel, 1 one kernel whenever the shape allows
   int opt_direct_sums;                                                  // 1 (default): with the direct carrier the scalar sums over the ranks travel the same way (tmhip_direct_allreduce) instead of ncclAllReduce
   int opt_direct_order;                                                 // direct carrier, one-kernel form: bit 0 / bit 1 = boundary time-slices FIRST for a stencil whose faces are packed now / were pushed ahead (else last)
-  int opt_split_pipe;                                                   // 1: boundary slices first, exterior kernel beside the stencil kernel, faces of a chain's next stencil exchanged ahead (hopping_impl.inc, launch_pipe)
   int opt_prepack;                                                      // 1 (default): the exterior kernel projects the faces of its output for the next stencil of a chain
   int opt_comm_split;                                                   // 0: do not split off a second communicator (exercises the one-communicator fallback)
   int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot, opt_cg_self;         // cg_her
@@ -186,12 +181,6 @@ static inline int tmhip_hop_block(const tmhip_ctx *ctx) { return ctx->opt_block 
 // Reductions go through RCCL on T-split ranks -- and in the one-rank RCCL loopback (tmhip_comm_set_loopback(ctx, 2)), so that the
 // multi-rank code path (partial sums, ncclAllReduce, scalar update as separate steps) runs in the single-GPU tests too.
 static inline bool tmhip_reduce_over_ranks(const tmhip_ctx *ctx) { return ctx->comm_ready && (ctx->g.nproc_t > 1 || ctx->loopback_rccl); }
-
-// "split_pipe": an exchange of faces AHEAD (comm stream) may still be in flight when the compute stream reaches an RCCL collective -- two
-// communicators at work at once, which RCCL allows only while every rank submits in the same order and the kernels can co-reside.  Called in
-// front of every compute-stream RCCL call: the compute stream first waits for the exchange ahead (a one-wave kernel, only when one is
-// outstanding), so that also with this option a face exchange is never in flight together with a collective of the compute stream.
-int tmhip_comm_quiesce(tmhip_ctx *ctx);
 
 // ---- host-staged shared-memory transport (xfer_shm.hip): stream-ordered ring exchange / sum / gather over the ranks of the node ----
 void tmhip_shm_destroy(tmhip_ctx *ctx);
@@ -240,8 +229,8 @@ enum { EPI_STORE = 0, EPI_TM_TIMES = 1, EPI_TM_SUB_G5 = 2, EPI_TM_SUB = 3, EPI_T
 // `comm`: 0 no halo exchange (Hopping_Matrix_nocom), HOP_COMM exchange the faces of `in` first, HOP_COMM | HOP_CHAINED additionally
 // promises that `in` is the output of this context's previous split-phase stencil and has not been written since (a composition
 // like Qtm_pm_psi, the stencils of a fused CG iteration): its faces were projected by that stencil's exterior kernel already
-// HOP_FEED: the caller expects the NEXT stencil of this context to gather this one's output ("split_pipe": its faces are then
-// projected and exchanged while this stencil is still running); a wrong guess costs one unused exchange, never a result
+// HOP_FEED: the caller expects the NEXT stencil of this context to gather this one's output (direct carrier: its faces are then
+// pushed into the neighbours' buffers by the waves that complete the boundary slices); a wrong guess costs one unused push, never a result
 enum { HOP_COMM = 1, HOP_CHAINED = 2, HOP_FEED = 4 };
 int tmhip_launch_hopping(tmhip_ctx *ctx, int ieo, v2d *out, const v2d *in, const v2d *p, int epi,
                          double cre, double cim, int comm, const v2d *cw = nullptr);

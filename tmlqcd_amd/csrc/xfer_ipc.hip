@@ -59,7 +59,7 @@ void point_at(tmhip_ctx *ctx, int which /* 0 up, 1 down */, char *base) {
 
 void reset_state(tmhip_ctx *ctx) {
   ctx->direct.push_seq = 0; ctx->direct.ahead_field = nullptr; ctx->direct.ahead_push = 0;
-  ctx->prepacked = nullptr; ctx->ahead_field = nullptr;
+  ctx->prepacked = nullptr;
 }
 
 }  // namespace

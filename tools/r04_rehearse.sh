@@ -1,6 +1,6 @@
 # the driver's N-rank command rehearsed on ONE GPU as real processes (the box admits six processes on its GPU):
 #   5 ranks (with the torchrun agent the six processes the box admits): configs[3] as 40 x 32^3 (T_local 8), headline 32^4 per rank; 4 ranks: configs[3] T_local 16, strong_32 T_local 8
-#   default (faces auto: host-staged ring first, then the direct carrier checked against it), split_pipe forced, direct carrier from the start
+#   default (faces auto: host-staged ring first, then the direct carrier checked against it), HIP events instead of flags (4 ranks), direct carrier from the start
 mkdir -p gpurun_out
 export TMLQCD_BENCH_TRACE=1
 run() {   # tag nranks env... -- args...
@@ -26,5 +26,5 @@ PY
   grep -c "gave up" gpurun_out/r04_bench_${tag}.err | sed 's/^/  give-ups: /'
 }
 run 5ranks_default 5 --
-run 4ranks_split_pipe 4 -- --opt split_pipe=2
+run 4ranks_events 4 -- --opt split_sync=1
 run 5ranks_ipc 5 TMLQCD_BENCH_TRANSPORT=ipc --

@@ -12,7 +12,7 @@ lat = Lattice(T, L, L, L, kappa=0.125, mu=0.01)
 lat.set_gauge(syn.gauge_field(1, T, L, L, L))
 f0 = lat.field(syn.spinor_field_eo(2, 0, T, L, L, L))
 f1, f2 = lat.field(), lat.field()
-for kv in os.environ.get("TL_OPTS", "").split(","):      # e.g. TL_OPTS=split_pipe=1
+for kv in os.environ.get("TL_OPTS", "").split(","):      # e.g. TL_OPTS=split_sync=1
     if "=" in kv:
         lat.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 if mode != "unsplit":
