@@ -626,11 +626,57 @@ def split_leg(R, args, L, Tg, what, steps, faces="comm"):
 WALL = {}        # wall seconds per leg of this rank's run (rank 0's go into the line)
 
 
+GUARDIAN = r"""
+import json, signal, sys
+signal.signal(signal.SIGTERM, signal.SIG_IGN); signal.signal(signal.SIGINT, signal.SIG_IGN); signal.signal(signal.SIGHUP, signal.SIG_IGN)
+saved, done = None, False
+for ln in sys.stdin:                      # ends when rank 0 does, however it ends
+    if ln.startswith("SAVE "):
+        saved = ln[5:]
+    elif ln.startswith("DONE"):
+        done = True
+if saved is not None and not done:
+    line = json.loads(saved)
+    line["faces_direct"] = {"ok": False, "error": "rank 0 ended during the direct-carrier legs; this is the line measured over the communicator before them"}
+    print(json.dumps(line), flush=True)
+"""
+
+
+class Guardian:
+    """The line measured over the communicator must survive whatever the direct-carrier legs behind it do to this process (a GPU fault
+    aborts it; a fault on another rank has the launcher end this one).  Rank 0 starts a small child BEFORE anything touches the GPU and
+    hands it the finished line in front of those legs; if rank 0 then ends without having printed its own line, the child prints the
+    saved one (marked `faces_direct.ok: false`) to the same stdout.  It never touches the GPU and ends with rank 0."""
+
+    def __init__(self, stdout_fd):
+        # a session of its own: torchrun ends a worker by signalling its whole process GROUP (SubprocessHandler.close: os.killpg)
+        self.p = subprocess.Popen([sys.executable, "-c", GUARDIAN], stdin=subprocess.PIPE, stdout=stdout_fd, text=True, start_new_session=True)
+
+    def _say(self, what):
+        try:
+            self.p.stdin.write(what + "\n")
+            self.p.stdin.flush()
+        except (OSError, ValueError):
+            pass
+
+    def save(self, line):
+        self._say("SAVE " + json.dumps(line))
+
+    def done(self):
+        self._say("DONE")
+        try:
+            self.p.stdin.close()
+            self.p.wait(timeout=10)
+        except Exception:
+            pass
+
+
 def rank_main(args, world, rank, local_rank):
     # stdout carries exactly ONE JSON line: RCCL prints a version banner to fd 1 when a communicator is
     # created, so everything before the final print goes to stderr.
     sys.stdout.flush()
     saved_stdout = os.dup(1)
+    guard = Guardian(saved_stdout) if (rank == 0 and (world > 1 or args.rehearse_split)) else None
     os.dup2(2, 1)
     R = Ranks(world, rank, local_rank, os.environ.get("TMLQCD_BENCH_FORCE_TORCH") == "1")
     import numpy as np   # noqa: F401 (the next-row legs)
@@ -926,6 +972,8 @@ def rank_main(args, world, rank, local_rank):
 
     def emit(line):
         line["wall_s"] = dict(WALL, total=time.perf_counter() - t_run)
+        if guard is not None:
+            guard.done()
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
@@ -944,6 +992,11 @@ def rank_main(args, world, rank, local_rank):
         dog = threading.Timer(budget, give_up)
         dog.daemon = True
         dog.start()
+        if guard is not None:
+            guard.save(dict(out, wall_s=dict(WALL, total=time.perf_counter() - t_run)))
+        fault = os.environ.get("TMLQCD_BENCH_TEST_FAULT", "")      # tests: a rank that dies in these legs (as a GPU fault would end it)
+        if (fault == "abort_direct" and rank == 0) or (fault == "abort_direct_peer" and rank == 1):
+            os.abort()
         os.environ.setdefault("TMLQCD_HIP_FLAG_TIMEOUT_S", "20")       # a neighbour that never pushes ends this attempt, not the run
         res = direct_legs(R, args, L, T, Tg if split_legs else 0, steps_s, f2_ref, dt)
         dog.cancel()

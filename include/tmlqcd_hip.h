@@ -362,7 +362,9 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "cg_sync" 1: host-side scalars as in the reference loop;  "cg_batch" n: iterations enqueued between two polls of `done`
  *   "gauge_cache" -1 (automatic) / 0 / 1: the 64-thread stencil launches of small unsplit lattices load the links with (0) or without (1) the
  *                  streaming hint; automatic = without while the gauge copy is <= 200 MB (it then stays in the Infinity Cache between calls)
- *   "swall_order" 0 / 1: block order of the owner-computes sw_all (one chunk per XCD / slab order, default)
+ *   "swall_order" 0 / 1 / 2: block order of the owner-computes sw_all (one chunk per XCD / slab order / sw_term's tile order, default: fabric reads
+ *                6.6 -> 4.0 GB per launch at 32^4, 3 % faster -- the kernel is bound by its 43 dependent 3x3 products per link, not by bytes;
+ *                profiles/r04_swall_ab.log)
  *   "swterm_order" 0 / 1: block order of sw_term (one chunk per XCD / small (x, y) tiles walked through all time-slices, default)
  * One option changes what is read from memory:
  * "gauge_recon" = 12 makes the twisted-mass stencil launches (fp64 and fp32) fetch only the first two rows of every link and

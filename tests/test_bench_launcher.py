@@ -106,3 +106,28 @@ def test_a_run_that_hangs_is_ended_and_reported():
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["value"] is None and "did not finish within 25 s" in rec["error"]
+
+
+def _guardian_child(ending):
+    """A stand-in for rank 0: hands the guardian a finished line, then ends the way `ending` says."""
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "g = bench.Guardian(1)\n"
+            "g.save({'metric': 'm', 'value': 5.0, 'faces': 'rccl'})\n"
+            "%s\n") % (ROOT, ending)
+    return subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, start_new_session=True)
+
+
+def test_guardian_prints_the_saved_line_when_rank_0_dies():
+    """bench.py's second-carrier phase: the communicator's line is handed to a child process first; rank 0 aborting (a GPU fault) or being
+    ended by the launcher (SIGTERM to its process group: another rank died) must leave exactly that line on stdout, marked as such."""
+    for ending in ("os.abort()", "os.killpg(os.getpgrp(), 15)"):      # (torchrun signals a worker's whole process group)
+        r = _guardian_child(ending)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode != 0 and len(lines) == 1, (ending, r.stdout, r.stderr[-500:])
+        rec = json.loads(lines[0])
+        assert rec["value"] == 5.0 and rec["faces"] == "rccl" and rec["faces_direct"]["ok"] is False and "rank 0 ended" in rec["faces_direct"]["error"]
+
+
+def test_guardian_stays_silent_when_rank_0_prints_its_own_line():
+    r = _guardian_child("g.done(); print('{\"own\": 1}', flush=True)")
+    assert r.returncode == 0 and [ln for ln in r.stdout.splitlines() if ln.startswith("{")] == ['{"own": 1}'], (r.stdout, r.stderr[-500:])

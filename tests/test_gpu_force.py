@@ -196,7 +196,54 @@ def test_clover_force_chain_against_oracle(dims, mu):
     lat.close()
 
 
-@pytest.mark.parametrize("T,L,world", [(2, 4, 2), (4, 4, 2), (2, 6, 3), (4, 8, 2)])
+def test_clover_force_and_clover_term_block_orders():
+    """The block orders of the two plaquette-leaf kernels ("swall_order" 0 chunk / 1 slab / 2 tile (default) / 8 wider tiles, "swterm_order"
+    0 / 1) on a lattice whose shape admits all of them (a 64-site block = whole z-rows of one (t, x) row): the order only changes
+    which XCD computes a block, so the results must be bit-identical to each other -- and agree with the oracle."""
+    from oracle.oraclebind import Oracle
+    from tmlqcd_amd import Lattice
+    T, LX, LY, LZ = 4, 16, 8, 16
+    kappa, c_sw, mu, theta = 0.131, 1.37, 0.02, (1.0, 0.5, -0.25, 0.125)
+    orc = Oracle(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta, threads=8)
+    lat = Lattice(T, LX, LY, LZ, kappa=kappa, mu=mu, theta=theta)
+    g = random_gauge(301, orc.VPR)
+    orc.set_gauge(g); lat.set_gauge(g)
+    sw = orc.sw_term(kappa, c_sw); swi, _ = orc.sw_invert(sw, 0, mu)
+    orc.set_clover(sw, swi)
+    got = []
+    for order in (0, 1):
+        lat.set_option("swterm_order", order)
+        lat.sw_term(g, kappa, c_sw)
+        got.append(lat.get_clover(True, False)[0])
+    assert np.array_equal(got[0], got[1]) and rel_err(got[1], sw) < TOL
+    lat.sw_invert(0, mu)
+    N, V = orc.Vh, orc.V
+    fh = [random_spinor(310 + i, N) for i in range(4)]
+    fo = []
+    for a in fh:
+        b = orc.new_field(); b[:N] = a; fo.append(b)
+    fd = [lat.field(a) for a in fh]
+    swm, swp = np.zeros((V, 4, 3, 3, 2)), np.zeros((V, 4, 3, 3, 2))
+    orc.sw_spinor_eo(0, swm, swp, fo[2], fo[3], 0.7); orc.sw_spinor_eo(1, swm, swp, fo[0], fo[1], 0.7); orc.sw_deriv(0, swm, swp, mu)
+    lat.swpm_zero()
+    lat.sw_spinor_eo(0, fd[2], fd[3], 0.7); lat.sw_spinor_eo(1, fd[0], fd[1], 0.7); lat.sw_deriv(0, mu)
+    ref = np.zeros((orc.VPR, 4, 8)); orc.sw_all(ref, swm, swp, kappa, c_sw)
+    first = None
+    for order in (0, 1, 2, 8):
+        lat.set_option("swall_order", order)
+        lat.derivative_zero()
+        lat.sw_all(kappa, c_sw)
+        d = lat.derivative()
+        assert rel_err(d, ref[:V]) < 4 * TOL, order
+        if first is None:
+            first = d
+        assert np.array_equal(d, first), order
+    with pytest.raises(Exception):
+        lat.set_option("swall_order", 3)
+    lat.close()
+
+
+@pytest.mark.parametrize("T,L,world", [(2, 4, 2), (4, 4, 2), (2, 6, 3), (4, 8, 2), (4, 16, 2)])      # (4, 16, 2): the interior launch runs in tile order
 def test_clover_force_on_two_t_slabs(T, L, world):
     """sw_all on T-split ranks: the leaves next to the t-faces reach links of BOTH ring neighbours (the two-sided derivative halo
     of xchange_deri.c).  Two contexts holding the two halves of the lattice (own sw_term / sw_invert from halo links, site-local

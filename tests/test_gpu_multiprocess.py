@@ -16,14 +16,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(nranks, extra=(), **more_env):
+def _bench(nranks, extra=(), rc_ok=True, **more_env):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(TMLQCD_BENCH_TRANSPORT="shm", HSA_ENABLE_IPC_MODE_LEGACY="0", TMLQCD_HIP_FLAG_TIMEOUT_S="60")
     env.update(more_env)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--L", "16", "--steps", "20", "--warmup", "2", "--cg-iters", "20",
            "--no-cpu", "--no-rows"] + list(extra)
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert (r.returncode == 0) == (rc_ok is True), r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     return json.loads(lines[0]), r.stderr
@@ -52,6 +52,17 @@ def test_bench_runs_as_n_processes_and_agrees_with_the_unsplit_lattice(nranks):
         s32 = rec["strong_32"]
         assert s32["rank_check"]["ok"] is True, s32
     assert rec["cg"]["iters_per_s"] > 0 and abs(rec["hermiticity_rel_dev"]) < 1e-12
+
+
+@pytest.mark.parametrize("who", ["abort_direct", "abort_direct_peer"])
+def test_bench_line_survives_a_rank_dying_in_the_direct_legs(who):
+    """The second-carrier phase of `bench.py --gpus N` must not be able to cost the line measured over the communicator: rank 0
+    (or rank 1, whereupon the launcher ends rank 0) aborts at the head of the direct legs, as a GPU fault would end it -- the run
+    fails, and its ONE line is the communicator's, complete, with `faces_direct.ok: false` (rank 0's guardian process prints it)."""
+    rec, err = _bench(2, rc_ok=False, TMLQCD_BENCH_TEST_FAULT=who)
+    assert rec["value"] and rec["value"] > 0 and rec["n_ranks"] == 2 and rec["rank_check"]["ok"] is True
+    assert rec["faces"] != "direct" and rec["faces_direct"]["ok"] is False and "rank 0 ended" in rec["faces_direct"]["error"]
+    assert rec["cg"]["iters_per_s"] > 0 and rec["strong"]["value"] > 0 and "total" in rec["wall_s"]
 
 
 def test_bench_with_the_direct_carrier_from_the_start():

@@ -994,7 +994,7 @@ static int sw_all_launch(tmhip_ctx *ctx, double kappa, double c_sw) {
   if (ie > ib && (!split || ctx->g.T > 2)) {
     const SwFastLd ld{ctx->gauge, (unsigned)ctx->gs, ctx->sw_ins, (unsigned)ctx->V, ctx->g.T, ctx->g.LX, ctx->g.LY, ctx->g.LZ, ctx->Vh};
     int chunk = ((ie - ib + 63) / 64 + 7) / 8, slab = 0, nbt = 0, grid = chunk * 16;
-    if (ctx->opt_swall_order != 0 && ctx->face % 64 == 0 && ctx->face / 64 >= 8) {      // default: slab order (32^4: 1.92 vs 2.01 ms)
+    if (ctx->opt_swall_order != 0 && ctx->face % 64 == 0 && ctx->face / 64 >= 8) {      // slab order (32^4: 1.92 vs 2.01 ms); fallback of the tile order
       nbt = ctx->face / 64; slab = (nbt + 7) / 8;
       grid = 8 * slab * ((ie - ib) / ctx->face) * 2;
     }

@@ -154,7 +154,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
     if (e && *e) { char *end = nullptr; const double v = strtod(e, &end); if (end != e && v >= 0.0) sec = v; }
     ctx->flag_timeout_ticks = (unsigned long long)(sec * 1.0e8);
   }
-  ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_recon = 0; ctx->opt_swall_order = 1; ctx->opt_swterm_order = 1; ctx->opt_gauge_cache = -1;
+  ctx->opt_stg = 1; ctx->opt_stg32 = 0; ctx->opt_hopsplit = -1; ctx->opt_occ32 = 0; ctx->opt_recon = 0; ctx->opt_swall_order = 2; ctx->opt_swterm_order = 1; ctx->opt_gauge_cache = -1;
   ctx->gauge_recon_dev = -1.0;
   TMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   {  // boundary pipeline (pack, exchange, boundary kernels) must not queue behind the interior kernel's blocks

@@ -160,7 +160,7 @@ struct tmhip_ctx {
   int opt_prepack;                                                      // 1 (default): the exterior kernel projects the faces of its output for the next stencil of a chain
   int opt_comm_split;                                                   // 0: do not split off a second communicator (exercises the one-communicator fallback)
   int opt_cg_sync, opt_cg_batch, opt_cg_fused_dot, opt_cg_self;         // cg_her
-  int opt_swall_order;                                                  // block order of the owner-computes sw_all: 0 one contiguous chunk per XCD, 1 slab order
+  int opt_swall_order;                                                  // block order of the owner-computes sw_all: 0 one contiguous chunk per XCD, 1 slab order, 2 tile order (default; 4 / 8: x-planes per tile)
   int opt_swterm_order;                                                 // block order of sw_term: 0 one contiguous chunk per XCD, 1 (default) tiles walked through all time-slices
   double gauge_recon_dev;   // max |U_row2 - conj(row0 x row1)| over all links of the resident gauge field (-1: not measured)
 };
