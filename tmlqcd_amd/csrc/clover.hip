@@ -631,31 +631,39 @@ __global__ __launch_bounds__(256) void sw_pack_slabs_kernel(v2d *__restrict__ ou
 // advances, so a link comes in once per tile that owns or borders it.  tb = 0: the plain order.
 // The four plaquette leaves around x in the (k, l) plane (clover_term.c:104-154), two at a time: A = the leaves in the +k+l and -k+l
 // quadrants, B = those in -k-l and +k-l.  Q is set (init) or added to.
+// A link that two consecutive leaves share is loaded ONCE and carried in registers (U_l(x) within A, U_l(x-l) within B, U_k(x-k) from A to
+// B: 13 link loads per plane instead of 16: 0.88 -> 0.82 ms at 32^4.  Carrying U_k(x) from the first leaf to the last as well (12 loads, +10
+// VGPRs) or dropping the scheduling barriers measured the same within noise, profiles/r04_swterm_ab.log; counters: the texture addressers are
+// busy 79 % of the kernel, the fp64 VALUs 52 %, at two waves per SIMD).
 template <class LD>
-__device__ __forceinline__ void sw_leaves_a(M3 &Q, const LD &ld, const SwSite &x, int par, int k, int l, bool init) {
+__device__ __forceinline__ void sw_leaves_a(M3 &Q, const LD &ld, const SwSite &x, int par, int k, int l, bool init, M3 *carry = nullptr) {
   const int opp = 1 - par;
   const SwSite xmk = sw_shift(x, k, -1);
   const typename LD::Loc l0 = ld.locate(x), lpk = ld.locate(sw_shift(x, k, 1)), lpl = ld.locate(sw_shift(x, l, 1)), lmk = ld.locate(xmk), lplmk = ld.locate(sw_shift(xmk, l, 1));
   M3 v1, v2;
+  const M3 ulx = ld.link(l0, par, l);
   v1 = m3_mulf<false, false>(ld.link(l0, par, k), ld.link(lpk, opp, l));
-  v2 = m3_mulf<false, false>(ld.link(l0, par, l), ld.link(lpl, opp, k));
+  v2 = m3_mulf<false, false>(ulx, ld.link(lpl, opp, k));
   if (init) Q = m3_mulf<false, true>(v1, v2); else m3_acc(Q, m3_mulf<false, true>(v1, v2));
   SWT_STEP();
-  v1 = m3_mulf<false, true>(ld.link(l0, par, l), ld.link(lplmk, par, k));
-  v2 = m3_mulf<true, false>(ld.link(lmk, opp, l), ld.link(lmk, opp, k));
+  v1 = m3_mulf<false, true>(ulx, ld.link(lplmk, par, k));
+  const M3 ukm = ld.link(lmk, opp, k);
+  v2 = m3_mulf<true, false>(ld.link(lmk, opp, l), ukm);
   m3_acc(Q, m3_mulf<false, false>(v1, v2));
+  if (carry) *carry = ukm;
 }
 template <class LD>
-__device__ __forceinline__ void sw_leaves_b(M3 &Q, const LD &ld, const SwSite &x, int par, int k, int l, bool init) {
+__device__ __forceinline__ void sw_leaves_b(M3 &Q, const LD &ld, const SwSite &x, int par, int k, int l, bool init, const M3 *carry = nullptr) {
   const int opp = 1 - par;
   const SwSite xmk = sw_shift(x, k, -1);
   const typename LD::Loc l0 = ld.locate(x), lmk = ld.locate(xmk), lml = ld.locate(sw_shift(x, l, -1)), lmkml = ld.locate(sw_shift(xmk, l, -1)), lpkml = ld.locate(sw_shift(sw_shift(x, k, 1), l, -1));
   M3 v1, v2;
-  v1 = m3_mulf<false, false>(ld.link(lmkml, par, l), ld.link(lmk, opp, k));
-  v2 = m3_mulf<false, false>(ld.link(lmkml, par, k), ld.link(lml, opp, l));
+  v1 = m3_mulf<false, false>(ld.link(lmkml, par, l), carry ? *carry : ld.link(lmk, opp, k));
+  const M3 ulm = ld.link(lml, opp, l);
+  v2 = m3_mulf<false, false>(ld.link(lmkml, par, k), ulm);
   if (init) Q = m3_mulf<true, false>(v1, v2); else m3_acc(Q, m3_mulf<true, false>(v1, v2));
   SWT_STEP();
-  v1 = m3_mulf<true, false>(ld.link(lml, opp, l), ld.link(lml, opp, k));
+  v1 = m3_mulf<true, false>(ulm, ld.link(lml, opp, k));
   v2 = m3_mulf<false, true>(ld.link(lpkml, par, l), ld.link(l0, par, k));
   m3_acc(Q, m3_mulf<false, false>(v1, v2));
 }
@@ -694,9 +702,12 @@ __global__ __launch_bounds__(256, LD::min_blocks == 1 ? 1 : SWT_MINW) void sw_te
   M3 Q;
   int k, l;
   plane_kl(w, k, l);
-  sw_leaves_a(Q, ld, x, par, k, l, true);
-  SWT_STEP();
-  sw_leaves_b(Q, ld, x, par, k, l, false);
+  {
+    M3 ukm;
+    sw_leaves_a(Q, ld, x, par, k, l, true, &ukm);
+    SWT_STEP();
+    sw_leaves_b(Q, ld, x, par, k, l, false, &ukm);
+  }
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll

@@ -10,7 +10,7 @@ for (T, L) in ((32, 32), (96, 48)) if "--big" in sys.argv else ((32, 32),):
     lat.momenta_upload(np.zeros((lat.V, 4, 8)))
     lat.update_gauge(0.0)
     ref = None
-    for order in (0, 1, 0, 1):
+    for order in [int(o) for o in os.environ.get("SWTERM_ORDERS", "0,1,0,1").split(",")]:
         lat.set_option("swterm_order", order)
         lat.sw_term(None, 0.125, 1.5); lat.sync()
         t0 = time.perf_counter()
