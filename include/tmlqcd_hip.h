@@ -360,8 +360,9 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "cg_self" 1 (default) | 0: small unsplit lattices (the hop-split stencil) -- the fused CG iteration adds up its partial sums inside the residual stencil
  *                (alpha) and the (P, p) kernel (stopping test, beta) instead of two one-block sum + scalar kernels in between
  *   "cg_sync" 1: host-side scalars as in the reference loop;  "cg_batch" n: iterations enqueued between two polls of `done`
- *   "gauge_cache" -1 (automatic) / 0 / 1: the 64-thread stencil launches of small unsplit lattices load the links with (0) or without (1) the
- *                  streaming hint; automatic = without while the gauge copy is <= 200 MB (it then stays in the Infinity Cache between calls)
+ *   "gauge_cache" -1 (automatic) / 0 / 1: the 64-thread stencil launches of small unsplit lattices, and the stencil launches of a T-split rank,
+ *                  load the links with (0) or without (1) the streaming hint; automatic = without while the gauge copy is <= 200 MB (it then
+ *                  stays in the Infinity Cache between calls: 4 x 32^3 per rank 65 -> 80 % of the unsplit rate, profiles/r04_gcache_ab.log)
  *   "swall_order" 0 / 1 / 2: block order of the owner-computes sw_all (one chunk per XCD / slab order / sw_term's tile order, default: fabric reads
  *                6.6 -> 4.0 GB per launch at 32^4, 3 % faster -- the kernel is bound by its 43 dependent 3x3 products per link, not by bytes;
  *                profiles/r04_swall_ab.log)
