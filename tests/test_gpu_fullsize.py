@@ -186,3 +186,38 @@ def test_t_split_32x64_over_two_contexts_full_size():
             f.free()
     for lat in lats:
         lat.close()
+
+
+def test_direct_carrier_with_48_cubed_faces():
+    """One rank's share of BASELINE configs[4] (48^3 x 96 over 8 GPUs: 12 x 48^3) over the direct carrier onto itself: 1728 boundary
+    waves per launch -- the largest faces the one-kernel form takes (twisted-mass kernels; the clover epilogues fall back to stencil +
+    exterior kernel at this size) -- against the same library's unsplit lattice, which is pinned against the oracle above: the plain
+    stencil, a chain, the benchmark loop (faces pushed ahead), the fused CG and the clover operator."""
+    from tmlqcd_amd import Lattice
+    from tmlqcd_amd import synthetic as syn
+    T, L = 12, 48
+    kappa, mu, c_sw = 0.125, 0.01, 1.5
+    gauge = syn.gauge_field(61, T, L, L, L)
+    k0, k1 = syn.spinor_field_eo(62, 0, T, L, L, L), syn.spinor_field_eo(63, 1, T, L, L, L)
+    out = {}
+    for split in (False, True):
+        lat = Lattice(T, L, L, L, kappa=kappa, mu=mu)
+        lat.set_gauge(gauge)
+        if split:
+            lat.set_loopback(3)
+        lat.sw_term(gauge, kappa, c_sw); lat.sw_invert(0, mu)
+        d0, d1, a, b = lat.field(k0), lat.field(k1), lat.field(), lat.field()
+        res = []
+        lat.Hopping_Matrix(0, a, d1); res.append(a.download())
+        lat.Hopping_Matrix(1, b, d0); res.append(b.download())
+        lat.Qtm_pm_psi(a, d0); res.append(a.download())
+        lat.bench_hopping(d1, a, b, 5); res.append(a.download()); res.append(b.download())
+        lat.op("Qsw_pm_psi", a, d0); res.append(a.download())
+        x = lat.field(); x.zero()
+        it, hist = lat.cg_her(x, d0, 12, 1e-30, 1, lat.Vh)
+        res.append(x.download())
+        out[split] = (res, hist)
+        lat.close()
+    for i, (u, s) in enumerate(zip(out[False][0], out[True][0])):
+        assert rel_err(s, u) < TOL, i
+    assert np.allclose(out[True][1], out[False][1], rtol=1e-10)
