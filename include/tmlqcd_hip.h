@@ -344,7 +344,7 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *   "direct_form" -1 (default) | 0 | 1: the direct carrier (tmhip_comm_init_ipc) -- 1: one kernel per stencil (the boundary waves wait for their
  *                neighbour's word after their seven local hops, add the hop across the cut, project their output and store the projection into the
  *                neighbour's buffer); 0: stencil kernel + exterior kernel (which waits and pushes); -1: one kernel while the boundary waves of a
- *                launch are at most 2048 (clover epilogues: 512; ranks sharing a GPU in a rehearsal: 1024 / their number)
+ *                launch are at most 2048 (fp64 clover epilogues: 1792; ranks sharing a GPU in a rehearsal: 1024 / their number)
  *   "direct_sums" 1 (default) | 0 (before tmhip_comm_init_ipc): with the direct carrier every rank maps every rank's block and the scalar sums
  *                over the ranks (square_norm .. with parallel = 1, the alpha and the stopping test of cg_her) are one wave that stores this
  *                rank's partial sum into every rank's block and adds up its own row in rank order (the same bits on every rank) instead

@@ -88,6 +88,9 @@ def main(argv):
                 epi = int(g[0]) if g else -1
                 ragged = len(g) > 1 and g[1] == "2"
                 floor = 1 if (epi in CLOVER_EPI or ragged) else 3
+                # the one-kernel form of the direct carrier sizes its wait budget on two waves per SIMD for the clover epilogues (direct_one_kernel)
+                if epi in CLOVER_EPI and len(g) > 1 and g[1] == "3":
+                    floor = 2
                 tag = "%s (>= %d waves)" % (what, floor)
                 break
         scratch, occ = k.get("ScratchSize [bytes/lane]", -1), k.get("Occupancy [waves/SIMD]", -1)
