@@ -330,8 +330,9 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  * them changes a result beyond rounding (reduction order, FMA contraction); unknown names are refused.
  * TMLQCD_HIP_OPTIONS="name=value,name=value" in the environment applies them when the context is created (executables linked against
  * the drop-in unmodified); a malformed or unknown entry fails tmhip_create.
- *   "block" 0|256|64 threads per block (0: automatic, 64 on small local lattices)
- *   "xcd"   block order: 2 automatic (default; tile order up to L = 32, slab order above), 0 none, 1 one chunk per XCD,
+ *   "block" 0|256|64 threads per block (0: automatic, 64 on local lattices of fewer than 131072 sites per parity)
+ *   "xcd"   block order: 2 automatic (default; tile order up to L = 32, slab order above -- and on lattices of fewer than 24 time-slices
+ *           whose time-slices are large (L >= 24): one rank's share of a T split, profiles/r04_shape_sweep.log), 0 none, 1 one chunk per XCD,
  *           3 slab, 4 tile;  "tgrp" time-slices per tile group (0 = automatic)
  *   "occ" / "occ32"  waves per SIMD allowed by a dynamic-LDS cap for the fp64 / fp32 stencil (3 / 0 = no cap)
  *   "minw" 4: __launch_bounds__(BS, 4)

@@ -176,7 +176,7 @@ struct tmhip_ctx {
 // Threads per stencil block: "block" 0 (default) picks 64 for small local lattices -- below ~2 blocks of 256 per CU a launch is
 // latency-bound and four times as many independent blocks finish sooner (8^4: 5.7 vs 7.5 us, 12^4: 9.9 vs 14.1, 20^4: 25.3 vs
 // 33.0; level at 24^4, 256 ahead from there: profiles/r01_diagnostics.md) -- and 256 otherwise.
-static inline int tmhip_hop_block(const tmhip_ctx *ctx) { return ctx->opt_block ? ctx->opt_block : (ctx->Vh <= 131072 ? 64 : 256); }
+static inline int tmhip_hop_block(const tmhip_ctx *ctx) { return ctx->opt_block ? ctx->opt_block : (ctx->Vh < 131072 ? 64 : 256); }   // (8 x 32^3 = 131072 sites per parity: 256 threads + the LDS-staged kernel, 80.8 -> 75.2 us per {H_eo, H_oe} with the slab order; 4 x 32^3: 64 threads, 34.5 against 41.6)
 
 // Reductions go through RCCL on T-split ranks -- and in the one-rank RCCL loopback (tmhip_comm_set_loopback(ctx, 2)), so that the
 // multi-rank code path (partial sums, ncclAllReduce, scalar update as separate steps) runs in the single-GPU tests too.
