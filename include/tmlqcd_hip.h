@@ -351,7 +351,8 @@ int tmhip_event_elapsed_ms(tmhip_ctx *ctx, int slot_start, int slot_stop, double
  *                rank's partial sum into every rank's block and adds up its own row in rank order (the same bits on every rank) instead
  *                of an ncclAllReduce
  *   "direct_order" bit 0 / bit 1: one-kernel form -- boundary time-slices dispatched first (else last) in a stencil whose faces are packed now /
- *                were pushed ahead by the stencil before (default 2)
+ *                were pushed ahead by the stencil before (default 3: first in both; with the slab order of short lattices the boundary slices are
+ *                spread over all XCDs and going first is worth 2 - 3 % at T_local 8 / 16, profiles/r04_split_forms_ab.log)
  *   "prepack" 1 (default) | 0: T-split ranks -- the exterior kernel also projects the completed boundary slices of its output into the send buffers, so
  *                the next stencil of a chain (Qtm_pm_psi, a fused CG iteration) starts its exchange without a pack kernel
  *   "flag_timeout_ms" bound of those device-side waits (default 120 s, or TMLQCD_HIP_FLAG_TIMEOUT_S in the environment; 0 = none): a late

@@ -143,7 +143,7 @@ def test_loopback_split_path_matches(setup16, mode, split_sync, prepack, form):
         lat.set_loopback(0)
         lat.set_option("split_sync", 0)
         lat.set_option("prepack", 1)
-        lat.set_option("direct_form", -1); lat.set_option("direct_order", 2)
+        lat.set_option("direct_form", -1); lat.set_option("direct_order", 3)
     dk.free(); dl.free()
 
 

@@ -82,7 +82,7 @@ def _run(lat, seed, nops, split, gen=None, skew=None):
 
 FORMS = [("flags", {}), ("events", {"split_sync": 1}), ("no prepack", {"prepack": 0})]
 # loopback 3 = the direct carrier (faces stored by the producing waves into "the neighbour's" buffers): its own two forms
-DIRECT_FORMS = [("one kernel, boundary last / first", {"direct_form": 1, "direct_order": 2}), ("one kernel, boundary first / last", {"direct_form": 1, "direct_order": 1}),
+DIRECT_FORMS = [("one kernel", {"direct_form": 1}), ("one kernel, boundary last / first", {"direct_form": 1, "direct_order": 2}), ("one kernel, boundary first / last", {"direct_form": 1, "direct_order": 1}),
                 ("stencil + exterior kernel", {"direct_form": 0})]
 def forms_of(loopback):
     return DIRECT_FORMS if loopback == 3 else FORMS

@@ -146,7 +146,7 @@ int tmhip_create(const tmhip_geom *geom, int device, tmhip_ctx **out) {
   ctx->ns = (ctx->Vh + 63) / 64 * 64; ctx->gs = ctx->ns;
   ctx->VPR = ctx->V + (g.nproc_t > 1 ? 2 * g.LX * g.LY * g.LZ : 0);
   ctx->opt_block = 0; ctx->opt_xcd = 2; ctx->opt_minw = 0; ctx->opt_occ = 3; ctx->opt_cg_sync = 0;
-  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_direct_form = -1; ctx->opt_direct_order = 2; ctx->opt_direct_sums = 1;
+  ctx->opt_cg_batch = 4; ctx->opt_cg_fused_dot = 2; ctx->opt_cg_self = 1; ctx->opt_comm_split = 1; ctx->opt_split_sync = 0; ctx->opt_prepack = 1; ctx->opt_direct_form = -1; ctx->opt_direct_order = 3; ctx->opt_direct_sums = 1;
   {
     // bound of the device-side waits for the neighbours' faces: TMLQCD_HIP_FLAG_TIMEOUT_S in the environment (0 = none), default 120 s
     double sec = 120.0;
