@@ -35,6 +35,9 @@ RULES = [
     (r"^void hop32::hop_kernel<(\d+), ([0123]), true, (64|256), 1, (-1|-2), 0>", "fp32 gather"),
     (r"^void hop32::hop_exterior_kernel<(\d+), true>", "fp32 exterior"),
     (r"^void hop32::pack_faces_kernel", "fp32 pack"),
+    # the two plaquette-leaf kernels of the clover rows (interior instances): 230 - 254 VGPRs by design, two waves per SIMD, no scratch
+    (r"^void sw_term_kernel<SwFastLd>", "sw_term", 2),
+    (r"^void sw_all_gather_kernel<SwFastLd>", "sw_all gather", 2),
 ]
 
 
@@ -81,8 +84,13 @@ def main(argv):
     bad, rows, guarded = [], [], 0
     for k in sorted(ks, key=lambda k: k["name"]):
         tag, floor = "", None
-        for rx, what in RULES:
+        for rule in RULES:
+            rx, what = rule[0], rule[1]
             m = re.match(rx, k["name"])
+            if m and len(rule) > 2:
+                floor = rule[2]
+                tag = "%s (>= %d waves)" % (what, floor)
+                break
             if m:
                 g = m.groups()
                 epi = int(g[0]) if g else -1
