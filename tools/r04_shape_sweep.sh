@@ -1,7 +1,6 @@
 # launch-shape options on the lattices of one rank's share of the BASELINE multi-GPU configs (unsplit kernels; the split kernels take the same
 # shapes): block 64 / 256 x block order 1 / 2 (automatic) / 3 / 4
 mkdir -p gpurun_out
-for shape in "${SHAPES[@]:-8 32}" ; do :; done
 for TL in "8 32" "12 48" "4 32" "16 32"; do
   set -- $TL; T=$1; L=$2
   for blk in 0 64 256; do
