@@ -19,12 +19,14 @@ for name, lb, opts in (("unsplit", 0, {}), ("default form (copies)", 1, {}), ("d
     if lb:
         lat.set_loopback(lb)
     a, b = lat.field(k), lat.field()
-    lat.op("Qsw_pm_psi", b, a); lat.sync()
+    for _ in range(int(os.environ.get("PWARM", "300"))):      # (the first lattice of a process otherwise pays the GPU's clock ramp: its numbers came out 10 - 25 % high)
+        lat.op("Qsw_pm_psi", b, a)
+    lat.sync()
     out = b.download()
     if ref is None:
         ref = out
     dev = np.abs(out - ref).max() / np.abs(ref).max()
-    n = 50
+    n = 200
     t0 = time.perf_counter()
     for _ in range(n):
         lat.op("Qsw_pm_psi", b, a)
