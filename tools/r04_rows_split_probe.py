@@ -17,8 +17,10 @@ def prep(lat, g, world, r):
     lat.swpm_zero(); lat.sw_spinor_eo(1, a, a, 0.5); lat.sw_spinor_eo(0, b, b, 0.5); lat.sw_deriv(0, mu); lat.derivative_zero()
 
 
-def timed(f, sync, n=10):
-    f(); sync()
+def timed(f, sync, n=20):
+    for _ in range(30):        # (warm: the first lattice of a process otherwise pays the GPU's clock ramp)
+        f()
+    sync()
     t0 = time.perf_counter()
     for _ in range(n):
         f()
