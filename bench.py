@@ -449,9 +449,17 @@ def comm_labels(R, S, faces):
             "ranks_sharing_a_gpu": sharers if direct else None}
 
 
+CALIBRATION_STEPS = int(os.environ.get("TMLQCD_BENCH_CALIBRATION_STEPS", "512"))
+
+
 def time_hopping(ph, R, lat, f0, f1, f2, steps, warmup, what="hopping"):
-    """warmup untimed steps, then exactly `steps` steps bracketed by a barrier + synchronisation on both sides (the closing one is
-    the step's own agreement all-reduce); max over ranks of (wall seconds, HIP-event ms)."""
+    """benchmark.c's calibration pass (benchmark.c:262-281: j_max = 512 applications of {H_eo, H_oe} before the measurement, which the
+    reference uses to size its timed loop and which leaves the machine in its steady state), then `warmup` untimed steps, then exactly
+    `steps` steps bracketed by a barrier + synchronisation on both sides (the closing one is the step's own agreement all-reduce); max over
+    ranks of (wall seconds, HIP-event ms).  The pass is reported in the line (`config.calibration_steps`); with five warm-up steps alone the
+    first timed launches of a fresh process run 2 % below the steady rate (profiles/r04_warmup_check.log)."""
+    if CALIBRATION_STEPS > 0:
+        ph.step(what + " calibration pass", lambda: (lat.bench_hopping(f0, f1, f2, CALIBRATION_STEPS), lat.sync()))
     ph.step(what + " warm-up", lambda: (lat.bench_hopping(f0, f1, f2, max(warmup, 1)), lat.sync()))
     ph.collective(lambda: R.barrier(lat))
 
@@ -942,6 +950,7 @@ def rank_main(args, world, rank, local_rank):
                                    "global %dx%d^3, fp64, kappa=0.125, periodic, random SU(3) gauge + Gaussian spinor"
                                    % (T, L, T * world, L),
                        "local_lattice": [T, L, L, L], "global_lattice": [T * world, L, L, L],
+                       "calibration_steps": CALIBRATION_STEPS,      # untimed, before the `warmup` steps: benchmark.c:262-281 (see time_hopping)
                        "parallelism": ("T-split ring of %d, half-spinor faces %s" % (world, "as direct stores into the neighbours' memory (ring: %s)" % R.ring if faces_a == "direct" else "over " + R.transport) if world > 1 else
                                        ("single GPU, split-phase path rehearsed with self-exchange (loopback %d)" % args.loopback
                                         if args.loopback else "single GPU"))},
